@@ -1,0 +1,145 @@
+"""ctypes binding of libi2v_hip.so (C ABI declared in include/i2v_hip.h).
+
+There is NO fallback: if the shared library is missing, or a kernel reports an error, the caller gets an
+exception.  Build the library with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libi2v_hip.so")
+ABI_VERSION = 1
+
+I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
+I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT = 0, 1, 2
+I2V_A_PLAIN, I2V_A_CONV3X3 = 0, 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("lda", C.c_int64),
+        ("a2", C.c_void_p), ("lda2", C.c_int64),
+        ("k_split", C.c_int32), ("a_mode", C.c_int32),
+        ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int64), ("rows_per_vec", C.c_int32),
+        ("c", C.c_void_p), ("ldc", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("epilogue", C.c_int32), ("store_mode", C.c_int32),
+        ("frames", C.c_int32), ("hw", C.c_int32),
+        ("vt_len", C.c_int32), ("vt_ld", C.c_int32),
+        ("out_scale", C.c_float),
+        ("n_img", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("cin", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_row_stride", C.c_int64), ("q_batch_stride", C.c_int64),
+        ("k", C.c_void_p), ("k_row_stride", C.c_int64), ("k_batch_stride", C.c_int64),
+        ("vt", C.c_void_p), ("vt_row_stride", C.c_int64), ("vt_batch_stride", C.c_int64),
+        ("o", C.c_void_p), ("o_row_stride", C.c_int64), ("o_batch_stride", C.c_int64),
+        ("batch_q", C.c_int32), ("kv_group", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+        ("lq", C.c_int32), ("lk", C.c_int32),
+        ("scale", C.c_float), ("accumulate", C.c_int32), ("acc_scale", C.c_float),
+    ]
+
+
+class TAttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_row_stride", C.c_int64),
+        ("k", C.c_void_p), ("k_row_stride", C.c_int64),
+        ("vt", C.c_void_p), ("vt_ld", C.c_int32),
+        ("o", C.c_void_p), ("o_row_stride", C.c_int64),
+        ("n_pixels", C.c_int32), ("frames", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
+class GnParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("c1", C.c_int32),
+        ("x2", C.c_void_p), ("c2", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("y", C.c_void_p),
+        ("n_img", C.c_int32), ("hw", C.c_int32), ("groups", C.c_int32), ("frames_per_stat", C.c_int32),
+        ("eps", C.c_float), ("silu", C.c_int32),
+        ("out_perm", C.c_int32), ("frames", C.c_int32),
+        ("workspace", C.c_void_p),
+    ]
+
+
+class LnParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("pe", C.c_void_p), ("ld_pe", C.c_int64), ("pe_period", C.c_int32),
+        ("y", C.c_void_p), ("ldy", C.c_int64),
+        ("rows", C.c_int32), ("C", C.c_int32),
+        ("eps", C.c_float),
+    ]
+
+
+# every symbol include/i2v_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "i2v_abi_version": (C.c_int, []),
+    "i2v_last_error": (C.c_char_p, []),
+    "i2v_gemm_f16": (C.c_int, [C.POINTER(GemmParams), _P]),
+    "i2v_attention_f16": (C.c_int, [C.POINTER(AttnParams), _P]),
+    "i2v_temporal_attention_f16": (C.c_int, [C.POINTER(TAttnParams), _P]),
+    "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "i2v_groupnorm_f16": (C.c_int, [C.POINTER(GnParams), _P]),
+    "i2v_layernorm_f16": (C.c_int, [C.POINTER(LnParams), _P]),
+    "i2v_nchw_to_tokens": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_tokens_to_nchw": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_timestep_embedding": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "i2v_silu_f16": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "i2v_repeat_rows_f16": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int32, _P]),
+    "i2v_copy3d_f16": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                 C.c_int64, _P]),
+    "i2v_ddim_prep": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libi2v_hip.so and bind every exported symbol.  Raises HipLibraryError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built.  Run `python __graft_entry__.py build` "
+            "(needs hipcc, cross-compiles gfx950 without a GPU).  There is no CPU fallback for this path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export `{name}` declared in include/i2v_hip.h") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.i2v_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"{LIB_PATH} has ABI version {v}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().i2v_last_error()
+        raise HipLibraryError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

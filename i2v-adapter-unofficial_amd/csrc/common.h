@@ -1,0 +1,62 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of libi2v_hip.so.
+// wave = 64 lanes; MFMA fragment layouts follow /opt/skills/guides/cdna_hip_programming.md section 3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/i2v_hip.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define I2V_WAVE 64
+
+// error plumbing (thread-local message, never throws / aborts across the ABI)
+void i2v_set_error(const char* fmt, ...);
+#define I2V_FAIL(code, ...)     \
+  do {                          \
+    i2v_set_error(__VA_ARGS__); \
+    return (code);              \
+  } while (0)
+#define I2V_CHECK_ARG(cond, ...) \
+  do {                           \
+    if (!(cond)) I2V_FAIL(I2V_ERR_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+
+int i2v_check_launch(const char* what);
+
+static inline int64_t i2v_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// D(16x16, f32) += A(16x32, f16) * B(32x16, f16)
+//   A fragment: lane l holds A[row = l & 15][k = 8 * (l >> 4) + j], j = 0..7
+//   B fragment: lane l holds B[k = 8 * (l >> 4) + j][col = l & 15]
+//   D fragment: lane l holds D[row = 4 * (l >> 4) + r][col = l & 15], r = 0..3
+__device__ __forceinline__ f32x4 mfma16x16x32(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ f16x8 ld_global_16B(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
+__device__ __forceinline__ f16x8 zero8() {
+  f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return z;
+}
+
+// XCD-aware block remap (guide T1, bijective form): blocks b and b+8 share an XCD/L2, so give each XCD a
+// contiguous run of logical tile ids.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  if (nwg < nx * 2) return bid;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

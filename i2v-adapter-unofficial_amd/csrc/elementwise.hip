@@ -1,0 +1,236 @@
+// Layout edges (NCHW <-> token-major), timestep embedding, SiLU, row repeat / 2-D copy, and the two halves of
+// the DDIM + classifier-free-guidance step that bracket the UNet call.  All pure HBM traffic.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_MAX_BLOCKS = 4096;
+
+inline int ew_blocks(int64_t n) {
+  const int64_t b = i2v_cdiv(n, 256);
+  return (int)(b < EW_MAX_BLOCKS ? (b < 1 ? 1 : b) : EW_MAX_BLOCKS);
+}
+
+template <bool SRC_F32>
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const void* __restrict__ src, f16* __restrict__ dst, int n,
+                                                             int c, int hw, int c_pad) {
+  const int64_t total = (int64_t)n * hw * c_pad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c_pad);
+    const int64_t t = i / c_pad;
+    const int p = (int)(t % hw);
+    const int64_t img = t / hw;
+    float v = 0.f;
+    if (ch < c) {
+      const int64_t s = (img * c + ch) * hw + p;
+      v = SRC_F32 ? reinterpret_cast<const float*>(src)[s] : (float)reinterpret_cast<const f16*>(src)[s];
+    }
+    dst[i] = (f16)v;
+  }
+}
+
+template <bool DST_F32>
+__global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const f16* __restrict__ src, int64_t ld, void* __restrict__ dst,
+                                                             int n, int c, int hw) {
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % hw);
+    const int64_t t = i / hw;
+    const int ch = (int)(t % c);
+    const int64_t img = t / c;
+    const f16 v = src[(img * hw + p) * ld + ch];
+    if (DST_F32)
+      reinterpret_cast<float*>(dst)[i] = (float)v;
+    else
+      reinterpret_cast<f16*>(dst)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, const int32_t* __restrict__ t_index,
+                                                                 f16* __restrict__ out, int n, int dim) {
+  const int half = dim / 2;
+  const int total = n * half;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int row = i / half, j = i - row * half;
+    const float tv = t_index ? t[*t_index] : t[row];
+    // freq_j = exp(-ln(10000) * j / half); embedding = [cos | sin]  (flip_sin_to_cos = True, shift 0)
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);
+    const float a = tv * freq;
+    out[(int64_t)row * dim + j] = (f16)cosf(a);
+    out[(int64_t)row * dim + half + j] = (f16)sinf(a);
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = (f16)silu_f((float)x[i]);
+}
+
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows_in,
+                                                          int64_t cols, int repeat) {
+  const int64_t total = rows_in * repeat * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols, cidx = i - r * cols;
+    y[i] = x[(r / repeat) * cols + cidx];
+  }
+}
+
+__global__ __launch_bounds__(256) void copy3d_kernel(const f16* __restrict__ src, int64_t sbs, int64_t ld_src,
+                                                     f16* __restrict__ dst, int64_t dbs, int64_t ld_dst, int64_t batches,
+                                                     int64_t rows, int64_t cols) {
+  const int64_t total = batches * rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t cidx = i % cols;
+    const int64_t t = i / cols;
+    const int64_t r = t % rows, b = t / rows;
+    dst[b * dbs + r * ld_dst + cidx] = src[b * sbs + r * ld_src + cidx];
+  }
+}
+
+// latents fp32 [b, f, c, hw]; cond fp32 [b, c, hw]; model_in fp16 [copies*b*f, hw, c_pad]
+__global__ __launch_bounds__(256) void ddim_prep_kernel(float* __restrict__ latents, const float* __restrict__ cond,
+                                                        f16* __restrict__ model_in, int b, int f, int c, int hw, int c_pad,
+                                                        int copies) {
+  const int64_t per_copy = (int64_t)b * f * hw * c_pad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_copy; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c_pad);
+    int64_t t = i / c_pad;
+    const int p = (int)(t % hw);
+    t /= hw;
+    const int fr = (int)(t % f);
+    const int bb = (int)(t / f);
+    float v = 0.f;
+    if (ch < c) {
+      const int64_t li = (((int64_t)bb * f + fr) * c + ch) * hw + p;
+      if (fr == 0) {
+        v = cond[((int64_t)bb * c + ch) * hw + p];
+        latents[li] = v;  // latents[:, 0] = condition_image_latents
+      } else {
+        v = latents[li];
+      }
+    }
+    const f16 hv = (f16)v;
+    for (int k = 0; k < copies; ++k) model_in[k * per_copy + i] = hv;
+  }
+}
+
+__global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ latents, const f16* __restrict__ np, int64_t ld_np,
+                                                        const float* __restrict__ coef, const int32_t* __restrict__ step_index,
+                                                        float guidance, int b, int f, int c, int hw, int copies) {
+  const int64_t total = (int64_t)b * f * c * hw;
+  const float* cf = coef + 4 * (int64_t)(*step_index);
+  const float sa_t = cf[0], sb_t = cf[1], sa_p = cf[2], sb_p = cf[3];
+  const int64_t bf = (int64_t)b * f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % hw);
+    int64_t t = i / hw;
+    const int ch = (int)(t % c);
+    const int64_t img = t / c;  // b * f + fr
+    float eps;
+    if (copies == 2) {
+      const float u = (float)np[(img * hw + p) * ld_np + ch];
+      const float cnd = (float)np[((bf + img) * hw + p) * ld_np + ch];
+      eps = u + guidance * (cnd - u);
+    } else {
+      eps = (float)np[(img * hw + p) * ld_np + ch];
+    }
+    const float x = latents[i];
+    const float x0 = (x - sb_t * eps) / sa_t;
+    latents[i] = sa_p * x0 + sb_p * eps;
+  }
+}
+
+__global__ void bump_step_kernel(int32_t* step_index) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step_index += 1;
+}
+
+}  // namespace
+
+extern "C" int i2v_nchw_to_tokens(const void* src, int32_t src_is_f32, void* dst, int32_t n, int32_t c, int32_t hw,
+                                  int32_t c_pad, i2v_stream_t stream) {
+  I2V_CHECK_ARG(src && dst && n > 0 && c > 0 && hw > 0 && c_pad >= c, "i2v_nchw_to_tokens: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)n * hw * c_pad;
+  if (src_is_f32)
+    hipLaunchKernelGGL(nchw_to_tokens_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, s, src,
+                       reinterpret_cast<f16*>(dst), n, c, hw, c_pad);
+  else
+    hipLaunchKernelGGL(nchw_to_tokens_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, s, src,
+                       reinterpret_cast<f16*>(dst), n, c, hw, c_pad);
+  return i2v_check_launch("i2v_nchw_to_tokens");
+}
+
+extern "C" int i2v_tokens_to_nchw(const void* src, int64_t ld, void* dst, int32_t dst_is_f32, int32_t n, int32_t c,
+                                  int32_t hw, i2v_stream_t stream) {
+  I2V_CHECK_ARG(src && dst && n > 0 && c > 0 && hw > 0 && ld >= c, "i2v_tokens_to_nchw: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)n * hw * c;
+  if (dst_is_f32)
+    hipLaunchKernelGGL(tokens_to_nchw_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, s,
+                       reinterpret_cast<const f16*>(src), ld, dst, n, c, hw);
+  else
+    hipLaunchKernelGGL(tokens_to_nchw_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, s,
+                       reinterpret_cast<const f16*>(src), ld, dst, n, c, hw);
+  return i2v_check_launch("i2v_tokens_to_nchw");
+}
+
+extern "C" int i2v_timestep_embedding(const float* t, const int32_t* t_index, void* out, int32_t n, int32_t dim,
+                                      i2v_stream_t stream) {
+  I2V_CHECK_ARG(t && out && n > 0 && dim > 0 && dim % 2 == 0, "i2v_timestep_embedding: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(ew_blocks((int64_t)n * dim / 2)), dim3(256), 0, s, t, t_index,
+                     reinterpret_cast<f16*>(out), n, dim);
+  return i2v_check_launch("i2v_timestep_embedding");
+}
+
+extern "C" int i2v_silu_f16(const void* x, void* y, int64_t n, i2v_stream_t stream) {
+  I2V_CHECK_ARG(x && y && n > 0, "i2v_silu_f16: bad arguments");
+  hipLaunchKernelGGL(silu_kernel, dim3(ew_blocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(x), reinterpret_cast<f16*>(y), n);
+  return i2v_check_launch("i2v_silu_f16");
+}
+
+extern "C" int i2v_repeat_rows_f16(const void* x, void* y, int64_t rows_in, int64_t cols, int32_t repeat,
+                                   i2v_stream_t stream) {
+  I2V_CHECK_ARG(x && y && rows_in > 0 && cols > 0 && repeat > 0, "i2v_repeat_rows_f16: bad arguments");
+  hipLaunchKernelGGL(repeat_rows_kernel, dim3(ew_blocks(rows_in * repeat * cols)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(x), reinterpret_cast<f16*>(y),
+                     rows_in, cols, repeat);
+  return i2v_check_launch("i2v_repeat_rows_f16");
+}
+
+extern "C" int i2v_copy3d_f16(const void* src, int64_t src_batch_stride, int64_t ld_src, void* dst,
+                              int64_t dst_batch_stride, int64_t ld_dst, int64_t batches, int64_t rows, int64_t cols,
+                              i2v_stream_t stream) {
+  I2V_CHECK_ARG(src && dst && batches > 0 && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols,
+                "i2v_copy3d_f16: bad arguments");
+  hipLaunchKernelGGL(copy3d_kernel, dim3(ew_blocks(batches * rows * cols)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), src_batch_stride, ld_src,
+                     reinterpret_cast<f16*>(dst), dst_batch_stride, ld_dst, batches, rows, cols);
+  return i2v_check_launch("i2v_copy3d_f16");
+}
+
+extern "C" int i2v_ddim_prep(float* latents, const float* cond, void* model_in, int32_t b, int32_t f, int32_t c,
+                             int32_t hw, int32_t c_pad, int32_t cfg_copies, i2v_stream_t stream) {
+  I2V_CHECK_ARG(latents && cond && model_in && b > 0 && f > 0 && c > 0 && hw > 0 && c_pad >= c,
+                "i2v_ddim_prep: bad arguments");
+  I2V_CHECK_ARG(cfg_copies == 1 || cfg_copies == 2, "i2v_ddim_prep: cfg_copies must be 1 or 2");
+  hipLaunchKernelGGL(ddim_prep_kernel, dim3(ew_blocks((int64_t)b * f * hw * c_pad)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), latents, cond, reinterpret_cast<f16*>(model_in), b, f, c, hw,
+                     c_pad, cfg_copies);
+  return i2v_check_launch("i2v_ddim_prep");
+}
+
+extern "C" int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, const float* coef,
+                                 int32_t* step_index, float guidance_scale, int32_t b, int32_t f, int32_t c, int32_t hw,
+                                 int32_t cfg_copies, i2v_stream_t stream) {
+  I2V_CHECK_ARG(latents && noise_pred && coef && step_index && b > 0 && f > 0 && c > 0 && hw > 0 && ld_np >= c,
+                "i2v_ddim_cfg_step: bad arguments");
+  I2V_CHECK_ARG(cfg_copies == 1 || cfg_copies == 2, "i2v_ddim_cfg_step: cfg_copies must be 1 or 2");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_blocks((int64_t)b * f * c * hw)), dim3(256), 0, s, latents,
+                     reinterpret_cast<const f16*>(noise_pred), ld_np, coef, step_index, guidance_scale, b, f, c, hw,
+                     cfg_copies);
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step_index);
+  return i2v_check_launch("i2v_ddim_cfg_step");
+}

@@ -1,0 +1,282 @@
+// GroupNorm(+SiLU) and LayerNorm(+positional embedding) on token-major fp16, fp32 statistics.  HBM-bound:
+// 16-byte vector loads over the (frames x H x W) token axis, wavefront shuffles for the row reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_ROWS_PER_CHUNK = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------- GroupNorm
+// pass 1: per (image, row-chunk, channel) partial sum / sum of squares.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
+                                                       int c2, int hw, float* __restrict__ partial) {
+  __shared__ float red[256 * 16];
+  const int C = c1 + c2, nvec = C / 8;
+  const int chunk = blockIdx.x, img = blockIdx.y, nchunk = gridDim.x;
+  const int row_begin = chunk * GN_ROWS_PER_CHUNK;
+  const int row_end = min(hw, row_begin + GN_ROWS_PER_CHUNK);
+  const int tid = threadIdx.x;
+  const int cols_per_pass = nvec < 256 ? nvec : 256;
+  const int rows_par = 256 / cols_per_pass;
+  const int col_lane = tid % cols_per_pass, row_lane = tid / cols_per_pass;
+  const bool active = row_lane < rows_par;
+  const int nv1 = c1 / 8;
+
+  for (int col0 = 0; col0 < nvec; col0 += cols_per_pass) {
+    const int col = col0 + col_lane;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (active && col < nvec) {
+      const f16* base;
+      int64_t ld;
+      int coff;
+      if (col < nv1) {
+        base = x1 + (int64_t)img * hw * c1;
+        ld = c1;
+        coff = col * 8;
+      } else {
+        base = x2 + (int64_t)img * hw * c2;
+        ld = c2;
+        coff = (col - nv1) * 8;
+      }
+      for (int r = row_begin + row_lane; r < row_end; r += rows_par) {
+        const f16x8 v = ld_global_16B(base + (int64_t)r * ld + coff);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          s[e] += f;
+          q[e] += f * f;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[tid * 16 + e] = s[e];
+      red[tid * 16 + 8 + e] = q[e];
+    }
+    __syncthreads();
+    if (row_lane == 0 && col < nvec) {
+      for (int rl = 1; rl < rows_par; ++rl) {
+        const int o = (rl * cols_per_pass + col_lane) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s[e] += red[o + e];
+          q[e] += red[o + 8 + e];
+        }
+      }
+      float* dst = partial + (((int64_t)img * nchunk + chunk) * C + col * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dst[2 * e] = s[e];
+        dst[2 * e + 1] = q[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: one wave per (stat group, channel group): mean / rstd, then per-(image, channel) scale & shift.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C, int groups,
+                                                         int fps, int hw, float eps, const f16* __restrict__ gamma,
+                                                         const f16* __restrict__ beta, float* __restrict__ coef) {
+  const int sg = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C / groups;
+  const int total = fps * nchunk * cpg;
+  float s = 0.f, q = 0.f;
+  for (int i = lane; i < total; i += 64) {
+    const int c = i % cpg, t = i / cpg;
+    const int ch = t % nchunk, f = t / nchunk;
+    const float* src = partial + ((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 2;
+    s += src[0];
+    q += src[1];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  const float cnt = (float)fps * (float)hw * (float)cpg;
+  const float mean = s / cnt;
+  float var = q / cnt - mean * mean;
+  var = var < 0.f ? 0.f : var;
+  const float rstd = rsqrtf(var + eps);
+  for (int i = lane; i < fps * cpg; i += 64) {
+    const int c = grp * cpg + i % cpg, f = i / cpg;
+    const float ga = (float)gamma[c] * rstd;
+    float* dst = coef + ((int64_t)(sg * fps + f) * C + c) * 2;
+    dst[0] = ga;
+    dst[1] = (float)beta[c] - mean * ga;
+  }
+}
+
+// pass 3: y = silu?(x * a + b), optional (b, f, p) -> (b, p, f) row permutation on store.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
+                                                       int c2, const float* __restrict__ coef, f16* __restrict__ y,
+                                                       int n_img, int hw, int silu, int out_perm, int frames) {
+  const int C = c1 + c2, nvec = C / 8, nv1 = c1 / 8;
+  const int64_t total = (int64_t)n_img * hw * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int col = (int)(idx % nvec);
+    const int64_t rowg = idx / nvec;
+    const int row = (int)(rowg % hw), img = (int)(rowg / hw);
+    f16x8 v;
+    if (col < nv1)
+      v = ld_global_16B(x1 + ((int64_t)img * hw + row) * c1 + col * 8);
+    else
+      v = ld_global_16B(x2 + ((int64_t)img * hw + row) * c2 + (col - nv1) * 8);
+    const float4* cf = reinterpret_cast<const float4*>(coef + ((int64_t)img * C + col * 8) * 2);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 ab = cf[e];  // (a, b) of channel 2e, (a, b) of channel 2e + 1
+      float r0 = (float)v[2 * e] * ab.x + ab.y;
+      float r1 = (float)v[2 * e + 1] * ab.z + ab.w;
+      if (silu) {
+        r0 = silu_f(r0);
+        r1 = silu_f(r1);
+      }
+      o[2 * e] = (f16)r0;
+      o[2 * e + 1] = (f16)r1;
+    }
+    int64_t orow = rowg;
+    if (out_perm) {
+      const int b = img / frames, f = img - b * frames;
+      orow = ((int64_t)b * hw + row) * frames + f;
+    }
+    *reinterpret_cast<f16x8*>(y + orow * C + col * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+// one wave per row; the row lives in registers (NV 16-byte vectors per lane) so the variance is an exact
+// second pass over registers.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const i2v_ln_params p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= p.rows) return;
+  const int nvec = p.C / 8;
+  const f16* x = reinterpret_cast<const f16*>(p.x) + (int64_t)row * p.ldx;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nvec) {
+      const f16x8 t = ld_global_16B(x + vi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (float)t[e];
+        s += v[i][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (lane + 64 * i < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+  const f16* gamma = reinterpret_cast<const f16*>(p.gamma);
+  const f16* beta = reinterpret_cast<const f16*>(p.beta);
+  const f16* pe = p.pe ? reinterpret_cast<const f16*>(p.pe) + (int64_t)(row % p.pe_period) * p.ld_pe : nullptr;
+  f16* y = reinterpret_cast<f16*>(p.y) + (int64_t)row * p.ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nvec) {
+      const f16x8 ga = ld_global_16B(gamma + vi * 8), be = ld_global_16B(beta + vi * 8);
+      f16x8 pv = zero8();
+      if (pe) pv = ld_global_16B(pe + vi * 8);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float r = (v[i][e] - mean) * rstd * (float)ga[e] + (float)be[e];
+        if (pe) r += (float)pv[e];
+        o[e] = (f16)r;
+      }
+      *reinterpret_cast<f16x8*>(y + vi * 8) = o;
+    }
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int64_t i2v_groupnorm_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels) {
+  const int64_t nchunk = i2v_cdiv(hw, GN_ROWS_PER_CHUNK);
+  return ((int64_t)n_img * nchunk * channels * 2 + (int64_t)n_img * channels * 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_groupnorm_f16: null params");
+  const i2v_gn_params& p = *pp;
+  const int C = p.c1 + p.c2;
+  I2V_CHECK_ARG(p.x && p.gamma && p.beta && p.y && p.workspace, "i2v_groupnorm_f16: null pointer");
+  I2V_CHECK_ARG(p.n_img > 0 && p.hw > 0 && p.c1 > 0 && p.c2 >= 0, "i2v_groupnorm_f16: bad sizes");
+  I2V_CHECK_ARG((p.c2 == 0) == (p.x2 == nullptr), "i2v_groupnorm_f16: x2 / c2 mismatch");
+  I2V_CHECK_ARG(p.c1 % 8 == 0 && p.c2 % 8 == 0, "i2v_groupnorm_f16: channel counts must be multiples of 8 (%d, %d)",
+                p.c1, p.c2);
+  I2V_CHECK_ARG(p.groups > 0 && C % p.groups == 0, "i2v_groupnorm_f16: channels %d not divisible by groups %d", C,
+                p.groups);
+  I2V_CHECK_ARG(p.frames_per_stat > 0 && p.n_img % p.frames_per_stat == 0,
+                "i2v_groupnorm_f16: n_img %d not divisible by frames_per_stat %d", p.n_img, p.frames_per_stat);
+  if (p.out_perm) I2V_CHECK_ARG(p.frames > 0 && p.n_img % p.frames == 0, "i2v_groupnorm_f16: bad frames for out_perm");
+  I2V_CHECK_ARG(al16(p.x) && al16(p.y) && (!p.x2 || al16(p.x2)) && al16(p.workspace) && al16(p.gamma) && al16(p.beta),
+                "i2v_groupnorm_f16: pointers must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nchunk = (int)i2v_cdiv(p.hw, GN_ROWS_PER_CHUNK);
+  float* partial = reinterpret_cast<float*>(p.workspace);
+  float* coef = partial + (int64_t)p.n_img * nchunk * C * 2;
+  const f16* x1 = reinterpret_cast<const f16*>(p.x);
+  const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(64), 0, s, partial, nchunk, C,
+                     p.groups, p.frames_per_stat, p.hw, p.eps, reinterpret_cast<const f16*>(p.gamma),
+                     reinterpret_cast<const f16*>(p.beta), coef);
+  const int64_t total = (int64_t)p.n_img * p.hw * (C / 8);
+  const int blocks = (int)(i2v_cdiv(total, 256) < 4096 ? i2v_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, x1, p.c1, x2, p.c2, coef,
+                     reinterpret_cast<f16*>(p.y), p.n_img, p.hw, p.silu, p.out_perm, p.frames);
+  return i2v_check_launch("i2v_groupnorm_f16");
+}
+
+extern "C" int i2v_layernorm_f16(const i2v_ln_params* pp, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_layernorm_f16: null params");
+  const i2v_ln_params& p = *pp;
+  I2V_CHECK_ARG(p.x && p.gamma && p.beta && p.y, "i2v_layernorm_f16: null pointer");
+  I2V_CHECK_ARG(p.rows > 0 && p.C > 0 && p.C % 8 == 0 && p.C <= 4096,
+                "i2v_layernorm_f16: C (%d) must be a multiple of 8 and <= 4096", p.C);
+  I2V_CHECK_ARG(p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.ldx >= p.C && p.ldy >= p.C, "i2v_layernorm_f16: bad ldx / ldy");
+  I2V_CHECK_ARG(al16(p.x) && al16(p.y) && al16(p.gamma) && al16(p.beta), "i2v_layernorm_f16: 16-byte alignment");
+  if (p.pe) I2V_CHECK_ARG(p.pe_period > 0 && p.ld_pe % 8 == 0 && al16(p.pe), "i2v_layernorm_f16: bad pe arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)i2v_cdiv(p.rows, 4)), block(256);
+  const int nv = (int)i2v_cdiv(p.C / 8, 64);
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL(ln_kernel<2>, grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(ln_kernel<3>, grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL(ln_kernel<5>, grid, block, 0, s, p); break;
+    case 6: hipLaunchKernelGGL(ln_kernel<6>, grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL(ln_kernel<7>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(ln_kernel<8>, grid, block, 0, s, p); break;
+  }
+  return i2v_check_launch("i2v_layernorm_f16");
+}

@@ -1,0 +1,162 @@
+// Temporal (motion-module) self-attention for gfx950: sequence = the <= 32 frames of ONE pixel, batch = B * H * W.
+//
+// Inside a motion module the token order is (b, pixel, frame) (the GroupNorm entry kernel writes it, the proj_out
+// GEMM epilogue undoes it), so a pixel's q / k rows are `frames` consecutive rows and its V^T block
+// [channel][frame] is contiguous.  Every q / k / v element is used by exactly one (pixel, head) problem, so
+// there is nothing to share: fragments go straight from global memory to registers (no LDS) and the kernel is
+// bound by HBM traffic (read q, k, v^T once, write o once).
+// One wave computes one (pixel, head): S^T[32 keys x 16 NQT queries] with 16x16x32 MFMAs over the head dim,
+// softmax over the keys with two wavefront shuffles, O^T = V^T P^T with one 16x16x32 MFMA per 16 channels
+// (the S^T accumulator is the B operand; key rows are permuted as in attention.hip so that a lane's 8 keys are
+// one contiguous 16-byte run of a V^T row).
+#include "common.h"
+
+namespace {
+
+template <int DQK, int DPV, int NQT>
+__global__ __launch_bounds__(256) void tattn_kernel(const i2v_tattn_params p, const float scale_log2, const int n_items) {
+  constexpr int KSTEPS = DQK / 32, DT = DPV / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int F = p.frames, d = p.head_dim, C = p.heads * p.head_dim;
+  const f16* __restrict__ Qb = reinterpret_cast<const f16*>(p.q);
+  const f16* __restrict__ Kb = reinterpret_cast<const f16*>(p.k);
+  const f16* __restrict__ Vb = reinterpret_cast<const f16*>(p.vt);
+  f16* __restrict__ Ob = reinterpret_cast<f16*>(p.o);
+
+  for (int item = blockIdx.x * 4 + wave; item < n_items; item += gridDim.x * 4) {
+    const int pix = item / p.heads, h = item - pix * p.heads;
+    const f16* Q = Qb + (int64_t)pix * F * p.q_row_stride + h * d;
+    const f16* K = Kb + (int64_t)pix * F * p.k_row_stride + h * d;
+    const f16* Vt = Vb + ((int64_t)pix * C + h * d) * p.vt_ld;
+
+    f32x4 sacc[2][NQT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int dd = 32 * s + 8 * g;
+      f16x8 qf[NQT], kf[2];
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) {
+        const int f = j * 16 + l15;
+        qf[j] = (f < F && dd < d) ? ld_global_16B(Q + (int64_t)f * p.q_row_stride + dd) : zero8();
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int f = 8 * (l15 >> 2) + 4 * kt + (l15 & 3);
+        kf[kt] = (f < F && dd < d) ? ld_global_16B(K + (int64_t)f * p.k_row_stride + dd) : zero8();
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int j = 0; j < NQT; ++j) sacc[kt][j] = mfma16x16x32(kf[kt], qf[j], sacc[kt][j]);
+    }
+
+    f16x8 pf[NQT];
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      float sv[2][4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 8 * g + 4 * kt + r;
+          const float v = key < F ? sacc[kt][j][r] * scale_log2 : -INFINITY;
+          sv[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv[kt][r] = __builtin_amdgcn_exp2f(sv[kt][r] - mx);
+          ls += sv[kt][r];
+        }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      const float inv = 1.0f / ls;
+      f16x8 pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pk[r] = (f16)(sv[0][r] * inv);
+        pk[4 + r] = (f16)(sv[1][r] * inv);
+      }
+      pf[j] = pk;
+    }
+
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int ch = i * 16 + l15;
+      f16x8 vf = zero8();
+      if (ch < d && 8 * g < F) {
+        vf = ld_global_16B(Vt + (int64_t)ch * p.vt_ld + 8 * g);
+        if (8 * g + 8 > F) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (8 * g + e >= F) vf[e] = (f16)0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) {
+        const f32x4 oacc = mfma16x16x32(vf, pf[j], f32x4{0.f, 0.f, 0.f, 0.f});
+        const int f = j * 16 + l15, dd = i * 16 + 4 * g;
+        if (f < F && dd < d) {
+          f16x4 ov = {(f16)oacc[0], (f16)oacc[1], (f16)oacc[2], (f16)oacc[3]};
+          *reinterpret_cast<f16x4*>(Ob + ((int64_t)pix * F + f) * p.o_row_stride + h * d + dd) = ov;
+        }
+      }
+    }
+  }
+}
+
+template <int DQK, int DPV>
+int launch_t(const i2v_tattn_params& p, hipStream_t s) {
+  const float scale_log2 = p.scale * 1.4426950408889634f;
+  const int64_t items64 = (int64_t)p.n_pixels * p.heads;
+  const int n_items = (int)items64;
+  int64_t blocks = i2v_cdiv(items64, 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (p.frames <= 16)
+    hipLaunchKernelGGL((tattn_kernel<DQK, DPV, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p, scale_log2, n_items);
+  else
+    hipLaunchKernelGGL((tattn_kernel<DQK, DPV, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p, scale_log2, n_items);
+  return i2v_check_launch("i2v_temporal_attention_f16");
+}
+
+inline bool al(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+extern "C" int i2v_temporal_attention_f16(const i2v_tattn_params* pp, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_temporal_attention_f16: null params");
+  const i2v_tattn_params& p = *pp;
+  I2V_CHECK_ARG(p.q && p.k && p.vt && p.o, "i2v_temporal_attention_f16: null pointer");
+  I2V_CHECK_ARG(p.n_pixels > 0 && p.heads > 0, "i2v_temporal_attention_f16: n_pixels / heads must be positive");
+  I2V_CHECK_ARG((int64_t)p.n_pixels * p.heads < (1ll << 31), "i2v_temporal_attention_f16: too many items");
+  I2V_CHECK_ARG(p.frames >= 1 && p.frames <= 32, "i2v_temporal_attention_f16: frames (%d) must be in [1, 32]", p.frames);
+  I2V_CHECK_ARG(p.head_dim > 0 && p.head_dim % 8 == 0 && p.head_dim <= 160,
+                "i2v_temporal_attention_f16: head_dim (%d) must be a multiple of 8 and <= 160", p.head_dim);
+  I2V_CHECK_ARG(p.q_row_stride % 8 == 0 && p.k_row_stride % 8 == 0 && p.o_row_stride % 4 == 0,
+                "i2v_temporal_attention_f16: row strides must be multiples of 8 (q, k) / 4 (o)");
+  I2V_CHECK_ARG(p.vt_ld % 8 == 0 && p.vt_ld >= ((p.frames + 7) / 8) * 8,
+                "i2v_temporal_attention_f16: vt_ld must be a multiple of 8 and >= frames rounded up to 8");
+  I2V_CHECK_ARG(al(p.q, 16) && al(p.k, 16) && al(p.vt, 16) && al(p.o, 8), "i2v_temporal_attention_f16: pointer alignment");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int d = p.head_dim;
+  if (d <= 16) return launch_t<32, 16>(p, s);
+  if (d <= 32) return launch_t<32, 32>(p, s);
+  if (d <= 48) return launch_t<64, 48>(p, s);
+  if (d <= 64) return launch_t<64, 64>(p, s);
+  if (d <= 80) return launch_t<96, 80>(p, s);
+  if (d <= 96) return launch_t<96, 96>(p, s);
+  if (d <= 128) return launch_t<128, 128>(p, s);
+  return launch_t<160, 160>(p, s);
+}

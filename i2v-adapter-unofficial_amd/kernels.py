@@ -1,0 +1,405 @@
+"""Tensor-level wrappers over the C ABI (include/i2v_hip.h).
+
+PyTorch is used only for device memory and the stream: every function validates its operands on the host
+(shape / dtype / contiguity, so a kernel never sees shapes its grid does not assume), allocates the output with
+torch.empty and launches the HIP kernel on torch's current stream through ctypes.  Nothing here computes with
+torch ops and nothing falls back to the CPU: a CPU tensor or a missing library raises.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (I2V_A_CONV3X3, I2V_A_PLAIN, I2V_EPI_GEGLU, I2V_EPI_GELU, I2V_EPI_NONE, I2V_STORE_ROWMAJOR,
+                   I2V_STORE_ROWPERM, I2V_STORE_VT, AttnParams, GemmParams, GnParams, HipLibraryError, LnParams,
+                   TAttnParams)
+
+f16 = torch.float16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=f16):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise HipLibraryError(f"{name} is on {t.device}: the I2V-Adapter HIP path has no CPU fallback "
+                              "(move tensors to a ROCm device)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _mat(t: torch.Tensor, name: str):
+    """2-D fp16 matrix whose rows are unit-stride; returns (tensor, leading dimension)."""
+    _req(t, name)
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D, got {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name} must have unit stride along its last dim")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    return t, ld
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+# ---------------------------------------------------------------------------------------------- GEMM / conv
+def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0, epilogue=I2V_EPI_NONE,
+         out=None, store=I2V_STORE_ROWMAJOR, frames=0, hw=0, vt_len=0, vt_ld=0, out_scale=1.0):
+    """C = epi(A W^T + bias + rowvec + residual) * out_scale   (see i2v_gemm_f16)."""
+    lib = _lib.load()
+    a, lda = _mat(a, "a")
+    w, ldw = _mat(w, "w")
+    M, K1 = a.shape
+    N, K = w.shape
+    p = GemmParams()
+    p.a, p.lda = _p(a), lda
+    if a2 is not None:
+        a2, lda2 = _mat(a2, "a2")
+        if a2.shape[0] != M or K1 + a2.shape[1] != K:
+            raise ValueError(f"dual-source A shapes {tuple(a.shape)} + {tuple(a2.shape)} do not match W {tuple(w.shape)}")
+        p.a2, p.lda2, p.k_split = _p(a2), lda2, K1
+    elif K1 != K:
+        raise ValueError(f"A is {tuple(a.shape)} but W is {tuple(w.shape)}")
+    p.a_mode = I2V_A_PLAIN
+    p.w, p.ldw = _p(w), ldw
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise ValueError("bias must be a contiguous vector of N elements")
+        p.bias = _p(bias)
+    n_out = N // 2 if epilogue == I2V_EPI_GEGLU else N
+    if store == I2V_STORE_VT:
+        if out is None or vt_len <= 0 or vt_ld < vt_len or N % vt_len != 0:
+            raise ValueError("VT store needs an `out` buffer, vt_len > 0, vt_ld >= vt_len and N % vt_len == 0")
+        _req(out, "out")
+        if not out.is_contiguous() or out.numel() < (N // vt_len) * M * vt_ld:
+            raise ValueError("VT `out` must be contiguous with at least (N / vt_len) * M * vt_ld elements")
+        p.c, p.ldc = _p(out), vt_ld
+        p.vt_len, p.vt_ld = vt_len, vt_ld
+    else:
+        if out is None:
+            out = torch.empty((M, n_out), dtype=f16, device=a.device)
+        out, ldc = _mat(out, "out")
+        if out.shape != (M, n_out):
+            raise ValueError(f"out must be {(M, n_out)}, got {tuple(out.shape)}")
+        p.c, p.ldc = _p(out), ldc
+    if residual is not None:
+        residual, ldr = _mat(residual, "residual")
+        if residual.shape != (M, n_out) or epilogue == I2V_EPI_GEGLU:
+            raise ValueError(f"residual must be {(M, n_out)} (and is not supported with GEGLU)")
+        p.residual, p.ldr = _p(residual), ldr
+    if rowvec is not None:
+        rowvec, ldv = _mat(rowvec, "rowvec")
+        if rows_per_vec <= 0 or M % rows_per_vec != 0 or rowvec.shape != (M // rows_per_vec, N):
+            raise ValueError(f"rowvec must be [M / rows_per_vec, N], got {tuple(rowvec.shape)}")
+        p.rowvec, p.ld_rowvec, p.rows_per_vec = _p(rowvec), ldv, rows_per_vec
+    p.M, p.N, p.K = M, N, K
+    p.epilogue, p.store_mode = epilogue, store
+    p.frames, p.hw = frames, hw
+    p.out_scale = out_scale
+    _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16")
+    return out
+
+
+def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
+            out_scale=1.0):
+    """3x3 / pad 1 convolution of a token-major image x [N, H, W, Cin] with w_packed [Cout, 9 * Cin]
+    (k = (ky * 3 + kx) * Cin + ci); optional nearest-2x upsampling of the input first."""
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"x must be a contiguous [N, H, W, C] tensor, got {tuple(x.shape)}")
+    n, h, wd, cin = x.shape
+    w_packed, ldw = _mat(w_packed, "w_packed")
+    cout, K = w_packed.shape
+    if K != 9 * cin:
+        raise ValueError(f"w_packed is {tuple(w_packed.shape)} but x has {cin} channels")
+    if upsample:
+        if stride != 1:
+            raise ValueError("upsample conv must have stride 1")
+        oh, ow = 2 * h, 2 * wd
+    else:
+        oh, ow = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    M = n * oh * ow
+    out = torch.empty((n, oh, ow, cout), dtype=f16, device=x.device)
+    p = GemmParams()
+    p.a, p.lda = _p(x), cin
+    p.a_mode = I2V_A_CONV3X3
+    p.w, p.ldw = _p(w_packed), ldw
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != cout or not bias.is_contiguous():
+            raise ValueError("bias must be a contiguous vector of Cout elements")
+        p.bias = _p(bias)
+    if residual is not None:
+        _req(residual, "residual")
+        if tuple(residual.shape) != (n, oh, ow, cout) or not residual.is_contiguous():
+            raise ValueError(f"residual must be contiguous {(n, oh, ow, cout)}")
+        p.residual, p.ldr = _p(residual), cout
+    if rowvec is not None:
+        rowvec, ldv = _mat(rowvec, "rowvec")
+        if rows_per_vec <= 0 or M % rows_per_vec != 0 or rowvec.shape != (M // rows_per_vec, cout):
+            raise ValueError(f"rowvec must be [M / rows_per_vec, Cout], got {tuple(rowvec.shape)}")
+        p.rowvec, p.ld_rowvec, p.rows_per_vec = _p(rowvec), ldv, rows_per_vec
+    p.c, p.ldc = _p(out), cout
+    p.M, p.N, p.K = M, cout, K
+    p.epilogue, p.store_mode = I2V_EPI_NONE, I2V_STORE_ROWMAJOR
+    p.out_scale = out_scale
+    p.n_img, p.in_h, p.in_w, p.cin = n, h, wd, cin
+    p.out_h, p.out_w, p.stride, p.upsample = oh, ow, stride, 1 if upsample else 0
+    _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16(conv3x3)")
+    return out
+
+
+def project_vt(tokens, w_v, batch_len, out=None):
+    """V^T[batch][channel][key] = (tokens W_v^T)^T, emitted directly by the GEMM epilogue (I2V_STORE_VT).
+    tokens [batches * batch_len, K]; w_v [C, K]; returns [batches, C, pad8(batch_len)] (tail keys unwritten)."""
+    tokens, _ = _mat(tokens, "tokens")
+    T = tokens.shape[0]
+    if T % batch_len != 0:
+        raise ValueError(f"{T} tokens are not a multiple of batch_len {batch_len}")
+    ld = pad8(batch_len)
+    Cc = w_v.shape[0]
+    if out is None:
+        out = torch.empty((T // batch_len, Cc, ld), dtype=f16, device=tokens.device)
+    gemm(w_v, tokens, store=I2V_STORE_VT, vt_len=batch_len, vt_ld=ld, out=out)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attention(q, k, vt, *, batch_q, lq, lk, heads, head_dim, kv_group=1, scale=None, out=None, accumulate=False,
+              acc_scale=1.0):
+    """Flash attention forward.  q [batch_q * lq, >= heads*head_dim] (row-strided view is fine),
+    k [batch_kv * lk, ...], vt [batch_kv, heads*head_dim, >= pad8(lk)], returns [batch_q * lq, heads*head_dim]."""
+    lib = _lib.load()
+    q, ldq = _mat(q, "q")
+    k, ldk = _mat(k, "k")
+    _req(vt, "vt")
+    Cc = heads * head_dim
+    bkv = batch_q // kv_group
+    if q.shape[0] != batch_q * lq or q.shape[1] < Cc:
+        raise ValueError(f"q is {tuple(q.shape)}, expected [{batch_q * lq}, >={Cc}]")
+    if k.shape[0] != bkv * lk or k.shape[1] < Cc:
+        raise ValueError(f"k is {tuple(k.shape)}, expected [{bkv * lk}, >={Cc}]")
+    if vt.dim() != 3 or not vt.is_contiguous() or vt.shape[0] != bkv or vt.shape[1] != Cc or vt.shape[2] < pad8(lk):
+        raise ValueError(f"vt is {tuple(vt.shape)}, expected contiguous [{bkv}, {Cc}, >={pad8(lk)}]")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs the `out` tensor holding the previous result")
+        out = torch.empty((batch_q * lq, Cc), dtype=f16, device=q.device)
+    out, ldo = _mat(out, "out")
+    if out.shape[0] != batch_q * lq or out.shape[1] < Cc:
+        raise ValueError("bad `out` shape")
+    p = AttnParams()
+    p.q, p.q_row_stride, p.q_batch_stride = _p(q), ldq, lq * ldq
+    p.k, p.k_row_stride, p.k_batch_stride = _p(k), ldk, lk * ldk
+    p.vt, p.vt_row_stride, p.vt_batch_stride = _p(vt), vt.shape[2], Cc * vt.shape[2]
+    p.o, p.o_row_stride, p.o_batch_stride = _p(out), ldo, lq * ldo
+    p.batch_q, p.kv_group, p.heads, p.head_dim, p.lq, p.lk = batch_q, kv_group, heads, head_dim, lq, lk
+    p.scale = float(head_dim) ** -0.5 if scale is None else scale
+    p.accumulate, p.acc_scale = 1 if accumulate else 0, acc_scale
+    _lib.check(lib.i2v_attention_f16(C.byref(p), _stream()), "i2v_attention_f16")
+    return out
+
+
+def temporal_attention(q, k, vt, *, n_pixels, frames, heads, head_dim, scale=None):
+    """Motion-module attention over the frame axis; tokens in (b, pixel, frame) order.
+    q, k [n_pixels * frames, >= C]; vt [n_pixels, C, >= pad8(frames)]."""
+    lib = _lib.load()
+    q, ldq = _mat(q, "q")
+    k, ldk = _mat(k, "k")
+    _req(vt, "vt")
+    Cc = heads * head_dim
+    if q.shape[0] != n_pixels * frames or k.shape[0] != n_pixels * frames or q.shape[1] < Cc or k.shape[1] < Cc:
+        raise ValueError("q / k must be [n_pixels * frames, >= C]")
+    if vt.dim() != 3 or not vt.is_contiguous() or vt.shape[0] != n_pixels or vt.shape[1] != Cc or \
+            vt.shape[2] < pad8(frames):
+        raise ValueError(f"vt is {tuple(vt.shape)}, expected contiguous [{n_pixels}, {Cc}, >={pad8(frames)}]")
+    out = torch.empty((n_pixels * frames, Cc), dtype=f16, device=q.device)
+    p = TAttnParams()
+    p.q, p.q_row_stride = _p(q), ldq
+    p.k, p.k_row_stride = _p(k), ldk
+    p.vt, p.vt_ld = _p(vt), vt.shape[2]
+    p.o, p.o_row_stride = _p(out), Cc
+    p.n_pixels, p.frames, p.heads, p.head_dim = n_pixels, frames, heads, head_dim
+    p.scale = float(head_dim) ** -0.5 if scale is None else scale
+    _lib.check(lib.i2v_temporal_attention_f16(C.byref(p), _stream()), "i2v_temporal_attention_f16")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- norms
+def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_stat=1, out_perm=False, frames=0):
+    """GroupNorm (+SiLU) of a token-major image batch x [N, H, W, C1] (optionally concatenated with x2 along C).
+    Returns [N, H, W, C]; with out_perm the rows are written in (b, pixel, frame) order and the result is
+    returned flat as [N * H * W, C]."""
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"x must be contiguous [N, H, W, C], got {tuple(x.shape)}")
+    n, h, w, c1 = x.shape
+    c2 = 0
+    if x2 is not None:
+        _req(x2, "x2")
+        if x2.dim() != 4 or not x2.is_contiguous() or x2.shape[:3] != x.shape[:3]:
+            raise ValueError("x2 must be contiguous [N, H, W, C2] with the same N, H, W as x")
+        c2 = x2.shape[3]
+    Cc = c1 + c2
+    _req(gamma, "gamma")
+    _req(beta, "beta")
+    if gamma.numel() != Cc or beta.numel() != Cc:
+        raise ValueError(f"gamma / beta must have {Cc} elements")
+    ws = torch.empty((lib.i2v_groupnorm_workspace_bytes(n, h * w, Cc) + 3) // 4, dtype=torch.float32, device=x.device)
+    y = torch.empty((n * h * w, Cc) if out_perm else (n, h, w, Cc), dtype=f16, device=x.device)
+    p = GnParams()
+    p.x, p.c1, p.x2, p.c2 = _p(x), c1, _p(x2), c2
+    p.gamma, p.beta, p.y = _p(gamma.contiguous()), _p(beta.contiguous()), _p(y)
+    p.n_img, p.hw, p.groups, p.frames_per_stat = n, h * w, groups, frames_per_stat
+    p.eps, p.silu = eps, 1 if silu else 0
+    p.out_perm, p.frames = (1 if out_perm else 0), frames
+    p.workspace = _p(ws)
+    _lib.check(lib.i2v_groupnorm_f16(C.byref(p), _stream()), "i2v_groupnorm_f16")
+    return y
+
+
+def layernorm(x, gamma, beta, eps, *, pe=None, pe_period=0):
+    """LayerNorm over the last dim of a 2-D token matrix (+ pe[row % pe_period])."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    rows, Cc = x.shape
+    _req(gamma, "gamma")
+    _req(beta, "beta")
+    y = torch.empty((rows, Cc), dtype=f16, device=x.device)
+    p = LnParams()
+    p.x, p.ldx = _p(x), ldx
+    p.gamma, p.beta = _p(gamma), _p(beta)
+    if pe is not None:
+        pe, ldpe = _mat(pe, "pe")
+        if pe.shape[1] != Cc or pe.shape[0] < pe_period or pe_period <= 0:
+            raise ValueError("pe must be [>= pe_period, C]")
+        p.pe, p.ld_pe, p.pe_period = _p(pe), ldpe, pe_period
+    p.y, p.ldy = _p(y), Cc
+    p.rows, p.C, p.eps = rows, Cc, eps
+    _lib.check(lib.i2v_layernorm_f16(C.byref(p), _stream()), "i2v_layernorm_f16")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- edges / misc
+def nchw_to_tokens(src, c_pad=None):
+    """[N, C, H, W] (fp32 or fp16) -> token-major fp16 [N, H, W, c_pad]."""
+    lib = _lib.load()
+    _req(src, "src", dtype=None)
+    if src.dtype not in (torch.float32, f16) or src.dim() != 4:
+        raise TypeError("src must be a 4-D fp32 / fp16 tensor")
+    src = src.contiguous()
+    n, c, h, w = src.shape
+    c_pad = c if c_pad is None else c_pad
+    dst = torch.empty((n, h, w, c_pad), dtype=f16, device=src.device)
+    _lib.check(lib.i2v_nchw_to_tokens(_p(src), 1 if src.dtype == torch.float32 else 0, _p(dst), n, c, h * w, c_pad,
+                                      _stream()), "i2v_nchw_to_tokens")
+    return dst
+
+
+def tokens_to_nchw(src, c=None, dtype=f16):
+    """token-major fp16 [N, H, W, ld] -> [N, c, H, W] in `dtype` (fp16 / fp32)."""
+    lib = _lib.load()
+    _req(src, "src")
+    if src.dim() != 4 or not src.is_contiguous():
+        raise ValueError("src must be contiguous [N, H, W, C]")
+    n, h, w, ld = src.shape
+    c = ld if c is None else c
+    if dtype not in (torch.float32, f16):
+        raise TypeError("dtype must be fp32 or fp16")
+    dst = torch.empty((n, c, h, w), dtype=dtype, device=src.device)
+    _lib.check(lib.i2v_tokens_to_nchw(_p(src), ld, _p(dst), 1 if dtype == torch.float32 else 0, n, c, h * w,
+                                      _stream()), "i2v_tokens_to_nchw")
+    return dst
+
+
+def timestep_embedding(t, dim, t_index=None):
+    """t fp32 [n] (or a table indexed by the device scalar `t_index`, with n = t_rows) -> [n, dim] fp16."""
+    lib = _lib.load()
+    _req(t, "t", dtype=torch.float32)
+    n = 1 if t_index is not None else t.numel()
+    if t_index is not None:
+        _req(t_index, "t_index", dtype=torch.int32)
+    out = torch.empty((n, dim), dtype=f16, device=t.device)
+    _lib.check(lib.i2v_timestep_embedding(_p(t), _p(t_index), _p(out), n, dim, _stream()), "i2v_timestep_embedding")
+    return out
+
+
+def silu(x):
+    lib = _lib.load()
+    _req(x, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.check(lib.i2v_silu_f16(_p(x), _p(y), x.numel(), _stream()), "i2v_silu_f16")
+    return y
+
+
+def repeat_rows(x, repeat):
+    lib = _lib.load()
+    x, _ = _mat(x, "x")
+    x = x.contiguous()
+    y = torch.empty((x.shape[0] * repeat, x.shape[1]), dtype=f16, device=x.device)
+    _lib.check(lib.i2v_repeat_rows_f16(_p(x), _p(y), x.shape[0], x.shape[1], repeat, _stream()), "i2v_repeat_rows_f16")
+    return y
+
+
+def copy3d(src, dst):
+    """dst[b, r, :] = src[b, r, :] for 3-D fp16 tensors whose last dim is unit-stride (views allowed)."""
+    lib = _lib.load()
+    _req(src, "src")
+    _req(dst, "dst")
+    if src.dim() != 3 or dst.shape != src.shape or src.stride(2) != 1 or dst.stride(2) != 1:
+        raise ValueError("copy3d needs two 3-D tensors of equal shape with unit last stride")
+    b, r, c = src.shape
+    _lib.check(lib.i2v_copy3d_f16(_p(src), src.stride(0), src.stride(1), _p(dst), dst.stride(0), dst.stride(1), b, r, c,
+                                  _stream()), "i2v_copy3d_f16")
+    return dst
+
+
+def ddim_prep(latents, cond, c_pad, cfg_copies):
+    """latents fp32 [B, F, C, H, W] (frame 0 overwritten in place with cond [B, C, H, W]) ->
+    model input tokens fp16 [cfg_copies * B * F, H, W, c_pad]."""
+    lib = _lib.load()
+    _req(latents, "latents", dtype=torch.float32)
+    _req(cond, "cond", dtype=torch.float32)
+    if latents.dim() != 5 or not latents.is_contiguous() or not cond.is_contiguous():
+        raise ValueError("latents must be contiguous [B, F, C, H, W]; cond contiguous [B, C, H, W]")
+    b, f, c, h, w = latents.shape
+    if tuple(cond.shape) != (b, c, h, w):
+        raise ValueError(f"cond must be {(b, c, h, w)}, got {tuple(cond.shape)}")
+    out = torch.empty((cfg_copies * b * f, h, w, c_pad), dtype=f16, device=latents.device)
+    _lib.check(lib.i2v_ddim_prep(_p(latents), _p(cond), _p(out), b, f, c, h * w, c_pad, cfg_copies, _stream()),
+               "i2v_ddim_prep")
+    return out
+
+
+def ddim_cfg_step(latents, noise_pred, coef, step_index, guidance_scale, cfg_copies):
+    """In-place DDIM update of latents fp32 [B, F, C, H, W] from noise_pred tokens fp16
+    [cfg_copies * B * F, H, W, ld]; coef fp32 [steps, 4]; step_index device int32 scalar (incremented)."""
+    lib = _lib.load()
+    _req(latents, "latents", dtype=torch.float32)
+    _req(noise_pred, "noise_pred")
+    _req(coef, "coef", dtype=torch.float32)
+    _req(step_index, "step_index", dtype=torch.int32)
+    b, f, c, h, w = latents.shape
+    if noise_pred.dim() != 4 or not noise_pred.is_contiguous() or noise_pred.shape[0] != cfg_copies * b * f or \
+            noise_pred.shape[1] != h or noise_pred.shape[2] != w or noise_pred.shape[3] < c:
+        raise ValueError(f"noise_pred must be contiguous [{cfg_copies * b * f}, {h}, {w}, >={c}]")
+    if coef.dim() != 2 or coef.shape[1] != 4 or not coef.is_contiguous():
+        raise ValueError("coef must be contiguous [steps, 4]")
+    _lib.check(lib.i2v_ddim_cfg_step(_p(latents), _p(noise_pred), noise_pred.shape[3], _p(coef), _p(step_index),
+                                     float(guidance_scale), b, f, c, h * w, cfg_copies, _stream()),
+               "i2v_ddim_cfg_step")
+    return latents

@@ -1,0 +1,228 @@
+/*
+ * i2v_hip.h -- C ABI of libi2v_hip.so: hand-written HIP (gfx950 / MI355X) kernels for the
+ * I2V-Adapter denoising path.
+ *
+ * The reference (xUhEngwAng/I2V-Adapter-Unofficial) has no FFI: the path sits behind a Python module
+ * API and its arithmetic is executed by torch/aten kernels reached through `diffusers`.
+ * Each entry point below replaces the aten kernel family named in its comment, at the reference call
+ * site cited (file:line relative to /root/reference; i2v = src/modules/i2v_adapter.py,
+ * unet = src/models/unet_motion_cross_frame_attn.py, pipe = src/pipelines/pipeline_i2v_adapter.py).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + explicit sizes/strides; no torch types.
+ *   - activations are fp16, TOKEN-MAJOR CHANNELS-LAST: x[image][pixel][channel]; strides are in ELEMENTS.
+ *   - every function is asynchronous on the caller's `stream` (a hipStream_t), never allocates, never
+ *     synchronises, never touches the null stream => safe inside hipGraph capture.
+ *   - return value: 0 ok, <0 error (I2V_ERR_*); i2v_last_error() returns a thread-local message.
+ *   - the caller owns every buffer (including workspaces, whose sizes the *_workspace_bytes helpers give).
+ */
+#ifndef I2V_HIP_H
+#define I2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2V_ABI_VERSION 1
+
+#define I2V_OK 0
+#define I2V_ERR_INVALID_ARG (-1)
+#define I2V_ERR_UNSUPPORTED (-2)
+#define I2V_ERR_LAUNCH (-3)
+
+typedef void* i2v_stream_t; /* hipStream_t */
+
+int i2v_abi_version(void);
+const char* i2v_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution with fused epilogue (MFMA, fp16 in, fp32 accumulate, fp16 out)
+ *
+ *   C[m, n] = epi( sum_k A[m, k] * W[n, k]  + bias[n] + rowvec[m / rows_per_vec, n] + residual[m', n] )
+ *             * out_scale
+ *
+ * replaces aten addmm / conv2d(+bias) at: attention projections to_q/to_k/to_v/to_out (diffusers
+ * `Attention`, constructed i2v:32-37,409-418), GEGLU feed-forward (i2v:554), 1x1 proj_in/proj_out
+ * (i2v:219-226,299-305), ResnetBlock2D conv1/conv2/conv_shortcut/time_emb_proj (unet:203-214,384-395,
+ * 563-574,594-605), Downsample2D/Upsample2D convs (unet:250-259,431-432), conv_in/conv_out
+ * (unet:757-759,879-881), motion-module proj_in/proj_out/q/k/v/out/ff (unet:232-244), time embedding MLP
+ * (unet:766-770), ImageProjection (unet:1284-1287).
+ * ------------------------------------------------------------------------------------------------ */
+enum {
+  I2V_EPI_NONE = 0,
+  I2V_EPI_GELU = 1,  /* erf GELU on the result                                                     */
+  I2V_EPI_GEGLU = 2  /* W rows interleaved (value_i, gate_i): C[m, n/2] = v * gelu_erf(g); N even   */
+};
+
+enum {
+  I2V_STORE_ROWMAJOR = 0, /* C[m * ldc + n]                                                         */
+  I2V_STORE_ROWPERM = 1,  /* rows arrive in (b, pixel, frame) order and are stored (and the residual
+                             is read) in (b, frame, pixel) order: m = (b*hw + p)*frames + f ->
+                             m' = (b*frames + f)*hw + p            (motion-module exit)   */
+  I2V_STORE_VT = 2        /* transposed, batched: element (m, n) -> C[((n / vt_len) * M + m) * vt_ld
+                             + n % vt_len]; used with A = weight [C, K], W = tokens [T, K] to emit
+                             V^T[batch][channel][key] for the attention kernels                     */
+};
+
+enum {
+  I2V_A_PLAIN = 0,  /* A is [M, K] row-major (optionally two sources concatenated along K)          */
+  I2V_A_CONV3X3 = 1 /* A is gathered on the fly from an NHWC image: K = 9 * cin, k = tap * cin + ci */
+};
+
+typedef struct i2v_gemm_params {
+  const void* a;        /* fp16 */
+  int64_t lda;
+  const void* a2;       /* optional second K-range source (skip-connection concat, unet:478); NULL if unused */
+  int64_t lda2;
+  int32_t k_split;      /* columns [0, k_split) come from a, [k_split, K) from a2; multiple of 8     */
+  int32_t a_mode;       /* I2V_A_*                                                                  */
+  const void* w;        /* fp16 [N, K] row-major (torch Linear / repacked conv weight)               */
+  int64_t ldw;
+  const void* bias;     /* fp16 [N] or NULL                                                          */
+  const void* residual; /* fp16 [M, N] (ld = ldr) or NULL                                            */
+  int64_t ldr;
+  const void* rowvec;   /* fp16 [M / rows_per_vec, N] (ld = ld_rowvec) or NULL: time-embedding add   */
+  int64_t ld_rowvec;
+  int32_t rows_per_vec;
+  void* c;              /* fp16                                                                      */
+  int64_t ldc;
+  int32_t M, N, K;
+  int32_t epilogue;     /* I2V_EPI_*                                                                 */
+  int32_t store_mode;   /* I2V_STORE_*                                                               */
+  int32_t frames, hw;   /* I2V_STORE_ROWPERM                                                         */
+  int32_t vt_len, vt_ld;/* I2V_STORE_VT                                                              */
+  float out_scale;
+  /* I2V_A_CONV3X3 geometry: input image [n_img, in_h, in_w, cin] fp16 (pixel stride = lda elements),
+     3x3 kernel, padding 1, `stride` 1 or 2; `upsample` = 1 applies nearest-2x to the input first
+     (Upsample2D).  M = n_img * out_h * out_w. */
+  int32_t n_img, in_h, in_w, cin, out_h, out_w, stride, upsample;
+} i2v_gemm_params;
+
+int i2v_gemm_f16(const i2v_gemm_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flash-style attention forward (MFMA QK^T / PV, wavefront-shuffle online softmax).
+ *   O[bq, l, h, :] (+)= softmax_j( scale * Q[bq, l, h, :] . K[bq / kv_group, j, h, :] ) V[bq / kv_group, j, h, :]
+ * replaces F.scaled_dot_product_attention at:
+ *   K1 cross-frame adapter attention i2v:483-492  (kv_group = num_frames: every frame reads frame-0 K/V)
+ *   K2 spatial self-attention        i2v:468-473  (kv_group = 1)
+ *   K3 text cross-attention + IP-Adapter decoupled branch i2v:527-532, unet:1263-1279
+ *      (second call with accumulate = 1, acc_scale = ip scale)
+ * V is passed TRANSPOSED: vt[b][h*d + i][key] (see I2V_STORE_VT), row stride vt_row_stride >= lk rounded
+ * up to 8; entries past lk may hold garbage (they are masked in-kernel).  head_dim % 8 == 0, <= 160.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_attn_params {
+  const void* q;  int64_t q_row_stride, q_batch_stride;
+  const void* k;  int64_t k_row_stride, k_batch_stride;
+  const void* vt; int64_t vt_row_stride, vt_batch_stride;
+  void* o;        int64_t o_row_stride, o_batch_stride;
+  int32_t batch_q, kv_group, heads, head_dim, lq, lk;
+  float scale;
+  int32_t accumulate;
+  float acc_scale;
+} i2v_attn_params;
+
+int i2v_attention_f16(const i2v_attn_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal (motion-module) self-attention: sequence = frames (<= 32) of one pixel; tokens are in
+ * (b, pixel, frame) order so each pixel's q/k rows are `frames` consecutive rows; vt is
+ * vt[pixel][h*d + i][frame] with row stride vt_ld (>= frames rounded up to 8).
+ * Replaces SDPA inside diffusers TransformerTemporalModel (unet:323-326,520-523,688-691).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_tattn_params {
+  const void* q; int64_t q_row_stride;
+  const void* k; int64_t k_row_stride;
+  const void* vt; int32_t vt_ld;
+  void* o; int64_t o_row_stride;
+  int32_t n_pixels, frames, heads, head_dim;
+  float scale;
+} i2v_tattn_params;
+
+int i2v_temporal_attention_f16(const i2v_tattn_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) on token-major fp16: statistics in fp32.
+ *   stat group = (frames_per_stat consecutive images) x (all pixels) x (C / groups channels)
+ *   frames_per_stat = 1: ResnetBlock2D norm1/norm2, Transformer2D norm, conv_norm_out
+ *                        (unet:203-214, i2v:218, unet:870-873)
+ *   frames_per_stat = F: TransformerTemporalModel.norm, statistics over (C/G, F, H, W)
+ * x may be two sources concatenated along channels (c1 from x, c2 from x2: skip concat, unet:478).
+ * out_perm = 1 writes rows in (b, pixel, frame) order (motion-module entry).
+ * workspace: i2v_groupnorm_workspace_bytes(...) bytes of scratch, fp32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_gn_params {
+  const void* x;  int32_t c1;
+  const void* x2; int32_t c2;
+  const void* gamma; const void* beta; /* fp16 [c1 + c2] */
+  void* y;                              /* fp16 [n_img, hw, c1 + c2] */
+  int32_t n_img, hw, groups, frames_per_stat;
+  float eps;
+  int32_t silu;
+  int32_t out_perm; int32_t frames; /* out_perm: images are (b, f); output row = (b*hw + p)*frames + f */
+  void* workspace;
+} i2v_gn_params;
+
+int64_t i2v_groupnorm_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels);
+int i2v_groupnorm_f16(const i2v_gn_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis (fp32 statistics), optional additive positional embedding
+ * y[r, :] = LN(x[r, :]) * gamma + beta (+ pe[r % pe_period, :])
+ * replaces native_layer_norm at i2v:445,514,539 and, with pe, LN + SinusoidalPositionalEmbedding of the
+ * motion-module block.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_ln_params {
+  const void* x; int64_t ldx;
+  const void* gamma; const void* beta; /* fp16 [C] */
+  const void* pe; int64_t ld_pe; int32_t pe_period; /* fp16 [pe_period, C] or NULL */
+  void* y; int64_t ldy;
+  int32_t rows, C;
+  float eps;
+} i2v_ln_params;
+
+int i2v_layernorm_f16(const i2v_ln_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout edges, embeddings and the sampler step
+ * ------------------------------------------------------------------------------------------------ */
+/* NCHW (fp32 if src_is_f32 else fp16) [n, c, h*w] -> token-major fp16 [n, h*w, c_pad], channels >= c zeroed
+ * (sample.reshape + conv_in input, unet:1358). */
+int i2v_nchw_to_tokens(const void* src, int32_t src_is_f32, void* dst, int32_t n, int32_t c, int32_t hw,
+                       int32_t c_pad, i2v_stream_t stream);
+/* token-major fp16 [n, hw, ld] (first c channels) -> NCHW (fp32 if dst_is_f32 else fp16) (unet:1446). */
+int i2v_tokens_to_nchw(const void* src, int64_t ld, void* dst, int32_t dst_is_f32, int32_t n, int32_t c,
+                       int32_t hw, i2v_stream_t stream);
+/* Timesteps(dim, flip_sin_to_cos=True, shift 0): out[b, :] = [cos(t*w) | sin(t*w)] fp16 (unet:763,1336).
+ * t is fp32 [n]; if t_index != NULL the single value t[*t_index] is used for every row (graph replay). */
+int i2v_timestep_embedding(const float* t, const int32_t* t_index, void* out, int32_t n, int32_t dim,
+                           i2v_stream_t stream);
+/* y = silu(x), fp16, n elements (nonlinearity(temb), ResnetBlock2D). */
+int i2v_silu_f16(const void* x, void* y, int64_t n, i2v_stream_t stream);
+/* y[r, :] = x[r / repeat, :]  (repeat_interleave of temb / context rows, unet:1344,1355). */
+int i2v_repeat_rows_f16(const void* x, void* y, int64_t rows_in, int64_t cols, int32_t repeat,
+                        i2v_stream_t stream);
+/* dst[b, r, :cols] = src[b, r, :cols] for b < batches, r < rows: fp16 strided 3-D copy (strides in elements).
+ * Used to gather the frame-0 tokens of every clip (i2v:484) and to split text / image context tokens. */
+int i2v_copy3d_f16(const void* src, int64_t src_batch_stride, int64_t ld_src, void* dst, int64_t dst_batch_stride,
+                   int64_t ld_dst, int64_t batches, int64_t rows, int64_t cols, i2v_stream_t stream);
+
+/* One DDIM step around the UNet call, pipe:666-691, split in the two halves that bracket it.
+ *   prep : latents[:, 0] = cond (pipe:669); model_in = tokens(cat([latents] * cfg_copies)) fp16, channels
+ *          padded to c_pad (pipe:672-673; scale_model_input is the identity for DDIM).
+ *   step : eps = u + g (c - u) (pipe:686-688); x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);
+ *          x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps (pipe:691); then *step_index += 1.
+ * latents fp32 [b, f, c, hw]; cond fp32 [b, c, hw]; noise_pred fp16 tokens [cfg_copies*b*f, hw, ld_np];
+ * coef fp32 [n_steps][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}; step_index device int32. */
+int i2v_ddim_prep(float* latents, const float* cond, void* model_in, int32_t b, int32_t f, int32_t c,
+                  int32_t hw, int32_t c_pad, int32_t cfg_copies, i2v_stream_t stream);
+int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, const float* coef,
+                      int32_t* step_index, float guidance_scale, int32_t b, int32_t f, int32_t c, int32_t hw,
+                      int32_t cfg_copies, i2v_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2V_HIP_H */

@@ -1,0 +1,349 @@
+"""GPU parity of every C-ABI kernel against plain fp32 torch on the CPU (same fp16-rounded inputs).
+
+Tolerance (stated, fp16 path): outputs are fp16 (10-bit mantissa, eps = 9.8e-4) with fp32 accumulation, so each
+kernel must match the fp32 reference within  |err| <= 3e-3 * |ref| + 3e-3 * max|ref|  (elementwise kernels:
+2e-3).  Everything is called through the C ABI (i2v_adapter_unofficial_amd.kernels -> ctypes -> libi2v_hip.so).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+    import i2v_adapter_unofficial_amd as pkg
+    return pkg.kernels
+
+
+def h(t):
+    """fp16-rounded fp32 copy (what the kernel actually sees)."""
+    return t.half().float()
+
+
+def close(got, ref, rel=3e-3, name=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    tol = rel * ref.abs() + rel * ref.abs().max()
+    err = (got - ref).abs()
+    bad = err > tol
+    assert not bad.any(), (f"{name}: {int(bad.sum())}/{bad.numel()} elements out of tolerance, max err "
+                           f"{err.max().item():.4e}, ref max {ref.abs().max().item():.4e}, first bad idx "
+                           f"{bad.nonzero()[0].tolist()}")
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 128, 64), (128, 256, 128), (300, 200, 136), (1000, 320, 320),
+                                    (154, 64, 768), (2, 1280, 320), (4096, 640, 2560), (70, 36, 72)])
+def test_gemm_plain(dev, M, N, K_):
+    k = K()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = h(torch.randn(M, K_, generator=g))
+    w = h(torch.randn(N, K_, generator=g) / math.sqrt(K_))
+    b = h(torch.randn(N, generator=g))
+    r = h(torch.randn(M, N, generator=g))
+    out = k.gemm(a.half().to(dev), w.half().to(dev))
+    close(out, a @ w.T, name="gemm")
+    out = k.gemm(a.half().to(dev), w.half().to(dev), b.half().to(dev), residual=r.half().to(dev), out_scale=0.5)
+    close(out, (a @ w.T + b + r) * 0.5, name="gemm+bias+residual")
+
+
+def test_gemm_rowvec_gelu(dev):
+    k = K()
+    g = torch.Generator().manual_seed(3)
+    M, N, K_, rpv = 384, 96, 64, 48
+    a, w = h(torch.randn(M, K_, generator=g)), h(torch.randn(N, K_, generator=g) / 8)
+    b, rv = h(torch.randn(N, generator=g)), h(torch.randn(M // rpv, N, generator=g))
+    out = k.gemm(a.half().to(dev), w.half().to(dev), b.half().to(dev), rowvec=rv.half().to(dev), rows_per_vec=rpv)
+    close(out, a @ w.T + b + rv.repeat_interleave(rpv, 0), name="gemm+rowvec")
+    out = k.gemm(a.half().to(dev), w.half().to(dev), b.half().to(dev), epilogue=k.I2V_EPI_GELU)
+    close(out, F.gelu(a @ w.T + b), name="gemm+gelu")
+
+
+@pytest.mark.parametrize("M,C,I", [(256, 64, 256), (130, 32, 100)])
+def test_gemm_geglu(dev, M, C, I):
+    k = K()
+    g = torch.Generator().manual_seed(5)
+    a = h(torch.randn(M, C, generator=g))
+    w = h(torch.randn(2 * I, C, generator=g) / math.sqrt(C))
+    b = h(torch.randn(2 * I, generator=g))
+    y = a @ w.T + b
+    ref = y[:, :I] * F.gelu(y[:, I:])
+    wi = torch.stack([w[:I], w[I:]], dim=1).reshape(2 * I, C)      # rows interleaved (value_i, gate_i)
+    bi = torch.stack([b[:I], b[I:]], dim=1).reshape(2 * I)
+    out = k.gemm(a.half().to(dev), wi.half().to(dev), bi.half().to(dev), epilogue=k.I2V_EPI_GEGLU)
+    close(out, ref, name="geglu")
+
+
+def test_gemm_dual_source(dev):
+    k = K()
+    g = torch.Generator().manual_seed(6)
+    M, K1, K2, N = 200, 64, 40, 72
+    a1, a2 = h(torch.randn(M, K1, generator=g)), h(torch.randn(M, K2, generator=g))
+    w = h(torch.randn(N, K1 + K2, generator=g) / 10)
+    out = k.gemm(a1.half().to(dev), w.half().to(dev), a2=a2.half().to(dev))
+    close(out, torch.cat([a1, a2], 1) @ w.T, name="dual-source")
+
+
+def test_gemm_strided_a(dev):
+    k = K()
+    g = torch.Generator().manual_seed(7)
+    big = h(torch.randn(128, 192, generator=g))
+    w = h(torch.randn(48, 64, generator=g) / 8)
+    bd = big.half().to(dev)
+    out = k.gemm(bd[:, 64:128], w.half().to(dev))
+    close(out, big[:, 64:128] @ w.T, name="strided A")
+
+
+@pytest.mark.parametrize("B,F_,HW,C,N", [(2, 4, 16, 64, 64), (1, 16, 64, 32, 40), (2, 8, 9, 64, 128)])
+def test_gemm_rowperm(dev, B, F_, HW, C, N):
+    """motion-module exit: rows in (b, pixel, frame) order -> (b, frame, pixel) order, residual in the latter."""
+    k = K()
+    g = torch.Generator().manual_seed(8)
+    M = B * F_ * HW
+    a, w = h(torch.randn(M, C, generator=g)), h(torch.randn(N, C, generator=g) / 8)
+    b, r = h(torch.randn(N, generator=g)), h(torch.randn(M, N, generator=g))
+    y = (a @ w.T + b).reshape(B, HW, F_, N).permute(0, 2, 1, 3).reshape(M, N) + r
+    out = k.gemm(a.half().to(dev), w.half().to(dev), b.half().to(dev), residual=r.half().to(dev),
+                 store=k.I2V_STORE_ROWPERM, frames=F_, hw=HW)
+    close(out, y, name="rowperm")
+
+
+@pytest.mark.parametrize("batches,L,C,Kd", [(3, 64, 64, 32), (2, 77, 40, 768), (5, 16, 320, 320), (4, 6, 24, 16)])
+def test_project_vt(dev, batches, L, C, Kd):
+    k = K()
+    g = torch.Generator().manual_seed(9)
+    tok = h(torch.randn(batches * L, Kd, generator=g))
+    wv = h(torch.randn(C, Kd, generator=g) / math.sqrt(Kd))
+    vt = k.project_vt(tok.half().to(dev), wv.half().to(dev), L)
+    ref = (tok @ wv.T).reshape(batches, L, C).permute(0, 2, 1)
+    close(vt[:, :, :L], ref, name="project_vt")
+
+
+@pytest.mark.parametrize("n,hh,ww,cin,cout,stride,up", [
+    (2, 8, 8, 8, 32, 1, False), (3, 16, 12, 32, 64, 1, False), (2, 16, 16, 64, 48, 2, False),
+    (2, 8, 8, 32, 32, 1, True), (1, 7, 9, 16, 24, 2, False), (2, 32, 32, 320, 320, 1, False),
+    (1, 5, 5, 8, 4, 1, False)])
+def test_conv3x3(dev, n, hh, ww, cin, cout, stride, up):
+    k = K()
+    g = torch.Generator().manual_seed(10 + cin)
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = h(torch.randn(cout, generator=g))
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=1)
+    oh, ow = ref.shape[-2:]
+    rv = h(torch.randn(n, cout, generator=g))
+    res = h(torch.randn(n, cout, oh, ow, generator=g))
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().half().to(dev)
+    out = k.conv3x3(xt, wp, b.half().to(dev), stride=stride, upsample=up)
+    close(out.permute(0, 3, 1, 2), ref, name="conv3x3")
+    out = k.conv3x3(xt, wp, b.half().to(dev), stride=stride, upsample=up, rowvec=rv.half().to(dev),
+                    rows_per_vec=oh * ow, residual=res.permute(0, 2, 3, 1).contiguous().half().to(dev))
+    close(out.permute(0, 3, 1, 2), ref + rv[:, :, None, None] + res, name="conv3x3+temb+res")
+
+
+def _attn_ref(q, k_, v, heads, group):
+    bq, lq, c = q.shape
+    d = c // heads
+    kk = k_.repeat_interleave(group, 0)
+    vv = v.repeat_interleave(group, 0)
+    qh = q.view(bq, lq, heads, d).transpose(1, 2)
+    kh = kk.view(bq, -1, heads, d).transpose(1, 2)
+    vh = vv.view(bq, -1, heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(bq, lq, c)
+
+
+@pytest.mark.parametrize("bq,group,heads,d,lq,lk", [
+    (2, 1, 2, 8, 64, 64), (4, 2, 4, 16, 100, 100), (2, 1, 2, 32, 256, 256), (8, 4, 8, 40, 256, 256),
+    (2, 1, 8, 40, 1024, 1024), (2, 1, 2, 64, 130, 77), (2, 1, 8, 80, 256, 77), (2, 2, 4, 160, 64, 64),
+    (1, 1, 2, 160, 300, 200), (3, 1, 2, 24, 16, 4), (2, 1, 3, 48, 40, 129), (2, 1, 2, 96, 128, 64),
+    (2, 1, 1, 128, 128, 192)])
+def test_attention(dev, bq, group, heads, d, lq, lk):
+    k = K()
+    g = torch.Generator().manual_seed(bq * 100 + d + lq)
+    c = heads * d
+    bkv = bq // group
+    q = h(torch.randn(bq, lq, c, generator=g))
+    kk = h(torch.randn(bkv, lk, c, generator=g))
+    v = h(torch.randn(bkv, lk, c, generator=g))
+    ref = _attn_ref(q, kk, v, heads, group)
+    ld = k.pad8(lk)
+    vt = torch.full((bkv, c, ld), float("nan"))           # tail keys hold garbage: the kernel must mask them
+    vt[:, :, :lk] = v.permute(0, 2, 1)
+    out = k.attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
+                      batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    close(out.view(bq, lq, c), ref, name="attention")
+    prev = h(torch.randn(bq * lq, c, generator=g))
+    out2 = prev.half().to(dev)
+    k.attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
+                batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group, out=out2, accumulate=True,
+                acc_scale=0.75)
+    close(out2.view(bq, lq, c), prev.view(bq, lq, c) + 0.75 * ref, name="attention accumulate")
+
+
+def test_attention_strided_qk_and_spike(dev):
+    """q / k read as column slices of a fused projection; one spiked key forces the online-softmax rescale."""
+    k = K()
+    g = torch.Generator().manual_seed(77)
+    bq, heads, d, lq, lk = 2, 4, 40, 192, 320
+    c = heads * d
+    qk = h(torch.randn(bq * lq, 2 * c, generator=g))
+    kv_src = h(torch.randn(bq * lk, 2 * c, generator=g))
+    kv_src[lk // 2 + 70, c:] *= 12.0      # a key far above the running max, in the 3rd key tile
+    v = h(torch.randn(bq, lk, c, generator=g))
+    q, kk = qk[:, :c].reshape(bq, lq, c), kv_src[:, c:].reshape(bq, lk, c)
+    ref = _attn_ref(q, kk, v, heads, 1)
+    vt = v.permute(0, 2, 1).contiguous()
+    qd, kd = qk.half().to(dev), kv_src.half().to(dev)
+    out = k.attention(qd[:, :c], kd[:, c:], vt.half().to(dev), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d)
+    close(out.view(bq, lq, c), ref, name="attention strided+spike")
+
+
+@pytest.mark.parametrize("npix,frames,heads,d", [(10, 16, 8, 40), (7, 8, 4, 8), (5, 4, 2, 16), (33, 32, 8, 80),
+                                                 (3, 24, 2, 160), (64, 16, 8, 160), (9, 5, 3, 24)])
+def test_temporal_attention(dev, npix, frames, heads, d):
+    k = K()
+    g = torch.Generator().manual_seed(npix + frames)
+    c = heads * d
+    q = h(torch.randn(npix, frames, c, generator=g))
+    kk = h(torch.randn(npix, frames, c, generator=g))
+    v = h(torch.randn(npix, frames, c, generator=g))
+    ref = _attn_ref(q, kk, v, heads, 1)
+    ld = k.pad8(frames)
+    vt = torch.full((npix, c, ld), float("nan"))
+    vt[:, :, :frames] = v.permute(0, 2, 1)
+    out = k.temporal_attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
+                               n_pixels=npix, frames=frames, heads=heads, head_dim=d)
+    close(out.view(npix, frames, c), ref, name="temporal attention")
+
+
+@pytest.mark.parametrize("n,hh,ww,c1,c2,groups,fps,silu,perm", [
+    (4, 8, 8, 32, 0, 8, 1, True, False), (2, 16, 16, 320, 0, 32, 1, True, False),
+    (4, 8, 8, 64, 0, 32, 4, False, True), (2, 20, 20, 64, 32, 32, 1, True, False),
+    (2, 4, 4, 1280, 1280, 32, 1, True, False), (8, 5, 7, 40, 0, 4, 2, False, False),
+    (2, 32, 32, 320, 0, 32, 2, False, True)])
+def test_groupnorm(dev, n, hh, ww, c1, c2, groups, fps, silu, perm):
+    k = K()
+    g = torch.Generator().manual_seed(n + c1)
+    c = c1 + c2
+    x = h(torch.randn(n, c, hh, ww, generator=g) * 2 + 0.5)
+    ga, be = h(torch.randn(c, generator=g)), h(torch.randn(c, generator=g))
+    if fps == 1:
+        ref = F.group_norm(x, groups, ga, be, eps=1e-5)
+    else:   # statistics over (C/G, fps frames, H, W)   (TransformerTemporalModel.norm)
+        xr = x.view(n // fps, fps, c, hh, ww).permute(0, 2, 1, 3, 4)
+        ref = F.group_norm(xr, groups, ga, be, eps=1e-5).permute(0, 2, 1, 3, 4).reshape(n, c, hh, ww)
+    if silu:
+        ref = F.silu(ref)
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    x1, x2 = (xt, None) if c2 == 0 else (xt[..., :c1].contiguous(), xt[..., c1:].contiguous())
+    out = k.groupnorm(x1, ga.half().to(dev), be.half().to(dev), groups, 1e-5, x2=x2, silu=silu, frames_per_stat=fps,
+                      out_perm=perm, frames=fps)
+    ref_t = ref.permute(0, 2, 3, 1)
+    if perm:
+        ref_t = ref_t.reshape(n // fps, fps, hh * ww, c).permute(0, 2, 1, 3).reshape(n * hh * ww, c)
+    close(out, ref_t, name="groupnorm")
+
+
+@pytest.mark.parametrize("rows,c,pe_period", [(100, 64, 0), (333, 320, 0), (64, 1280, 16), (40, 2560, 0), (48, 40, 8)])
+def test_layernorm(dev, rows, c, pe_period):
+    k = K()
+    g = torch.Generator().manual_seed(rows + c)
+    x = h(torch.randn(rows, c, generator=g) * 3 + 1)
+    ga, be = h(torch.randn(c, generator=g)), h(torch.randn(c, generator=g))
+    ref = F.layer_norm(x, (c,), ga, be, eps=1e-5)
+    pe = None
+    if pe_period:
+        pe = h(torch.randn(32, c, generator=g))
+        ref = ref + pe[:pe_period].repeat(rows // pe_period, 1)
+    out = k.layernorm(x.half().to(dev), ga.half().to(dev), be.half().to(dev), 1e-5,
+                      pe=None if pe is None else pe.half().to(dev), pe_period=pe_period)
+    close(out, ref, name="layernorm")
+
+
+def test_layout_edges_and_misc(dev):
+    k = K()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 4, 6, 5, generator=g)
+    t = k.nchw_to_tokens(x.to(dev), c_pad=8)
+    assert t.shape == (3, 6, 5, 8)
+    close(t[..., :4].permute(0, 3, 1, 2), h(x), rel=1e-6, name="nchw_to_tokens")
+    assert (t[..., 4:] == 0).all()
+    back = k.tokens_to_nchw(t, c=4, dtype=torch.float32)
+    close(back, h(x), rel=1e-6, name="tokens_to_nchw")
+    t16 = k.nchw_to_tokens(x.half().to(dev))
+    close(k.tokens_to_nchw(t16), h(x), rel=1e-6, name="fp16 edge roundtrip")
+    y = h(torch.randn(37, 24, generator=g))
+    close(k.silu(y.half().to(dev)), F.silu(y), rel=2e-3, name="silu")
+    close(k.repeat_rows(y.half().to(dev), 3), y.repeat_interleave(3, 0), rel=1e-6, name="repeat_rows")
+    src = y.half().to(dev).view(1, 37, 24).expand(1, 37, 24)
+    big = h(torch.randn(4, 10, 24, generator=g)).half().to(dev)
+    dst = torch.zeros(4, 3, 8, dtype=torch.float16, device=dev)
+    k.copy3d(big[:, 2:5, 8:16], dst)
+    close(dst, big[:, 2:5, 8:16], rel=1e-6, name="copy3d")
+
+
+def test_timestep_embedding(dev):
+    from oracle.blocks import Timesteps
+    k = K()
+    t = torch.tensor([0.0, 1.0, 40.0, 500.0, 999.0])
+    ref = Timesteps(320, True, 0)(t)
+    out = k.timestep_embedding(t.to(dev), 320)
+    close(out, ref, rel=2e-3, name="timestep embedding")
+    idx = torch.tensor([3], dtype=torch.int32, device=dev)
+    out = k.timestep_embedding(t.to(dev), 320, t_index=idx)
+    close(out, ref[3:4], rel=2e-3, name="timestep embedding (indexed)")
+
+
+def test_ddim_prep_and_step(dev):
+    from oracle.blocks import DDIMScheduler
+    k = K()
+    g = torch.Generator().manual_seed(4)
+    b, f, c, hh, ww = 2, 3, 4, 6, 5
+    lat = torch.randn(b, f, c, hh, ww, generator=g)
+    cond = torch.randn(b, c, hh, ww, generator=g)
+    lat_d = lat.clone().to(dev)
+    mi = k.ddim_prep(lat_d, cond.to(dev), 8, 2)
+    ref_lat = lat.clone()
+    ref_lat[:, 0] = cond
+    assert torch.equal(lat_d.cpu(), ref_lat)
+    assert mi.shape == (2 * b * f, hh, ww, 8)
+    tok = ref_lat.reshape(b * f, c, hh, ww).permute(0, 2, 3, 1)
+    close(mi[: b * f, ..., :4], h(tok), rel=1e-6, name="prep copy 0")
+    close(mi[b * f:, ..., :4], h(tok), rel=1e-6, name="prep copy 1")
+    sch = DDIMScheduler()
+    sch.set_timesteps(25)
+    ts = sch.timesteps[3:]
+    coef = []
+    for t in ts.tolist():
+        pt = t - 1000 // 25
+        a_t = sch.alphas_cumprod[t]
+        a_p = sch.alphas_cumprod[pt] if pt >= 0 else sch.final_alpha_cumprod
+        coef.append([a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()])
+    coef = torch.tensor(coef, dtype=torch.float32)
+    npred = h(torch.randn(2 * b * f, hh, ww, 4, generator=g))
+    step = torch.tensor([5], dtype=torch.int32, device=dev)
+    k.ddim_cfg_step(lat_d, npred.half().to(dev), coef.to(dev), step, 7.5, 2)
+    assert int(step.item()) == 6
+    u, cnd = npred[: b * f], npred[b * f:]
+    eps = (u + 7.5 * (cnd - u)).permute(0, 3, 1, 2).reshape(b, f, c, hh, ww)
+    ref = sch.step(eps, ts[5], ref_lat)
+    close(lat_d, ref, rel=1e-5, name="ddim step")
+
+
+def test_bad_arguments_raise(dev):
+    import i2v_adapter_unofficial_amd as pkg
+    k = K()
+    with pytest.raises(pkg.HipLibraryError):
+        k.gemm(torch.zeros(4, 8, dtype=torch.float16), torch.zeros(4, 8, dtype=torch.float16))     # CPU tensors
+    with pytest.raises(pkg.HipLibraryError):
+        k.gemm(torch.zeros(4, 12, dtype=torch.float16, device=dev), torch.zeros(4, 12, dtype=torch.float16, device=dev))
+    with pytest.raises(pkg.HipLibraryError):
+        k.attention(torch.zeros(8, 12, dtype=torch.float16, device=dev), torch.zeros(8, 12, dtype=torch.float16, device=dev),
+                    torch.zeros(1, 12, 8, dtype=torch.float16, device=dev), batch_q=1, lq=8, lk=8, heads=1, head_dim=12)
