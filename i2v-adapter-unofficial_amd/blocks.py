@@ -1,0 +1,687 @@
+"""Host-side building blocks of the I2V-Adapter path on the HIP kernels.
+
+These classes mirror the `diffusers` modules the reference constructs: same names, ctor
+kwargs, attribute names and state-dict keys, so reference checkpoints load by key.  torch.nn modules are used
+ONLY as parameter containers; every `forward` runs the hand-written HIP kernels through
+`i2v_adapter_unofficial_amd.kernels` (C ABI).  Internally activations are token-major fp16:
+images are [N, H, W, C] tensors, token matrices are [rows, C]; the public `forward`s accept / return the
+reference's NCHW tensors and convert at the edge.
+"""
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from ._lib import (I2V_EPI_GEGLU, I2V_EPI_GELU, I2V_EPI_NONE, I2V_STORE_ROWPERM, HipLibraryError)
+
+f16 = torch.float16
+
+
+# ----------------------------------------------------------------------------------------------------------
+class HipModule(nn.Module):
+    """Base class: lazily (re)builds kernel-layout fp16 copies of the parameters (`_pack`) whenever a
+    parameter was moved, cast or overwritten (data_ptr / version check)."""
+
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+        self._packed_key = None
+
+    def _pack(self):
+        return {}
+
+    def packed(self):
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in self.parameters())
+        key += tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if self._packed is None or key != self._packed_key:
+            for p in self.parameters():
+                if not p.is_cuda:
+                    raise HipLibraryError(
+                        f"{type(self).__name__} has parameters on {p.device}: the HIP path has no CPU fallback")
+            with torch.no_grad():
+                self._packed = self._pack()
+            self._packed_key = key
+        return self._packed
+
+
+def w16(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(f16).contiguous()
+
+
+def pack_conv3x3(weight: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> [Cout, 9 * Cin'] with k = (ky * 3 + kx) * Cin' + ci (Cin zero-padded to Cin')."""
+    co, ci = weight.shape[:2]
+    w = weight.detach().permute(0, 2, 3, 1)
+    if cin_pad is not None and cin_pad != ci:
+        w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+        ci = cin_pad
+    return w.reshape(co, 9 * ci).to(f16).contiguous()
+
+
+def pack_geglu(weight, bias):
+    """rows (value_i, gate_i) interleaved so that the gate pair lands in one lane of the GEMM epilogue."""
+    inner = weight.shape[0] // 2
+    w = torch.stack([weight[:inner], weight[inner:]], dim=1).reshape(2 * inner, weight.shape[1])
+    b = torch.stack([bias[:inner], bias[inner:]], dim=1).reshape(2 * inner)
+    return w16(w), w16(b)
+
+
+def to_tokens(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
+    """reference NCHW tensor -> token-major fp16 [N, H, W, C]."""
+    return K.nchw_to_tokens(x, c_pad)
+
+
+def from_tokens(x: torch.Tensor, dtype) -> torch.Tensor:
+    return K.tokens_to_nchw(x, dtype=dtype if dtype in (torch.float32, f16) else f16)
+
+
+def _as_f16_matrix(t: torch.Tensor) -> torch.Tensor:
+    """user-facing 2-D / 3-D tensor (fp16 / fp32) -> contiguous fp16 (dtype cast is plumbing at the API edge)."""
+    if not t.is_cuda:
+        raise HipLibraryError(f"tensor on {t.device}: the HIP path has no CPU fallback")
+    return t.to(f16).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------- A1
+class Timesteps(nn.Module):
+    """A1 (unet:763).  No parameters."""
+
+    def __init__(self, num_channels: int, flip_sin_to_cos: bool = True, downscale_freq_shift: float = 0):
+        super().__init__()
+        if not flip_sin_to_cos or downscale_freq_shift != 0:
+            raise NotImplementedError("hot path uses Timesteps(C, flip_sin_to_cos=True, freq_shift=0)")
+        self.num_channels = num_channels
+
+    def forward(self, timesteps: torch.Tensor) -> torch.Tensor:
+        return K.timestep_embedding(timesteps.to(torch.float32).contiguous(), self.num_channels)
+
+
+class TimestepEmbedding(HipModule):
+    """A1 (unet:766-770)."""
+
+    def __init__(self, in_channels: int, time_embed_dim: int, act_fn: str = "silu"):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def _pack(self):
+        return dict(w1=w16(self.linear_1.weight), b1=w16(self.linear_1.bias), w2=w16(self.linear_2.weight),
+                    b2=w16(self.linear_2.bias))
+
+    def forward(self, sample, condition=None):
+        p = self.packed()
+        h = K.silu(K.gemm(_as_f16_matrix(sample), p["w1"], p["b1"]))
+        return K.gemm(h, p["w2"], p["b2"])
+
+
+# ---------------------------------------------------------------------------------------------------------- A2/A3
+class ResnetBlock2D(HipModule):
+    """A2.  GN+SiLU -> conv3x3 (+bias +time-embedding row add fused) -> GN+SiLU -> conv3x3 (+bias + shortcut /
+    residual fused).  The skip concat of the up blocks (unet:478) is never materialised: GroupNorm reads both
+    sources and the 1x1 shortcut GEMM takes two K ranges."""
+
+    def __init__(self, in_channels, out_channels=None, temb_channels=512, eps=1e-6, groups=32,
+                 output_scale_factor=1.0, **_unused):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.output_scale_factor = output_scale_factor
+        self.groups, self.eps = groups, eps
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride=1, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps, affine=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, stride=1, padding=1)
+        self.nonlinearity = nn.SiLU()
+        self.conv_shortcut = (nn.Conv2d(in_channels, out_channels, 1, stride=1, padding=0)
+                              if in_channels != out_channels else None)
+
+    def _pack(self):
+        p = dict(g1=w16(self.norm1.weight), b1=w16(self.norm1.bias), w1=pack_conv3x3(self.conv1.weight),
+                 cb1=w16(self.conv1.bias), g2=w16(self.norm2.weight), b2=w16(self.norm2.bias),
+                 w2=pack_conv3x3(self.conv2.weight), cb2=w16(self.conv2.bias))
+        if self.time_emb_proj is not None:
+            p["wt"], p["bt"] = w16(self.time_emb_proj.weight), w16(self.time_emb_proj.bias)
+        if self.conv_shortcut is not None:
+            p["ws"] = w16(self.conv_shortcut.weight.reshape(self.out_channels, self.in_channels))
+            p["bs"] = w16(self.conv_shortcut.bias)
+        return p
+
+    def _fwd(self, x, temb_act, x2=None):
+        """x [N, H, W, C1] (+ x2 [N, H, W, C2] = channel concat); temb_act = silu(temb) [R, Tc] with N % R == 0."""
+        p = self.packed()
+        n, hh, ww, c1 = x.shape
+        cin = c1 + (x2.shape[3] if x2 is not None else 0)
+        if cin != self.in_channels:
+            raise ValueError(f"ResnetBlock2D expects {self.in_channels} input channels, got {cin}")
+        h = K.groupnorm(x, p["g1"], p["b1"], self.groups, self.eps, x2=x2, silu=True)
+        rowvec, rpv = None, 0
+        if self.time_emb_proj is not None and temb_act is not None:
+            rowvec = K.gemm(temb_act, p["wt"], p["bt"])
+            rpv = (n // temb_act.shape[0]) * hh * ww
+        h = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv)
+        h = K.groupnorm(h, p["g2"], p["b2"], self.groups, self.eps, silu=True)
+        if self.conv_shortcut is not None:
+            a2 = None if x2 is None else x2.view(-1, x2.shape[3])
+            s = K.gemm(x.view(-1, c1), p["ws"], p["bs"], a2=a2).view(n, hh, ww, self.out_channels)
+        else:
+            if x2 is not None:
+                raise ValueError("concat input needs a conv_shortcut")
+            s = x
+        return K.conv3x3(h, p["w2"], p["cb2"], residual=s, out_scale=1.0 / self.output_scale_factor)
+
+    def forward(self, input_tensor, temb, scale: float = 1.0):
+        x = to_tokens(input_tensor)
+        ta = K.silu(_as_f16_matrix(temb)) if temb is not None else None
+        return from_tokens(self._fwd(x, ta), input_tensor.dtype)
+
+
+class Downsample2D(HipModule):
+    """A3 (unet:250-259): conv 3x3, stride 2, padding 1."""
+
+    def __init__(self, channels, use_conv=True, out_channels=None, padding=1, name="conv"):
+        super().__init__()
+        if not use_conv or padding != 1:
+            raise NotImplementedError("hot path uses Downsample2D(use_conv=True, padding=1)")
+        out_channels = out_channels or channels
+        self.conv = nn.Conv2d(channels, out_channels, 3, stride=2, padding=padding)
+
+    def _pack(self):
+        return dict(w=pack_conv3x3(self.conv.weight), b=w16(self.conv.bias))
+
+    def _fwd(self, x):
+        p = self.packed()
+        return K.conv3x3(x, p["w"], p["b"], stride=2)
+
+    def forward(self, hidden_states, scale: float = 1.0):
+        return from_tokens(self._fwd(to_tokens(hidden_states)), hidden_states.dtype)
+
+
+class Upsample2D(HipModule):
+    """A3 (unet:431-432): nearest x2 folded into the conv's input gather (no upsampled tensor is written)."""
+
+    def __init__(self, channels, use_conv=True, out_channels=None):
+        super().__init__()
+        if not use_conv:
+            raise NotImplementedError("hot path uses Upsample2D(use_conv=True)")
+        out_channels = out_channels or channels
+        self.conv = nn.Conv2d(channels, out_channels, 3, padding=1)
+
+    def _pack(self):
+        return dict(w=pack_conv3x3(self.conv.weight), b=w16(self.conv.bias))
+
+    def _fwd(self, x, output_size=None):
+        if output_size is not None and tuple(output_size) != (2 * x.shape[1], 2 * x.shape[2]):
+            raise NotImplementedError("Upsample2D: only exact 2x nearest upsampling is implemented "
+                                      "(latent sizes must be divisible by 2**num_upsamplers)")
+        p = self.packed()
+        return K.conv3x3(x, p["w"], p["b"], upsample=True)
+
+    def forward(self, hidden_states, output_size=None, scale: float = 1.0):
+        return from_tokens(self._fwd(to_tokens(hidden_states), output_size), hidden_states.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------- A4/A5
+class Attention(HipModule):
+    """A4 parameter container (+A5 IP-Adapter branch) with a stand-alone forward.
+
+    The transformer blocks do not call this forward: they fuse the projections of several Attention modules
+    (e.g. attn1.to_q | attn1.to_k | i2v_adapter.to_q in one GEMM).  The stand-alone forward is the generic
+    form: q / k GEMMs, V^T emitted by the GEMM epilogue, flash attention, out-projection."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, bias=False, out_bias=True,
+                 dropout=0.0, upcast_attention=False):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("attention_bias=True is not on the hot path")
+        self.inner_dim = dim_head * heads
+        self.heads, self.dim_head = heads, dim_head
+        self.query_dim = query_dim
+        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.scale = dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, self.inner_dim, bias=False)
+        self.to_k = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=False)
+        self.to_v = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(self.inner_dim, query_dim, bias=out_bias), nn.Dropout(dropout)])
+        self.ip_num_tokens, self.ip_scale = 0, 1.0
+        self.to_k_ip = None
+        self.to_v_ip = None
+
+    def install_ip_adapter(self, to_k_ip_weight, to_v_ip_weight, num_tokens=4, scale=1.0):
+        """A5 (unet:1264-1279)."""
+        dev, dt = self.to_q.weight.device, self.to_q.weight.dtype
+        self.to_k_ip = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=False).to(device=dev, dtype=dt)
+        self.to_v_ip = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=False).to(device=dev, dtype=dt)
+        with torch.no_grad():
+            self.to_k_ip.weight.copy_(to_k_ip_weight)
+            self.to_v_ip.weight.copy_(to_v_ip_weight)
+        self.ip_num_tokens, self.ip_scale = num_tokens, scale
+
+    def _pack(self):
+        ob = self.to_out[0].bias
+        p = dict(wq=w16(self.to_q.weight), wk=w16(self.to_k.weight), wv=w16(self.to_v.weight),
+                 wo=w16(self.to_out[0].weight), bo=None if ob is None else w16(ob))
+        if self.to_k_ip is not None:
+            p["wk_ip"], p["wv_ip"] = w16(self.to_k_ip.weight), w16(self.to_v_ip.weight)
+        return p
+
+    def _cross(self, q, ctx_text, ctx_ip, batch_q, lq, kv_group):
+        """softmax(q Kt^T) Vt (+ ip_scale * softmax(q Kip^T) Vip) for context tensors [Bc, L, D]."""
+        p = self.packed()
+        bc, lt, dc = ctx_text.shape
+        k = K.gemm(ctx_text.view(-1, dc), p["wk"])
+        vt = K.project_vt(ctx_text.view(-1, dc), p["wv"], lt)
+        o = K.attention(q, k, vt, batch_q=batch_q, lq=lq, lk=lt, heads=self.heads, head_dim=self.dim_head,
+                        kv_group=kv_group, scale=self.scale)
+        if ctx_ip is not None:
+            li = ctx_ip.shape[1]
+            kip = K.gemm(ctx_ip.view(-1, dc), p["wk_ip"])
+            vtip = K.project_vt(ctx_ip.view(-1, dc), p["wv_ip"], li)
+            K.attention(q, kip, vtip, batch_q=batch_q, lq=lq, lk=li, heads=self.heads, head_dim=self.dim_head,
+                        kv_group=kv_group, scale=self.scale, out=o, accumulate=True, acc_scale=self.ip_scale)
+        return o
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are never passed on the hot path (SURVEY 8b)")
+        p = self.packed()
+        x = _as_f16_matrix(hidden_states)
+        b, l, c = x.shape
+        q = K.gemm(x.view(-1, c), p["wq"])
+        ctx = x if encoder_hidden_states is None else _as_f16_matrix(encoder_hidden_states)
+        ctx_ip = None
+        if self.ip_num_tokens and encoder_hidden_states is not None:
+            end = ctx.shape[1] - self.ip_num_tokens
+            ctx_text = torch.empty((ctx.shape[0], end, ctx.shape[2]), dtype=f16, device=x.device)
+            ctx_ip = torch.empty((ctx.shape[0], self.ip_num_tokens, ctx.shape[2]), dtype=f16, device=x.device)
+            K.copy3d(ctx[:, :end], ctx_text)
+            K.copy3d(ctx[:, end:], ctx_ip)
+            ctx = ctx_text
+        if b % ctx.shape[0] != 0:
+            raise ValueError(f"context batch {ctx.shape[0]} does not divide query batch {b}")
+        o = self._cross(q, ctx, ctx_ip, b, l, b // ctx.shape[0])
+        out = K.gemm(o, p["wo"], p["bo"])
+        return out.view(b, l, -1).to(hidden_states.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------- A7
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out, bias=True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2, bias=bias)
+
+
+class GELU(nn.Module):
+    def __init__(self, dim_in, dim_out, approximate="none", bias=True):
+        super().__init__()
+        if approximate != "none":
+            raise NotImplementedError("only erf GELU is implemented")
+        self.proj = nn.Linear(dim_in, dim_out, bias=bias)
+
+
+class FeedForward(HipModule):
+    """A7: Linear(C -> 8C) with the GEGLU gate fused into the GEMM epilogue, then Linear(4C -> C) with the
+    residual add fused."""
+
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu", inner_dim=None, bias=True):
+        super().__init__()
+        if not bias:
+            raise NotImplementedError("ff_bias=False is not on the hot path")
+        inner_dim = int(dim * mult) if inner_dim is None else inner_dim
+        dim_out = dim if dim_out is None else dim_out
+        self.activation_fn = activation_fn
+        if activation_fn == "geglu":
+            act = GEGLU(dim, inner_dim, bias=bias)
+        elif activation_fn == "gelu":
+            act = GELU(dim, inner_dim, bias=bias)
+        else:
+            raise ValueError(f"unsupported activation_fn {activation_fn}")
+        self.net = nn.ModuleList([act, nn.Dropout(dropout), nn.Linear(inner_dim, dim_out, bias=bias)])
+
+    def _pack(self):
+        proj = self.net[0].proj
+        if self.activation_fn == "geglu":
+            w1, b1 = pack_geglu(proj.weight.detach(), proj.bias.detach())
+        else:
+            w1, b1 = w16(proj.weight), w16(proj.bias)
+        return dict(w1=w1, b1=b1, w2=w16(self.net[2].weight), b2=w16(self.net[2].bias))
+
+    def _fwd(self, n2d, residual2d, **store):
+        p = self.packed()
+        epi = I2V_EPI_GEGLU if self.activation_fn == "geglu" else I2V_EPI_GELU
+        h = K.gemm(n2d, p["w1"], p["b1"], epilogue=epi)
+        return K.gemm(h, p["w2"], p["b2"], residual=residual2d, **store)
+
+    def forward(self, hidden_states, scale: float = 1.0):
+        x = _as_f16_matrix(hidden_states)
+        shp = x.shape
+        return self._fwd(x.view(-1, shp[-1]), None).view(*shp[:-1], -1).to(hidden_states.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------- A10
+class SinusoidalPositionalEmbedding(nn.Module):
+    """A10: buffer `pe` [1, max_len, C]; the add is fused into the LayerNorm kernel."""
+
+    def __init__(self, embed_dim: int, max_seq_length: int = 32):
+        super().__init__()
+        position = torch.arange(max_seq_length).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, embed_dim, 2) * (-math.log(10000.0) / embed_dim))
+        pe = torch.zeros(1, max_seq_length, embed_dim)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+
+class TemporalTransformerBlock(HipModule):
+    """BasicTransformerBlock(double_self_attention=True, positional_embeddings="sinusoidal") of A9, on tokens in
+    (b, pixel, frame) order: LN(+pe) -> fused q|k GEMM + V^T GEMM -> temporal attention -> out-proj (+residual),
+    twice; then LN -> GEGLU FF (+residual)."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, dropout=0.0, cross_attention_dim=None,
+                 activation_fn="geglu", attention_bias=False, double_self_attention=True,
+                 norm_elementwise_affine=True, norm_eps=1e-5, positional_embeddings="sinusoidal",
+                 num_positional_embeddings=32, **_unused):
+        super().__init__()
+        if cross_attention_dim is not None or not double_self_attention or positional_embeddings != "sinusoidal":
+            raise NotImplementedError("motion modules use double self-attention with sinusoidal positions (A9)")
+        self.dim, self.heads, self.dim_head = dim, num_attention_heads, attention_head_dim
+        self.eps = norm_eps
+        self.max_len = num_positional_embeddings
+        self.pos_embed = SinusoidalPositionalEmbedding(dim, max_seq_length=num_positional_embeddings)
+        self.norm1 = nn.LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+        self.attn1 = Attention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim,
+                               dropout=dropout, bias=attention_bias)
+        self.norm2 = nn.LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+        self.attn2 = Attention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim,
+                               dropout=dropout, bias=attention_bias)
+        self.norm3 = nn.LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
+
+    def _pack(self):
+        p = dict(pe=w16(self.pos_embed.pe[0]))
+        for i, (norm, attn) in enumerate(((self.norm1, self.attn1), (self.norm2, self.attn2)), 1):
+            p[f"g{i}"], p[f"b{i}"] = w16(norm.weight), w16(norm.bias)
+            p[f"wqk{i}"] = w16(torch.cat([attn.to_q.weight, attn.to_k.weight], dim=0))
+            p[f"wv{i}"] = w16(attn.to_v.weight)
+            p[f"wo{i}"], p[f"bo{i}"] = w16(attn.to_out[0].weight), w16(attn.to_out[0].bias)
+        p["g3"], p["b3"] = w16(self.norm3.weight), w16(self.norm3.bias)
+        return p
+
+    def _fwd(self, t, n_pixels, frames, **final_store):
+        """t [n_pixels * frames, C] in (b, pixel, frame) order.  `final_store` (ROWPERM + residual) is applied by
+        the caller's proj_out, not here."""
+        if frames > self.max_len:
+            raise ValueError(f"num_frames {frames} exceeds the positional table ({self.max_len})")
+        p = self.packed()
+        c = self.dim
+        for i in (1, 2):
+            n = K.layernorm(t, p[f"g{i}"], p[f"b{i}"], self.eps, pe=p["pe"], pe_period=frames)
+            qk = K.gemm(n, p[f"wqk{i}"])
+            vt = K.project_vt(n, p[f"wv{i}"], frames)
+            o = K.temporal_attention(qk[:, :c], qk[:, c:], vt, n_pixels=n_pixels, frames=frames, heads=self.heads,
+                                     head_dim=self.dim_head, scale=self.dim_head ** -0.5)
+            t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)
+        n = K.layernorm(t, p["g3"], p["b3"], self.eps)
+        return self.ff._fwd(n, t)
+
+
+class TransformerTemporalModel(HipModule):
+    """A9 motion module (unet:232-244, 413-425, 607-619).
+
+    MI355X layout: the GroupNorm entry kernel (statistics over (C/G, F, H, W) per clip) writes its output in
+    (b, pixel, frame) row order, so the sequence of one pixel is `frames` consecutive rows for every GEMM /
+    LayerNorm / attention inside the module, and the proj_out GEMM epilogue stores rows back in (b, frame, pixel)
+    order while adding the residual.  The reference's four permute+contiguous copies per module disappear."""
+
+    def __init__(self, num_attention_heads=16, attention_head_dim=88, in_channels=None, out_channels=None,
+                 num_layers=1, dropout=0.0, norm_num_groups=32, cross_attention_dim=None, attention_bias=False,
+                 activation_fn="geglu", norm_elementwise_affine=True, double_self_attention=True,
+                 positional_embeddings=None, num_positional_embeddings=None):
+        super().__init__()
+        inner_dim = num_attention_heads * attention_head_dim
+        self.in_channels, self.inner_dim = in_channels, inner_dim
+        self.groups = norm_num_groups
+        self.norm = nn.GroupNorm(norm_num_groups, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList([
+            TemporalTransformerBlock(inner_dim, num_attention_heads, attention_head_dim, dropout=dropout,
+                                     cross_attention_dim=cross_attention_dim, activation_fn=activation_fn,
+                                     attention_bias=attention_bias, double_self_attention=double_self_attention,
+                                     norm_elementwise_affine=norm_elementwise_affine,
+                                     positional_embeddings=positional_embeddings,
+                                     num_positional_embeddings=num_positional_embeddings)
+            for _ in range(num_layers)])
+        self.proj_out = nn.Linear(inner_dim, in_channels)
+
+    def _pack(self):
+        return dict(g=w16(self.norm.weight), b=w16(self.norm.bias), wi=w16(self.proj_in.weight),
+                    bi=w16(self.proj_in.bias), wo=w16(self.proj_out.weight), bo=w16(self.proj_out.bias))
+
+    def _fwd(self, x, num_frames):
+        p = self.packed()
+        n, hh, ww, c = x.shape
+        if n % num_frames != 0:
+            raise ValueError(f"batch {n} is not a multiple of num_frames {num_frames}")
+        n_pixels = (n // num_frames) * hh * ww
+        h = K.groupnorm(x, p["g"], p["b"], self.groups, 1e-6, frames_per_stat=num_frames, out_perm=True,
+                        frames=num_frames)                                   # rows now (b, pixel, frame)
+        t = K.gemm(h, p["wi"], p["bi"])
+        for blk in self.transformer_blocks:
+            t = blk._fwd(t, n_pixels, num_frames)
+        out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c), store=I2V_STORE_ROWPERM, frames=num_frames,
+                     hw=hh * ww)                                            # rows back in (b, frame, pixel)
+        return out.view(n, hh, ww, c)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, num_frames: int = 1, return_dict=False, **_unused):
+        return (from_tokens(self._fwd(to_tokens(hidden_states), num_frames), hidden_states.dtype),)
+
+
+# ---------------------------------------------------------------------------------------------------------- A6
+class ImageProjection(HipModule):
+    """A6 (unet:1284-1287)."""
+
+    def __init__(self, image_embed_dim=768, cross_attention_dim=768, num_image_text_embeds=4):
+        super().__init__()
+        self.num_image_text_embeds = num_image_text_embeds
+        self.cross_attention_dim = cross_attention_dim
+        self.image_embeds = nn.Linear(image_embed_dim, num_image_text_embeds * cross_attention_dim)
+        self.norm = nn.LayerNorm(cross_attention_dim)
+
+    def _pack(self):
+        return dict(w=w16(self.image_embeds.weight), b=w16(self.image_embeds.bias), g=w16(self.norm.weight),
+                    be=w16(self.norm.bias))
+
+    def forward(self, image_embeds):
+        p = self.packed()
+        x = _as_f16_matrix(image_embeds)
+        y = K.gemm(x, p["w"], p["b"]).view(-1, self.cross_attention_dim)
+        y = K.layernorm(y, p["g"], p["be"], self.norm.eps)
+        return y.view(x.shape[0], self.num_image_text_embeds, self.cross_attention_dim)
+
+
+# ---------------------------------------------------------------------------------------------------------- A11
+def _motion(out_channels, heads, groups, cross_dim, max_seq):
+    return TransformerTemporalModel(num_attention_heads=heads, in_channels=out_channels, norm_num_groups=groups,
+                                    cross_attention_dim=cross_dim, attention_bias=False, activation_fn="geglu",
+                                    positional_embeddings="sinusoidal", num_positional_embeddings=max_seq,
+                                    attention_head_dim=out_channels // heads)
+
+
+class DownBlockMotion(nn.Module):
+    """A11 (unet:54-68)."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
+                 output_scale_factor=1.0, add_downsample=True, downsample_padding=1,
+                 temporal_num_attention_heads=1, temporal_cross_attention_dim=None, temporal_max_seq_length=32,
+                 **_unused):
+        super().__init__()
+        resnets, motion_modules = [], []
+        for i in range(num_layers):
+            cin = in_channels if i == 0 else out_channels
+            resnets.append(ResnetBlock2D(cin, out_channels, temb_channels=temb_channels, eps=resnet_eps,
+                                         groups=resnet_groups, output_scale_factor=output_scale_factor))
+            motion_modules.append(_motion(out_channels, temporal_num_attention_heads, resnet_groups,
+                                          temporal_cross_attention_dim, temporal_max_seq_length))
+        self.resnets = nn.ModuleList(resnets)
+        self.motion_modules = nn.ModuleList(motion_modules)
+        self.downsamplers = (nn.ModuleList([Downsample2D(out_channels, use_conv=True, out_channels=out_channels,
+                                                         padding=downsample_padding, name="op")])
+                             if add_downsample else None)
+
+    def _fwd(self, x, temb_act, num_frames):
+        states = ()
+        for resnet, motion in zip(self.resnets, self.motion_modules):
+            x = resnet._fwd(x, temb_act)
+            x = motion._fwd(x, num_frames)
+            states += (x,)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                x = d._fwd(x)
+            states += (x,)
+        return x, states
+
+    def forward(self, hidden_states, temb=None, scale: float = 1.0, num_frames: int = 1):
+        ta = K.silu(_as_f16_matrix(temb)) if temb is not None else None
+        x, states = self._fwd(to_tokens(hidden_states), ta, num_frames)
+        dt = hidden_states.dtype
+        return from_tokens(x, dt), tuple(from_tokens(s, dt) for s in states)
+
+
+class UpBlockMotion(nn.Module):
+    """A11 (unet:122-137)."""
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, resolution_idx=None,
+                 num_layers=1, resnet_eps=1e-6, resnet_groups=32, output_scale_factor=1.0, add_upsample=True,
+                 temporal_num_attention_heads=1, temporal_cross_attention_dim=None, temporal_max_seq_length=32,
+                 **_unused):
+        super().__init__()
+        resnets, motion_modules = [], []
+        for i in range(num_layers):
+            res_skip_channels = in_channels if (i == num_layers - 1) else out_channels
+            resnet_in_channels = prev_output_channel if i == 0 else out_channels
+            resnets.append(ResnetBlock2D(resnet_in_channels + res_skip_channels, out_channels,
+                                         temb_channels=temb_channels, eps=resnet_eps, groups=resnet_groups,
+                                         output_scale_factor=output_scale_factor))
+            motion_modules.append(_motion(out_channels, temporal_num_attention_heads, resnet_groups,
+                                          temporal_cross_attention_dim, temporal_max_seq_length))
+        self.resnets = nn.ModuleList(resnets)
+        self.motion_modules = nn.ModuleList(motion_modules)
+        self.upsamplers = (nn.ModuleList([Upsample2D(out_channels, use_conv=True, out_channels=out_channels)])
+                           if add_upsample else None)
+        self.resolution_idx = resolution_idx
+
+    def _fwd(self, x, res_tuple, temb_act, num_frames, upsample_size=None):
+        for resnet, motion in zip(self.resnets, self.motion_modules):
+            skip = res_tuple[-1]
+            res_tuple = res_tuple[:-1]
+            x = resnet._fwd(x, temb_act, x2=skip)        # torch.cat([x, skip], 1) never materialised (unet:478)
+            x = motion._fwd(x, num_frames)
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                x = u._fwd(x, upsample_size)
+        return x
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, upsample_size=None, scale: float = 1.0,
+                num_frames: int = 1):
+        ta = K.silu(_as_f16_matrix(temb)) if temb is not None else None
+        res = tuple(to_tokens(r) for r in res_hidden_states_tuple)
+        return from_tokens(self._fwd(to_tokens(hidden_states), res, ta, num_frames, upsample_size),
+                           hidden_states.dtype)
+
+
+class MotionAdapter(nn.Module):
+    """Weight container with diffusers `MotionAdapter`'s state-dict layout (unet:1028-1036)."""
+
+    def __init__(self, block_out_channels=(320, 640, 1280, 1280), motion_layers_per_block=2,
+                 motion_mid_block_layers_per_block=1, motion_num_attention_heads=8, motion_norm_num_groups=32,
+                 motion_max_seq_length=32, use_motion_mid_block=True):
+        super().__init__()
+        self.config = dict(block_out_channels=tuple(block_out_channels),
+                           motion_layers_per_block=motion_layers_per_block,
+                           motion_mid_block_layers_per_block=motion_mid_block_layers_per_block,
+                           motion_num_attention_heads=motion_num_attention_heads,
+                           motion_norm_num_groups=motion_norm_num_groups,
+                           motion_max_seq_length=motion_max_seq_length,
+                           use_motion_mid_block=use_motion_mid_block)
+
+        def mm(ch, n):
+            m = nn.Module()
+            m.motion_modules = nn.ModuleList([
+                _motion(ch, motion_num_attention_heads, motion_norm_num_groups, None, motion_max_seq_length)
+                for _ in range(n)])
+            return m
+
+        self.down_blocks = nn.ModuleList([mm(c, motion_layers_per_block) for c in block_out_channels])
+        self.mid_block = (mm(block_out_channels[-1], motion_mid_block_layers_per_block)
+                          if use_motion_mid_block else None)
+        self.up_blocks = nn.ModuleList([mm(c, motion_layers_per_block + 1) for c in reversed(block_out_channels)])
+
+
+# ---------------------------------------------------------------------------------------------------------- A12
+class DDIMScheduler:
+    """A12 host side: the beta / alpha tables, the timestep list and the per-step coefficient table that the
+    device-side `i2v_ddim_cfg_step` kernel reads (pipe:755-757: SD-1.5 scheduler config, clip_sample=False,
+    timestep_spacing="linspace", steps_offset=1, epsilon prediction, set_alpha_to_one=False)."""
+
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                 beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
+                 timestep_spacing="linspace", prediction_type="epsilon"):
+        if beta_schedule == "scaled_linear":
+            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                                        dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise ValueError(beta_schedule)
+        if clip_sample or prediction_type != "epsilon":
+            raise NotImplementedError("hot path uses clip_sample=False, epsilon prediction")
+        self.num_train_timesteps = num_train_timesteps
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.steps_offset = steps_offset
+        self.timestep_spacing = timestep_spacing
+        self.num_inference_steps = None
+        self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.int64)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        import numpy as np
+        self.num_inference_steps = num_inference_steps
+        if self.timestep_spacing == "linspace":
+            ts = (np.linspace(0, self.num_train_timesteps - 1, num_inference_steps).round()[::-1]
+                  .copy().astype(np.int64))
+        elif self.timestep_spacing == "leading":
+            ratio = self.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+            ts += self.steps_offset
+        else:
+            raise ValueError(self.timestep_spacing)
+        self.timesteps = torch.from_numpy(ts)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step_coefficients(self, timesteps) -> torch.Tensor:
+        """[len(timesteps), 4] fp32: sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev), sqrt(1 - a_prev) with
+        t_prev = t - num_train_timesteps // num_inference_steps (the FULL step count, A12)."""
+        rows = []
+        for t in [int(v) for v in timesteps]:
+            prev_t = t - self.num_train_timesteps // self.num_inference_steps
+            a_t = self.alphas_cumprod[t]
+            a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+            rows.append(torch.stack([a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5]))
+        return torch.stack(rows).to(torch.float32)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        timesteps = timesteps.to(original_samples.device)
+        sa = (ac[timesteps] ** 0.5).flatten()
+        sb = ((1 - ac[timesteps]) ** 0.5).flatten()
+        while sa.dim() < original_samples.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * original_samples + sb * noise

@@ -1,0 +1,269 @@
+"""I2V-Adapter modules on the HIP kernels: drop-in for /root/reference/src/modules/i2v_adapter.py.
+
+Same class names, constructor kwargs, attribute names, state-dict keys and error behaviour as the reference
+(`I2VAdapterModule` i2v:49-93, `I2VAdapterTransformer2DModel` i2v:95-354, `I2VAdapterTransformerBlock`
+i2v:356-565).  The arithmetic runs in libi2v_hip.so; there is no CPU path.
+
+Cross-frame adapter attention (K1, i2v:475-494), MI355X-first: the reference repeats the frame-0 tokens F
+times and runs an ordinary cross-attention (F redundant K/V projections, F copies of K/V in HBM).  Here the
+frame-0 rows are gathered once per clip, K0 / V0^T are projected once, and the attention kernel maps every
+query frame of a clip onto the same K0 / V0^T (kv_group = F).  The adapter's to_q shares one GEMM with attn1's
+to_q | to_k, and both out-projections (+ both biases + the residual) are one dual-source GEMM.
+"""
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from .blocks import (Attention, FeedForward, HipModule, _as_f16_matrix, from_tokens, to_tokens, w16)
+
+f16 = torch.float16
+
+
+def get_block(out_channel, block_depth, num_attention_heads, transformer_layers_per_block):
+    """i2v:17-47."""
+    block = nn.Module()
+    attn_blocks = []
+    for _ in range(block_depth):
+        attn_block = nn.Module()
+        tbs = []
+        for _ in range(transformer_layers_per_block):
+            tb = nn.Module()
+            tb.i2v_adapter = Attention(query_dim=out_channel, heads=num_attention_heads,
+                                       dim_head=out_channel // num_attention_heads,
+                                       cross_attention_dim=out_channel)
+            tbs.append(tb)
+        attn_block.transformer_blocks = nn.ModuleList(tbs)
+        attn_blocks.append(attn_block)
+    block.attentions = nn.ModuleList(attn_blocks)
+    return block
+
+
+class I2VAdapterModule(nn.Module):
+    """i2v:49-93: the adapter checkpoint container (`down_blocks[].attentions[].transformer_blocks[].i2v_adapter`)."""
+
+    def __init__(self, block_depth, block_out_channels, num_attention_heads,
+                 transformer_layers_per_block: int = 1, mid_block_depth: int = 1):
+        super().__init__()
+        self.config = dict(block_depth=block_depth, block_out_channels=tuple(block_out_channels),
+                           num_attention_heads=num_attention_heads,
+                           transformer_layers_per_block=transformer_layers_per_block,
+                           mid_block_depth=mid_block_depth)
+        self.down_blocks = nn.ModuleList([
+            get_block(c, block_depth, num_attention_heads, transformer_layers_per_block)
+            for c in block_out_channels[:-1]])
+        rev = list(reversed(block_out_channels[:-1]))
+        up_blocks = nn.ModuleList([
+            get_block(c, block_depth + 1, num_attention_heads, transformer_layers_per_block) for c in rev])
+        self.up_blocks = nn.ModuleList([nn.Identity()]) + up_blocks
+        self.mid_block = get_block(block_out_channels[-1], mid_block_depth, num_attention_heads,
+                                   transformer_layers_per_block)
+
+    def forward(self):
+        pass
+
+
+class I2VAdapterTransformerBlock(HipModule):
+    """i2v:356-565 (layer-norm branch)."""
+
+    def __init__(self, dim: int, num_attention_heads: int, attention_head_dim: int, dropout=0.0,
+                 cross_attention_dim: Optional[int] = None, activation_fn: str = "geglu",
+                 num_embeds_ada_norm: Optional[int] = None, attention_bias: bool = False,
+                 only_cross_attention: bool = False, double_self_attention: bool = False,
+                 upcast_attention: bool = False, norm_elementwise_affine: bool = True,
+                 norm_type: str = "layer_norm", norm_eps: float = 1e-5, final_dropout: bool = False,
+                 attention_type: str = "default", positional_embeddings: Optional[str] = None,
+                 num_positional_embeddings: Optional[int] = None, ff_inner_dim: Optional[int] = None,
+                 ff_bias: bool = True, attention_out_bias: bool = True, **_unused):
+        super().__init__()
+        if norm_type != "layer_norm" or only_cross_attention or double_self_attention or positional_embeddings:
+            raise NotImplementedError("only the layer-norm spatial block of the hot path is implemented "
+                                      "(SURVEY 8b: ada-norm / GLIGEN / only_cross_attention branches are dropped)")
+        self.dim, self.heads, self.dim_head = dim, num_attention_heads, attention_head_dim
+        self.eps = norm_eps
+        self.only_cross_attention = only_cross_attention
+        self.norm1 = nn.LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+        self.attn1 = Attention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim,
+                               dropout=dropout, bias=attention_bias, out_bias=attention_out_bias)
+        if cross_attention_dim is not None:
+            self.norm2 = nn.LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+            self.attn2 = Attention(query_dim=dim, cross_attention_dim=cross_attention_dim,
+                                   heads=num_attention_heads, dim_head=attention_head_dim, dropout=dropout,
+                                   bias=attention_bias, out_bias=attention_out_bias)
+        else:
+            self.norm2 = None
+            self.attn2 = None
+        self.norm3 = nn.LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, inner_dim=ff_inner_dim,
+                              bias=ff_bias)
+        self.i2v_adapter = Attention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim,
+                                     dropout=dropout, bias=attention_bias, cross_attention_dim=dim,
+                                     out_bias=attention_out_bias)                           # i2v:409-418
+
+    def _pack(self):
+        a1, ad = self.attn1, self.i2v_adapter
+        p = dict(g1=w16(self.norm1.weight), b1=w16(self.norm1.bias), g3=w16(self.norm3.weight),
+                 b3=w16(self.norm3.bias))
+        # one GEMM: [attn1.to_q | attn1.to_k | i2v_adapter.to_q] (the first 2C rows alone when the adapter is off)
+        p["w_qkq"] = w16(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0))
+        p["w_v1"] = w16(a1.to_v.weight)
+        p["w_k_ad"], p["w_v_ad"] = w16(ad.to_k.weight), w16(ad.to_v.weight)
+        p["w_o1"], p["b_o1"] = w16(a1.to_out[0].weight), w16(a1.to_out[0].bias)
+        # attn1.to_out and i2v_adapter.to_out as one GEMM over K = 2C with summed biases
+        p["w_o_dual"] = w16(torch.cat([a1.to_out[0].weight, ad.to_out[0].weight], dim=1))
+        p["b_o_dual"] = w16(a1.to_out[0].bias.float() + ad.to_out[0].bias.float())
+        if self.attn2 is not None:
+            p["g2"], p["b2"] = w16(self.norm2.weight), w16(self.norm2.bias)
+            p["w_q2"] = w16(self.attn2.to_q.weight)
+            p["w_o2"], p["b_o2"] = w16(self.attn2.to_out[0].weight), w16(self.attn2.to_out[0].bias)
+        return p
+
+    def _fwd(self, x, n_img, L, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip):
+        """x [n_img * L, C] tokens; ctx_text [Bc, Lt, Dc] (+ ctx_ip [Bc, Li, Dc]) with n_img % Bc == 0."""
+        p = self.packed()
+        c = self.dim
+        n = K.layernorm(x, p["g1"], p["b1"], self.eps)                                       # i2v:444-445
+        if enable_cross_frame_attn:
+            if num_frames is None:
+                raise ValueError('`num_frames` must be provided when `enable_cross_frame_attn` is True.')
+            if n_img % num_frames != 0:
+                raise ValueError(f'Batch size {n_img} must be divisible by the number of frames {num_frames}.')
+            proj = K.gemm(n, p["w_qkq"])                                                     # q1 | k1 | q_adapter
+        else:
+            proj = K.gemm(n, p["w_qkq"][: 2 * c])
+        vt1 = K.project_vt(n, p["w_v1"], L)
+        o1 = K.attention(proj[:, :c], proj[:, c:2 * c], vt1, batch_q=n_img, lq=L, lk=L, heads=self.heads,
+                         head_dim=self.dim_head, scale=self.dim_head ** -0.5)                # i2v:468-473
+        if enable_cross_frame_attn:
+            clips = n_img // num_frames
+            first = torch.empty((clips, L, c), dtype=f16, device=x.device)
+            K.copy3d(n.view(clips, num_frames * L, c)[:, :L], first)                         # i2v:484 (no repeat)
+            f2d = first.view(-1, c)
+            k0 = K.gemm(f2d, p["w_k_ad"])
+            v0t = K.project_vt(f2d, p["w_v_ad"], L)
+            o2 = K.attention(proj[:, 2 * c:], k0, v0t, batch_q=n_img, lq=L, lk=L, heads=self.heads,
+                             head_dim=self.dim_head, kv_group=num_frames, scale=self.dim_head ** -0.5)
+            x = K.gemm(o1, p["w_o_dual"], p["b_o_dual"], a2=o2, residual=x)                  # i2v:494,501
+        else:
+            x = K.gemm(o1, p["w_o1"], p["b_o1"], residual=x)                                 # i2v:501
+        if self.attn2 is not None:                                                           # i2v:510-533
+            n = K.layernorm(x, p["g2"], p["b2"], self.eps)
+            q = K.gemm(n, p["w_q2"])
+            if ctx_text is None:
+                raise ValueError("encoder_hidden_states is required by the cross-attention layer")
+            if n_img % ctx_text.shape[0] != 0:
+                raise ValueError(f"context batch {ctx_text.shape[0]} does not divide batch {n_img}")
+            o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, n_img // ctx_text.shape[0])
+            x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
+        n = K.layernorm(x, p["g3"], p["b3"], self.eps)                                       # i2v:539
+        return self.ff._fwd(n, x)                                                            # i2v:554,561
+
+    def _split_ctx(self, encoder_hidden_states):
+        if encoder_hidden_states is None:
+            return None, None
+        ctx = _as_f16_matrix(encoder_hidden_states)
+        nip = self.attn2.ip_num_tokens if self.attn2 is not None else 0
+        if not nip:
+            return ctx, None
+        end = ctx.shape[1] - nip
+        ct = torch.empty((ctx.shape[0], end, ctx.shape[2]), dtype=f16, device=ctx.device)
+        ci = torch.empty((ctx.shape[0], nip, ctx.shape[2]), dtype=f16, device=ctx.device)
+        K.copy3d(ctx[:, :end], ct)
+        K.copy3d(ctx[:, end:], ci)
+        return ct, ci
+
+    def forward(self, hidden_states, enable_cross_frame_attn: bool = False, num_frames: Optional[int] = None,
+                attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, timestep=None,
+                cross_attention_kwargs=None, class_labels=None, added_cond_kwargs=None):
+        if attention_mask is not None or encoder_attention_mask is not None:
+            raise NotImplementedError("attention masks are never passed on the hot path (SURVEY 8b)")
+        x = _as_f16_matrix(hidden_states)
+        b, l, c = x.shape
+        ct, ci = self._split_ctx(encoder_hidden_states)
+        out = self._fwd(x.view(-1, c), b, l, enable_cross_frame_attn, num_frames, ct, ci)
+        return out.view(b, l, c).to(hidden_states.dtype)
+
+
+class _Out:
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class I2VAdapterTransformer2DModel(HipModule):
+    """i2v:95-354, continuous-input branch.  In token-major layout the reference's two permute+reshape copies
+    (i2v:226,300) are no-ops and the 1x1 proj_in / proj_out convolutions are plain GEMMs (proj_out fuses the
+    `+ residual` of i2v:314)."""
+
+    def __init__(self, num_attention_heads: int = 16, attention_head_dim: int = 88,
+                 in_channels: Optional[int] = None, out_channels: Optional[int] = None, num_layers: int = 1,
+                 dropout: float = 0.0, norm_num_groups: int = 32, cross_attention_dim: Optional[int] = None,
+                 attention_bias: bool = False, sample_size: Optional[int] = None,
+                 num_vector_embeds: Optional[int] = None, patch_size: Optional[int] = None,
+                 activation_fn: str = "geglu", num_embeds_ada_norm: Optional[int] = None,
+                 use_linear_projection: bool = False, only_cross_attention: bool = False,
+                 double_self_attention: bool = False, upcast_attention: bool = False,
+                 norm_type: str = "layer_norm", norm_elementwise_affine: bool = True, norm_eps: float = 1e-5,
+                 attention_type: str = "default", caption_channels: int = None):
+        super().__init__()
+        if in_channels is None or num_vector_embeds is not None or patch_size is not None:
+            raise NotImplementedError("only the continuous-input branch is on the hot path (SURVEY 8b)")
+        inner_dim = num_attention_heads * attention_head_dim
+        self.in_channels, self.inner_dim = in_channels, inner_dim
+        self.groups = norm_num_groups
+        self.use_linear_projection = use_linear_projection
+        self.norm = nn.GroupNorm(norm_num_groups, in_channels, eps=1e-6, affine=True)
+        if use_linear_projection:
+            self.proj_in = nn.Linear(in_channels, inner_dim)
+        else:
+            self.proj_in = nn.Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList([
+            I2VAdapterTransformerBlock(inner_dim, num_attention_heads, attention_head_dim, dropout=dropout,
+                                       cross_attention_dim=cross_attention_dim, activation_fn=activation_fn,
+                                       attention_bias=attention_bias, only_cross_attention=only_cross_attention,
+                                       double_self_attention=double_self_attention, norm_type=norm_type,
+                                       norm_elementwise_affine=norm_elementwise_affine, norm_eps=norm_eps)
+            for _ in range(num_layers)])
+        if use_linear_projection:
+            self.proj_out = nn.Linear(inner_dim, in_channels)
+        else:
+            self.proj_out = nn.Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0)
+
+    def from_transformer2d_model(self, transformer2d_model):
+        """i2v:171-182."""
+        self.load_state_dict(transformer2d_model.state_dict(), strict=False)
+        for mine, theirs in zip(self.transformer_blocks, transformer2d_model.transformer_blocks):
+            mine.i2v_adapter.load_state_dict(theirs.attn1.state_dict())
+            mine.i2v_adapter.to_out[0].weight.data.zero_()
+            mine.i2v_adapter.to_out[0].bias.data.zero_()
+
+    def _pack(self):
+        return dict(g=w16(self.norm.weight), b=w16(self.norm.bias),
+                    wi=w16(self.proj_in.weight.reshape(self.inner_dim, self.in_channels)), bi=w16(self.proj_in.bias),
+                    wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias))
+
+    def _fwd(self, x, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip):
+        p = self.packed()
+        n_img, hh, ww, c = x.shape
+        h = K.groupnorm(x, p["g"], p["b"], self.groups, 1e-6)                                # i2v:218
+        t = K.gemm(h.view(-1, c), p["wi"], p["bi"])                                          # i2v:219-226
+        for blk in self.transformer_blocks:                                                  # i2v:285-295
+            t = blk._fwd(t, n_img, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip)
+        out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c))                            # i2v:298-314
+        return out.view(n_img, hh, ww, c)
+
+    def forward(self, hidden_states, enable_cross_frame_attn: bool = False, encoder_hidden_states=None,
+                num_frames: Optional[int] = None, timestep=None, added_cond_kwargs=None, class_labels=None,
+                cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None,
+                return_dict: bool = True):
+        if attention_mask is not None or encoder_attention_mask is not None:
+            raise NotImplementedError("attention masks are never passed on the hot path (SURVEY 8b)")
+        ct, ci = self.transformer_blocks[0]._split_ctx(encoder_hidden_states)
+        out = from_tokens(self._fwd(to_tokens(hidden_states), enable_cross_frame_attn, num_frames, ct, ci),
+                          hidden_states.dtype)
+        if not return_dict:
+            return (out,)
+        return _Out(out)

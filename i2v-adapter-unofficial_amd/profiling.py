@@ -1,0 +1,112 @@
+"""Live per-kernel-class timing with HIP events on the launch stream (bench.py's `roofline` object).
+
+`with KernelProfile() as prof:` wraps every C-ABI wrapper of `kernels` with a pair of events recorded on torch's
+current stream (the stream the ctypes launches go to) and the ALGORITHMIC work of the call:
+  flops: gemm 2 M N K; conv3x3 2 M Cout 9 Cin; attention 4 Lq Lk C Bq; temporal attention 4 F F C pixels
+  bytes: operands read once + result written once (fp16), GroupNorm 2 reads + 1 write, LayerNorm 1 read + 1 write
+(the counting rules of SURVEY.md Appendix B / section 8d).  Only used outside the timed region.
+"""
+import torch
+
+from . import kernels as K
+
+
+def _numel_bytes(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if isinstance(t, torch.Tensor))
+
+
+def _work_gemm(args, kw, out):
+    a, w = args[0], args[1]
+    M, N, Kd = a.shape[0], w.shape[0], w.shape[1]
+    return "gemm", 2.0 * M * N * Kd, _numel_bytes(a, kw.get("a2"), w, kw.get("residual"), out)
+
+
+def _work_conv(args, kw, out):
+    x, w = args[0], args[1]
+    M = out.shape[0] * out.shape[1] * out.shape[2]
+    return "conv3x3", 2.0 * M * w.shape[0] * w.shape[1], _numel_bytes(x, w, kw.get("residual"), out)
+
+
+def _work_attn(args, kw, out):
+    c = kw["heads"] * kw["head_dim"]
+    return "attention", 4.0 * kw["batch_q"] * kw["lq"] * kw["lk"] * c, _numel_bytes(args[0], args[1], args[2], out)
+
+
+def _work_tattn(args, kw, out):
+    c = kw["heads"] * kw["head_dim"]
+    return ("temporal_attention", 4.0 * kw["n_pixels"] * kw["frames"] * kw["frames"] * c,
+            _numel_bytes(args[0], args[1], out) + kw["n_pixels"] * c * kw["frames"] * 2)
+
+
+def _work_gn(args, kw, out):
+    return "groupnorm", 0.0, 3 * _numel_bytes(out)
+
+
+def _work_ln(args, kw, out):
+    return "layernorm", 0.0, 2 * _numel_bytes(out)
+
+
+def _work_misc(name):
+    def f(args, kw, out):
+        return name, 0.0, 2 * _numel_bytes(out)
+    return f
+
+
+_WRAPPED = {
+    "gemm": _work_gemm, "conv3x3": _work_conv, "attention": _work_attn, "temporal_attention": _work_tattn,
+    "groupnorm": _work_gn, "layernorm": _work_ln, "silu": _work_misc("elementwise"),
+    "copy3d": _work_misc("elementwise"), "timestep_embedding": _work_misc("elementwise"),
+    "ddim_prep": _work_misc("elementwise"), "ddim_cfg_step": _work_misc("elementwise"),
+    "nchw_to_tokens": _work_misc("elementwise"), "tokens_to_nchw": _work_misc("elementwise"),
+}
+
+
+class KernelProfile:
+    def __init__(self):
+        self.records = []   # (class, flops, bytes, start event, end event)
+        self._saved = {}
+        self._depth = 0
+
+    def _wrap(self, name, fn, work):
+        def wrapped(*args, **kw):
+            if self._depth:                      # nested wrapper (project_vt -> gemm): time the outer call only
+                return fn(*args, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._depth += 1
+            s.record()
+            try:
+                out = fn(*args, **kw)
+            finally:
+                self._depth -= 1
+            e.record()
+            cls, flops, nbytes = work(args, kw, out)
+            self.records.append((cls, flops, nbytes, s, e))
+            return out
+        return wrapped
+
+    def __enter__(self):
+        for name, work in _WRAPPED.items():
+            self._saved[name] = getattr(K, name)
+            setattr(K, name, self._wrap(name, self._saved[name], work))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(K, name, fn)
+        self._saved = {}
+
+    def summary(self):
+        """{class: dict(calls, ms, flops, bytes, tflops, gbps)} after a device synchronise."""
+        torch.cuda.synchronize()
+        agg = {}
+        for cls, flops, nbytes, s, e in self.records:
+            d = agg.setdefault(cls, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        for d in agg.values():
+            sec = max(d["ms"], 1e-9) * 1e-3
+            d["tflops"] = d["flops"] / sec / 1e12
+            d["gbps"] = d["bytes"] / sec / 1e9
+        return agg

@@ -1,0 +1,115 @@
+"""Shared builders for the parity tests: matched (oracle, HIP) module pairs with identical fp16-representable
+weights, seeded synthetic inputs, the comparison helper with the stated fp16 tolerance, and
+`smoke_check()` used by __graft_entry__.smoke().
+
+Tolerance of the fp16 path (stated once, used everywhere): the HIP path stores activations in fp16 (eps = 9.8e-4)
+and accumulates / normalises in fp32; against the fp32 CPU oracle run on the SAME fp16-rounded weights and inputs
+a module output must satisfy   max|hip - oracle| <= REL_TOL * max|oracle|   with REL_TOL = 2e-2 for whole
+modules / the UNet (hundreds of chained fp16 roundings) and 3e-3 for single kernels (tests/test_kernels_gpu.py).
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REL_TOL_MODULE = 2e-2
+SMALL_UNET = dict(block_out_channels=(32, 64, 128, 128), num_attention_heads=4, norm_num_groups=8,
+                  cross_attention_dim=64, motion_num_attention_heads=4, motion_max_seq_length=32)
+
+
+def round_fp16_(module):
+    """make every parameter / buffer exactly representable in fp16 (the HIP path runs fp16 weights)."""
+    with torch.no_grad():
+        for p in list(module.parameters()) + list(module.buffers()):
+            if p.dtype.is_floating_point:
+                p.copy_(p.half().float())
+    return module
+
+
+def randomize_adapter_out_(module, std=0.02, seed=99):
+    """a freshly assembled model has zero adapter to_out (i2v:181-182) => K1 would not contribute."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if ".i2v_adapter.to_out." in name or name.startswith("i2v_adapter.to_out."):
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+    return module
+
+
+def compare(got, ref, rel=REL_TOL_MODULE, name=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite values"
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= rel * scale, f"{name}: max abs err {err:.4e} > {rel} * max|ref| ({scale:.4e})"
+    return err, scale
+
+
+def oracle_small_unet(seed=1234, ip=False):
+    from oracle.unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel
+    torch.manual_seed(seed)
+    m = UNetMotionCrossFrameAttnModel(**SMALL_UNET)
+    randomize_adapter_out_(m)
+    if ip:
+        m._load_ip_adapter_weights(small_ip_state_dict(m))
+    return round_fp16_(m).eval()
+
+
+def small_ip_state_dict(oracle_unet, clip_dim=48, seed=7):
+    """ip-adapter_sd15.bin layout for the small UNet: key ids 1, 3, ... in attn_processors order."""
+    g = torch.Generator().manual_seed(seed)
+    cross = oracle_unet.config.cross_attention_dim
+    sd = {"image_proj": {"proj.weight": torch.randn(4 * cross, clip_dim, generator=g) * 0.1,
+                         "proj.bias": torch.randn(4 * cross, generator=g) * 0.1,
+                         "norm.weight": 1 + 0.1 * torch.randn(cross, generator=g),
+                         "norm.bias": 0.1 * torch.randn(cross, generator=g)},
+          "ip_adapter": {}}
+    mods = dict(oracle_unet.named_modules())
+    names = [n for n in oracle_unet.attn_processor_names() if n.endswith("attn2.processor") and "motion_modules" not in n]
+    for i, n in enumerate(names):
+        a = mods[n[: -len(".processor")]]
+        sd["ip_adapter"][f"{2 * i + 1}.to_k_ip.weight"] = torch.randn(a.inner_dim, cross, generator=g) * 0.1
+        sd["ip_adapter"][f"{2 * i + 1}.to_v_ip.weight"] = torch.randn(a.inner_dim, cross, generator=g) * 0.1
+    return sd
+
+
+def hip_unet_from_oracle(oracle_unet, device, ip_state_dict=None, dtype=torch.float16):
+    import i2v_adapter_unofficial_amd as pkg
+    cfg = {k: v for k, v in dict(oracle_unet.config).items()}
+    cfg["encoder_hid_dim_type"] = None
+    m = pkg.UNetMotionCrossFrameAttnModel.from_config(cfg)
+    sd = {k: v for k, v in oracle_unet.state_dict().items() if "_ip." not in k and not k.startswith("encoder_hid_proj")}
+    m.load_state_dict(sd)
+    m = m.to(device=device, dtype=dtype)
+    if ip_state_dict is not None:
+        m._load_ip_adapter_weights(ip_state_dict)
+    return m.eval()
+
+
+def small_unet_inputs(b=2, f=4, hw=16, lt=7, clip_dim=48, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    h = lambda t: t.half().float()
+    return dict(sample=h(torch.randn(b, f, 4, hw, hw, generator=g)),
+                timestep=torch.tensor([10, 500][:b] if b <= 2 else list(range(10, 10 + b))),
+                ctx=h(torch.randn(b, lt, SMALL_UNET["cross_attention_dim"], generator=g)),
+                image_embeds=h(torch.randn(b, clip_dim, generator=g)))
+
+
+def smoke_check():
+    """One small invocation of the hot path on cuda:0 (reduced UNet: same topology as SD-1.5, narrow channels)
+    checked against the CPU oracle."""
+    dev = torch.device("cuda:0")
+    ou = oracle_small_unet()
+    hu = hip_unet_from_oracle(ou, dev)
+    inp = small_unet_inputs()
+    with torch.no_grad():
+        ref = ou(inp["sample"], inp["timestep"], True, inp["ctx"]).sample
+        got = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
+    err, scale = compare(got, ref, name="smoke: small UNet forward")
+    print(f"smoke ok: small UNet forward max abs err {err:.3e} (max|ref| {scale:.3e})")

@@ -1,0 +1,215 @@
+"""GPU parity of the HIP module / model / pipeline API against the CPU oracle.
+
+The module-level cases use the shapes of the reference's own tests (test/test_i2v_adapter.py,
+test/test_unet_motion_cross_frame_attn.py), which only assert output shapes; here the same calls are also
+compared numerically with the oracle (tolerance: tests/parity.py).  The model-level cases use the reduced UNet
+(SD-1.5 topology, narrow channels) of SURVEY 8c.
+"""
+import pytest
+import torch
+
+from tests.parity import (REL_TOL_MODULE, SMALL_UNET, compare, hip_unet_from_oracle, oracle_small_unet,
+                          randomize_adapter_out_, round_fp16_, small_ip_state_dict, small_unet_inputs)
+
+pytestmark = pytest.mark.gpu
+
+
+def pkg():
+    import i2v_adapter_unofficial_amd as p
+    return p
+
+
+def h(t):
+    return t.half().float()
+
+
+def _pair(oracle_cls, hip_cls, dev, seed, *args, **kwargs):
+    torch.manual_seed(seed)
+    o = round_fp16_(oracle_cls(*args, **kwargs)).eval()
+    m = hip_cls(*args, **kwargs)
+    m.load_state_dict(o.state_dict())
+    return o, m.to(device=dev, dtype=torch.float16).eval()
+
+
+@pytest.mark.parametrize("cross_frame", [True, False])
+def test_transformer_block(dev, cross_frame):
+    """reference test/test_i2v_adapter.py:73-124 (hidden 256, 8 heads, ctx 77 x 512, activation 'gelu')."""
+    from oracle.i2v_adapter import I2VAdapterTransformerBlock as O
+    o, m = _pair(O, pkg().I2VAdapterTransformerBlock, dev, 1, 256, 8, 32, dropout=0.0, cross_attention_dim=512,
+                 activation_fn="gelu")
+    g = torch.Generator().manual_seed(2)
+    frames, batch = 8, 4
+    bf = frames * batch if cross_frame else batch
+    x = h(torch.randn(bf, 64, 256, generator=g))
+    ctx = h(torch.randn(bf, 77, 512, generator=g))
+    kw = dict(enable_cross_frame_attn=cross_frame, num_frames=frames if cross_frame else None)
+    with torch.no_grad():
+        ref = o(x, encoder_hidden_states=ctx, **kw)
+        got = m(x.half().to(dev), encoder_hidden_states=ctx.half().to(dev), attention_mask=None,
+                encoder_attention_mask=None, **kw)
+    assert got.shape == (bf, 64, 256)
+    compare(got, ref, name="I2VAdapterTransformerBlock")
+
+
+def test_transformer_block_errors(dev):
+    m = pkg().I2VAdapterTransformerBlock(64, 8, 8, cross_attention_dim=32).to(dev).half()
+    x = torch.zeros(6, 16, 64, dtype=torch.float16, device=dev)
+    ctx = torch.zeros(6, 7, 32, dtype=torch.float16, device=dev)
+    with pytest.raises(ValueError, match="num_frames"):
+        m(x, enable_cross_frame_attn=True, encoder_hidden_states=ctx)
+    with pytest.raises(ValueError, match="divisible"):
+        m(x, enable_cross_frame_attn=True, num_frames=4, encoder_hidden_states=ctx)
+    with pytest.raises(pkg().HipLibraryError):
+        m(x.cpu(), encoder_hidden_states=ctx.cpu())
+
+
+@pytest.mark.parametrize("cross_frame", [True, False])
+def test_transformer_2d_model(dev, cross_frame):
+    """reference test/test_i2v_adapter.py:11-71 (8 heads, C = 512, ctx dim 1024, 16 x 16, F = 8)."""
+    from oracle.i2v_adapter import I2VAdapterTransformer2DModel as O
+    o, m = _pair(O, pkg().I2VAdapterTransformer2DModel, dev, 3, 8, 64, in_channels=512, out_channels=512,
+                 num_layers=1, cross_attention_dim=1024, norm_num_groups=32)
+    g = torch.Generator().manual_seed(4)
+    frames = 8
+    bf = 2 * frames if cross_frame else 6
+    x = h(torch.randn(bf, 512, 16, 16, generator=g))
+    ctx = h(torch.randn(bf, 77, 1024, generator=g))
+    kw = dict(enable_cross_frame_attn=cross_frame, num_frames=frames if cross_frame else None, return_dict=False)
+    with torch.no_grad():
+        ref = o(x, encoder_hidden_states=ctx, **kw)[0]
+        got = m(x.half().to(dev), encoder_hidden_states=ctx.half().to(dev), attention_mask=None,
+                encoder_attention_mask=None, **kw)[0]
+    assert got.shape == (bf, 512, 16, 16)
+    compare(got, ref, name="I2VAdapterTransformer2DModel")
+
+
+@pytest.mark.parametrize("cross_frame", [True, False])
+def test_down_block(dev, cross_frame):
+    """reference test/test_unet_motion_cross_frame_attn.py:18-92 (64 -> 128 ch, temb 512, ctx 768, 16 x 16, F = 8)."""
+    from oracle.unet_motion_cross_frame_attn import CrossFrameAttnDownBlockMotion as O
+    o, m = _pair(O, pkg().CrossFrameAttnDownBlockMotion, dev, 5, in_channels=64, out_channels=128,
+                 temb_channels=512, cross_attention_dim=768, num_layers=2, num_attention_heads=8)
+    g = torch.Generator().manual_seed(6)
+    frames, bf = 8, 16
+    x = h(torch.randn(bf, 64, 16, 16, generator=g))
+    temb = h(torch.randn(bf, 512, generator=g))
+    ctx = h(torch.randn(bf, 77, 768, generator=g))
+    with torch.no_grad():
+        ref, ref_states = o(hidden_states=x, temb=temb, enable_cross_frame_attn=cross_frame,
+                            encoder_hidden_states=ctx, num_frames=frames)
+        got, got_states = m(hidden_states=x.half().to(dev), temb=temb.half().to(dev),
+                            enable_cross_frame_attn=cross_frame, encoder_hidden_states=ctx.half().to(dev),
+                            num_frames=frames)
+    assert got.shape == (bf, 128, 8, 8) and len(got_states) == 3
+    compare(got, ref, name="CrossFrameAttnDownBlockMotion")
+    for i, (a, b) in enumerate(zip(got_states, ref_states)):
+        compare(a, b, name=f"output_states[{i}]")
+
+
+def test_motion_module_and_resnet(dev):
+    from oracle.blocks import ResnetBlock2D as OR, TransformerTemporalModel as OT
+    g = torch.Generator().manual_seed(8)
+    o, m = _pair(OT, pkg().TransformerTemporalModel, dev, 7, num_attention_heads=8, in_channels=320,
+                 norm_num_groups=32, attention_bias=False, activation_fn="geglu", positional_embeddings="sinusoidal",
+                 num_positional_embeddings=32, attention_head_dim=40)
+    x = h(torch.randn(2 * 16, 320, 8, 8, generator=g))
+    with torch.no_grad():
+        compare(m(x.half().to(dev), num_frames=16)[0], o(x, num_frames=16)[0], name="TransformerTemporalModel F=16")
+        compare(m(x[:24].half().to(dev), num_frames=12)[0], o(x[:24], num_frames=12)[0], name="TransformerTemporalModel F=12")
+    o, m = _pair(OR, pkg().ResnetBlock2D, dev, 9, 64, 96, temb_channels=128, eps=1e-5, groups=32)
+    x = h(torch.randn(4, 64, 12, 12, generator=g))
+    temb = h(torch.randn(4, 128, generator=g))
+    with torch.no_grad():
+        compare(m(x.half().to(dev), temb.half().to(dev)), o(x, temb), name="ResnetBlock2D")
+
+
+@pytest.mark.parametrize("cross_frame,ip", [(True, False), (False, False), (True, True)])
+def test_small_unet_forward(dev, cross_frame, ip):
+    ou = oracle_small_unet(ip=False)
+    ipsd = small_ip_state_dict(ou) if ip else None
+    if ip:
+        ou._load_ip_adapter_weights(ipsd)
+        round_fp16_(ou)
+        ipsd = {k: {kk: vv.half().float() for kk, vv in v.items()} for k, v in ipsd.items()}
+    hu = hip_unet_from_oracle(ou, dev, ip_state_dict=ipsd)
+    inp = small_unet_inputs()
+    added = {"image_embeds": inp["image_embeds"]} if ip else None
+    added_d = {"image_embeds": inp["image_embeds"].to(dev)} if ip else None
+    with torch.no_grad():
+        ref = ou(inp["sample"], inp["timestep"], cross_frame, inp["ctx"], added_cond_kwargs=added).sample
+        got = hu(inp["sample"].to(dev), inp["timestep"].to(dev), cross_frame, inp["ctx"].to(dev),
+                 added_cond_kwargs=added_d).sample
+    assert got.shape == ref.shape == (2, 4, 4, 16, 16) and got.dtype == torch.float32
+    err, scale = compare(got, ref, name="UNetMotionCrossFrameAttnModel")
+    print(f"small UNet cross_frame={cross_frame} ip={ip}: max abs err {err:.3e} (max|ref| {scale:.3e})")
+    if ip:
+        with pytest.raises(ValueError, match="image_embeds"):
+            hu(inp["sample"].to(dev), inp["timestep"].to(dev), cross_frame, inp["ctx"].to(dev))
+
+
+def test_adapter_contributes(dev):
+    """with a non-zero adapter to_out the cross-frame branch must change the output (K1 is exercised)."""
+    ou = oracle_small_unet()
+    hu = hip_unet_from_oracle(ou, dev)
+    inp = small_unet_inputs()
+    with torch.no_grad():
+        a = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
+        b = hu(inp["sample"].to(dev), inp["timestep"].to(dev), False, inp["ctx"].to(dev)).sample
+    assert (a - b).abs().max().item() > 1e-3
+
+
+def test_from_unet2d_and_adapter_roundtrip(dev):
+    from oracle.unet_motion_cross_frame_attn import (UNet2DConditionModel as OU2, UNetMotionCrossFrameAttnModel as OM)
+    from oracle.blocks import MotionAdapter as OMA
+    from oracle.i2v_adapter import I2VAdapterModule as OIA
+    p = pkg()
+    torch.manual_seed(21)
+    kw = dict(block_out_channels=(32, 64, 128, 128), attention_head_dim=4, norm_num_groups=8, cross_attention_dim=64)
+    ou2 = round_fp16_(OU2(**kw))
+    oma = round_fp16_(OMA(block_out_channels=(32, 64, 128, 128), motion_num_attention_heads=4, motion_norm_num_groups=8))
+    oia = round_fp16_(OIA(2, (32, 64, 128, 128), 4))
+    om = OM.from_unet2d(ou2, oma, oia).eval()
+    hu2 = p.UNet2DConditionModel(**kw)
+    hu2.load_state_dict(ou2.state_dict())
+    hma = p.MotionAdapter(block_out_channels=(32, 64, 128, 128), motion_num_attention_heads=4, motion_norm_num_groups=8)
+    hma.load_state_dict(oma.state_dict())
+    hia = p.I2VAdapterModule(2, (32, 64, 128, 128), 4)
+    hia.load_state_dict(oia.state_dict())
+    hm = p.UNetMotionCrossFrameAttnModel.from_unet2d(hu2.to(dev).half(), hma, hia).eval()
+    assert next(hm.parameters()).dtype == torch.float16 and next(hm.parameters()).is_cuda
+    sd_o, sd_h = om.state_dict(), hm.state_dict()
+    assert set(sd_o) == set(sd_h)
+    for k in sd_o:
+        assert torch.equal(sd_o[k].half(), sd_h[k].cpu().half()), k
+    ad = hm.obtain_i2v_adapter_modules()
+    assert set(ad.state_dict()) == set(oia.state_dict())
+    inp = small_unet_inputs()
+    with torch.no_grad():
+        ref = om(inp["sample"], inp["timestep"], True, inp["ctx"]).sample
+        got = hm(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
+    compare(got, ref, name="from_unet2d model")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipeline_trajectory(dev, use_graph):
+    """config-1 style plumbing: DDIM + CFG loop with frame-0 re-injection on the reduced UNet vs the oracle loop."""
+    from oracle.pipeline_i2v_adapter import I2VAdapterPipeline as OP
+    ou = oracle_small_unet()
+    hu = hip_unet_from_oracle(ou, dev)
+    g = torch.Generator().manual_seed(31)
+    pe, ne = h(torch.randn(1, 7, 64, generator=g)), h(torch.randn(1, 7, 64, generator=g))
+    cond = torch.randn(1, 4, 16, 16, generator=g)
+    kw = dict(num_frames=4, num_inference_steps=10, guidance_scale=7.5, frame_similarity_sample_ratio=0.9)
+    gens = lambda: dict(generator=torch.Generator().manual_seed(5), prior_mask_generator=torch.Generator().manual_seed(6),
+                        prior_noise_generator=torch.Generator().manual_seed(7))
+    ref = OP(ou)(pe, ne, cond, **kw, **gens()).frames
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+    got = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, condition_image_latents=cond, use_graph=use_graph,
+               **kw, **gens()).frames
+    assert got.shape == (1, 4, 4, 16, 16)
+    assert torch.equal(got[:, 0].cpu(), cond), "frame 0 must equal the condition latents exactly (pipe:699-700)"
+    err, scale = compare(got, ref, rel=5e-2, name="DDIM trajectory (9 steps)")
+    print(f"pipeline use_graph={use_graph}: max abs latent err {err:.3e} (max|ref| {scale:.3e})")
+    again = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, condition_image_latents=cond, use_graph=use_graph,
+                 **kw, **gens()).frames
+    assert torch.equal(got, again), "same seeds must reproduce the trajectory bit for bit"
