@@ -14,6 +14,8 @@
 // the row->key assignment of S^T tile `kt` is chosen as key = 32 (kt >> 1) + 8 g + 4 (kt & 1) + r so that the 8 values
 // a lane holds for k-step s are keys 32 s + 8 g + 0..7, i.e. one contiguous 16-byte read of a V^T row.
 // V arrives already transposed ([channel][key], written by the projection GEMM's I2V_STORE_VT epilogue).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -241,9 +243,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
 template <int DQK, int DPV>
 int launch_d(const i2v_attn_params& p, hipStream_t s) {
   const float scale_log2 = p.scale * 1.4426950408889634f;
+  // measured (profiles/r1_tile_sweep.txt): 2 query tiles per wave keep 2 waves / SIMD resident, so one wave's
+  // softmax VALU overlaps the other's MFMAs; 4 tiles drop to 1 wave / SIMD and serialise the two pipes.
   int qt = 1;
-  if (p.lq >= 128) qt = 2;
-  if (DQK <= 96 && p.lq >= 1024) qt = 4;
+  if (p.lq >= 128 && DQK <= 96) qt = 2;
+  static const int qt_env = getenv("I2V_ATTN_QT") ? atoi(getenv("I2V_ATTN_QT")) : 0;  // tuning override
+  if (qt_env == 1 || qt_env == 2 || (qt_env == 4 && DQK <= 96)) qt = qt_env;
   const dim3 block(256);
   const dim3 grid((unsigned)i2v_cdiv(p.lq, 64 * qt), (unsigned)p.heads, (unsigned)p.batch_q);
   if (qt == 4) {

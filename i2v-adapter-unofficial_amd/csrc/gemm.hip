@@ -11,6 +11,8 @@
 // (written after it), two LDS stages, one barrier per K-tile (guide T14 / T2).
 // A-operand loaders: plain row-major (optionally two K-ranges = skip-connection concat without a cat copy),
 // or im2col-on-the-fly over an NHWC image for 3x3 / stride 1|2 / nearest-2x-upsample convolutions.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -364,7 +366,15 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   }
 
   // tile selection: modelled time = waves of tiles over 256 CUs x tile area / shape efficiency
-  static const TileCfg cfgs[4] = {{128, 128, 2, 1.00f}, {128, 64, 3, 0.80f}, {64, 128, 3, 0.80f}, {64, 64, 5, 0.62f}};
+  // `eff` is measured relative throughput per tile area on MI355X at the UNet's shapes (tools/kernel_bench.py sweep,
+  // profiles/r1_tile_sweep.txt): the loop is latency-bound, so the smaller tiles with 3 blocks / CU win except
+  // for very long K; the im2col loader favours a short M tile (fewer gathered rows per block).
+  const bool conv = p.a_mode == I2V_A_CONV3X3;
+  const bool long_k = p.K >= 2048;
+  const TileCfg cfgs[4] = {{128, 128, 2, long_k ? 1.15f : 1.00f},
+                           {128, 64, 3, conv ? 1.00f : 1.30f},
+                           {64, 128, 3, conv ? 1.25f : 1.25f},
+                           {64, 64, 5, 1.10f}};
   int best = 0;
   double best_t = 1e300;
   for (int i = 0; i < 4; ++i) {
@@ -380,6 +390,8 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
       best = i;
     }
   }
+  static const int tile_env = getenv("I2V_GEMM_TILE") ? atoi(getenv("I2V_GEMM_TILE")) : -1;  // tuning override
+  if (tile_env >= 0 && tile_env < 4) best = tile_env;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (best) {
     case 0: return launch<128, 128>(p, vec4, s);

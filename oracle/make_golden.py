@@ -1,0 +1,135 @@
+"""Generate the golden vectors under tests/golden/ (TEST INFRASTRUCTURE; run in the build container only).
+
+    python -m oracle.make_golden
+
+Two families:
+
+1. `ref_attention_*.safetensors` -- produced by IMPORTING the reference-authored
+   /root/reference/src/modules/attention.py:26-62 `BasicAttention` (the same op as diffusers
+   `Attention` + `AttnProcessor2_0`: bias-free q/k/v, SDPA, biased out-projection) on seeded inputs, in the three
+   forms the hot path uses it: K2 self-attention, K1 cross-frame (context = frame-0 tokens of each clip repeated
+   over the frames, i2v:484-485) and K3 text cross-attention.  These pin the oracle's `Attention` (and, on the GPU,
+   the HIP attention path) to reference-authored code.  The reference's Python never leaves this container; only
+   these tensors do.
+
+2. `oracle_*.safetensors` -- outputs of the oracle itself on seeded weights / inputs (weights are NOT stored: they
+   are re-created from the recorded seed with torch's default initialisers), as regression pins of the restatement
+   and as fixtures for the HIP parity tests: transformer block (reference test shape), down block, reduced UNet with
+   and without IP tokens, a 10-step DDIM trajectory, and the add_noise known-answer test values.
+"""
+import os
+import sys
+
+import torch
+from safetensors.torch import save_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference"
+
+
+def h(t):
+    return t.half().float()
+
+
+def ref_attention_goldens():
+    sys.path.insert(0, REFERENCE)
+    from src.modules.attention import BasicAttention   # reference-authored, imported only here
+    cases = {
+        # name: (kind, clips, frames, tokens, heads, head_dim, ctx_tokens, ctx_dim)
+        "self_d8": ("self", 2, 4, 64, 8, 8, None, None),
+        "cross_frame_d8": ("cross_frame", 2, 4, 64, 8, 8, None, None),
+        "cross_frame_d40": ("cross_frame", 1, 3, 80, 2, 40, None, None),
+        "cross_frame_d80": ("cross_frame", 1, 2, 64, 2, 80, None, None),
+        "cross_frame_d160": ("cross_frame", 1, 2, 48, 2, 160, None, None),
+        "text_d40": ("text", 2, 2, 64, 2, 40, 77, 96),
+    }
+    for name, (kind, clips, frames, tokens, heads, d, lctx, dctx) in cases.items():
+        c = heads * d
+        torch.manual_seed(sum(map(ord, name)))
+        attn = BasicAttention(c, dctx if kind == "text" else c, head_dim=d, num_heads=heads)
+        with torch.no_grad():
+            for p in attn.parameters():
+                p.copy_(h(p))
+        g = torch.Generator().manual_seed(17)
+        x = h(torch.randn(clips * frames, tokens, c, generator=g))
+        if kind == "self":
+            ctx = None
+        elif kind == "cross_frame":
+            ctx = x[0:clips * frames:frames].repeat_interleave(frames, dim=0)      # i2v:484-485
+        else:
+            ctx = h(torch.randn(clips * frames, lctx, dctx, generator=g))
+        with torch.no_grad():
+            y = attn(x, ctx)
+        t = {"x": x, "y": y, "to_q": attn.to_q.weight.detach(), "to_k": attn.to_k.weight.detach(),
+             "to_v": attn.to_v.weight.detach(), "to_out_w": attn.to_out[0].weight.detach(),
+             "to_out_b": attn.to_out[0].bias.detach()}
+        if kind == "text":
+            t["ctx"] = ctx
+        meta = dict(kind=kind, clips=str(clips), frames=str(frames), heads=str(heads), head_dim=str(d))
+        save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(OUT, f"ref_attention_{name}.safetensors"),
+                  metadata=meta)
+        print("wrote ref_attention_" + name, tuple(y.shape))
+
+
+def oracle_goldens():
+    from oracle.blocks import DDPMScheduler
+    from oracle.i2v_adapter import I2VAdapterTransformerBlock
+    from oracle.pipeline_i2v_adapter import I2VAdapterPipeline
+    from oracle.unet_motion_cross_frame_attn import CrossFrameAttnDownBlockMotion
+    from tests.parity import (oracle_small_unet, round_fp16_, small_ip_state_dict, small_unet_inputs)
+    out = {}
+    with torch.no_grad():
+        # transformer block, reference test shape (test/test_i2v_adapter.py:73-110) with 2 clips x 4 frames
+        torch.manual_seed(101)
+        blk = round_fp16_(I2VAdapterTransformerBlock(256, 8, 32, dropout=0.0, cross_attention_dim=512,
+                                                     activation_fn="gelu")).eval()
+        g = torch.Generator().manual_seed(102)
+        x, ctx = h(torch.randn(8, 64, 256, generator=g)), h(torch.randn(8, 77, 512, generator=g))
+        out["block_y_cross_frame"] = blk(x, enable_cross_frame_attn=True, num_frames=4, encoder_hidden_states=ctx)
+        out["block_y_plain"] = blk(x, enable_cross_frame_attn=False, encoder_hidden_states=ctx)
+        # down block (test/test_unet_motion_cross_frame_attn.py:18-57) with 1 clip x 4 frames, 8 x 8
+        torch.manual_seed(103)
+        db = round_fp16_(CrossFrameAttnDownBlockMotion(in_channels=64, out_channels=128, temb_channels=512,
+                                                       cross_attention_dim=768, num_layers=2,
+                                                       num_attention_heads=8)).eval()
+        g = torch.Generator().manual_seed(104)
+        xs = h(torch.randn(4, 64, 8, 8, generator=g))
+        temb = h(torch.randn(4, 512, generator=g))
+        ctx2 = h(torch.randn(4, 77, 768, generator=g))
+        y, states = db(hidden_states=xs, temb=temb, enable_cross_frame_attn=True, encoder_hidden_states=ctx2,
+                       num_frames=4)
+        out["down_block_y"] = y
+        out["down_block_state0"] = states[0]
+        # reduced UNet, without and with IP tokens
+        inp = small_unet_inputs()
+        ou = oracle_small_unet()
+        out["unet_y"] = ou(inp["sample"], inp["timestep"], True, inp["ctx"]).sample
+        out["unet_y_no_cross_frame"] = ou(inp["sample"], inp["timestep"], False, inp["ctx"]).sample
+        oi = oracle_small_unet(ip=True)
+        out["unet_y_ip"] = oi(inp["sample"], inp["timestep"], True, inp["ctx"],
+                              added_cond_kwargs={"image_embeds": inp["image_embeds"]}).sample
+        # DDIM trajectory (config-1 plumbing on the reduced UNet)
+        g = torch.Generator().manual_seed(31)
+        pe, ne = h(torch.randn(1, 7, 64, generator=g)), h(torch.randn(1, 7, 64, generator=g))
+        cond = torch.randn(1, 4, 16, 16, generator=g)
+        out["ddim_latents"] = I2VAdapterPipeline(ou)(
+            pe, ne, cond, num_frames=4, num_inference_steps=10, guidance_scale=7.5, frame_similarity_sample_ratio=0.9,
+            generator=torch.Generator().manual_seed(5), prior_mask_generator=torch.Generator().manual_seed(6),
+            prior_noise_generator=torch.Generator().manual_seed(7)).frames
+        # add_noise KAT values (test/test_first_frame_pertubation.py): sqrt(alphas_cumprod) of DDPMScheduler(1000)
+        sch = DDPMScheduler(1000)
+        out["ddpm_sqrt_alphas_cumprod"] = sch.alphas_cumprod ** 0.5
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, "oracle_outputs.safetensors"))
+    for k, v in out.items():
+        print("oracle", k, tuple(v.shape))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    if os.path.isdir(REFERENCE):
+        ref_attention_goldens()
+    else:
+        print("reference not present: keeping the committed ref_attention_* fixtures")
+    oracle_goldens()

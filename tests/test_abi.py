@@ -1,0 +1,79 @@
+"""The C-ABI library loads and exports every symbol include/i2v_hip.h declares; the ctypes structures match the
+C structs byte for byte (checked by compiling the header with gcc).  No kernel is launched."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "i2v_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import i2v_adapter_unofficial_amd as pkg
+    if not os.path.exists(pkg._lib.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return pkg._lib
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(i2v_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    handle = lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 16
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in include/i2v_hip.h but not exported"
+        assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(lib.SIGNATURES) == set(syms)
+    assert handle.i2v_abi_version() == lib.ABI_VERSION
+
+
+def test_ctypes_structs_match_header(lib):
+    names = {"i2v_gemm_params": lib.GemmParams, "i2v_attn_params": lib.AttnParams, "i2v_tattn_params": lib.TAttnParams,
+             "i2v_gn_params": lib.GnParams, "i2v_ln_params": lib.LnParams}
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for cname, cls in names.items():
+        prog.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            prog.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    prog.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(src, "w").write("\n".join(prog))
+        subprocess.run(["gcc", "-std=c99", "-o", exe, src], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    for cname, cls in names.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_bad_arguments_return_error_codes_without_a_gpu(lib):
+    """argument validation happens on the host before any launch: callable with no GPU."""
+    h = lib.load()
+    assert h.i2v_gemm_f16(None, None) == -1
+    assert b"null params" in h.i2v_last_error()
+    p = lib.GemmParams()
+    assert h.i2v_gemm_f16(C.byref(p), None) == -1
+    assert h.i2v_attention_f16(None, None) == -1 and h.i2v_layernorm_f16(None, None) == -1
+    assert h.i2v_groupnorm_workspace_bytes(2, 300, 64) == (2 * 2 * 64 * 2 + 2 * 64 * 2) * 4
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libi2v_hip.so")
+    with pytest.raises(lib.HipLibraryError, match="no CPU fallback"):
+        lib.load()

@@ -1,0 +1,96 @@
+"""Host-side logic of the HIP package that needs no GPU: weight repacking, scheduler tables, sharding arithmetic,
+state-dict compatibility with the oracle, loud failure on CPU tensors."""
+import pytest
+import torch
+
+from tests.parity import SMALL_UNET, oracle_small_unet
+
+
+def pkg():
+    import i2v_adapter_unofficial_amd as p
+    return p
+
+
+def test_pack_conv3x3_is_tap_major():
+    from i2v_adapter_unofficial_amd.blocks import pack_conv3x3, pack_geglu
+    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = pack_conv3x3(w, cin_pad=8)
+    assert p.shape == (2, 72) and p.dtype == torch.float16
+    for co in range(2):
+        for ky in range(3):
+            for kx in range(3):
+                for ci in range(8):
+                    exp = w[co, ci, ky, kx] if ci < 3 else 0
+                    assert p[co, (ky * 3 + kx) * 8 + ci] == exp
+    wg, bg = pack_geglu(torch.arange(8.0).reshape(4, 2), torch.arange(4.0))
+    assert wg[:, 0].tolist() == [0, 4, 2, 6] and bg.tolist() == [0, 2, 1, 3]       # (value_i, gate_i) interleaved
+
+
+def test_scheduler_tables_match_oracle():
+    from oracle.blocks import DDIMScheduler as O
+    P = pkg().DDIMScheduler
+    o, p = O(), P()
+    o.set_timesteps(25)
+    p.set_timesteps(25)
+    assert torch.equal(o.timesteps, p.timesteps) and torch.equal(o.alphas_cumprod, p.alphas_cumprod)
+    ts = p.timesteps[3:]
+    coef = p.step_coefficients(ts)
+    x, eps = torch.randn(5), torch.randn(5)
+    for i, t in enumerate(ts.tolist()):
+        sa, sb, pa, pb = coef[i]
+        assert torch.allclose(pa * (x - sb * eps) / sa + pb * eps, o.step(eps, t, x), atol=1e-6)
+    n = torch.randn(2, 3, 4)
+    assert torch.equal(o.add_noise(x.new_ones(2, 3, 4), n, torch.tensor([5, 900])),
+                       p.add_noise(x.new_ones(2, 3, 4), n, torch.tensor([5, 900])))
+
+
+def test_state_dict_compatible_with_oracle_and_reference_layout():
+    ou = oracle_small_unet()
+    m = pkg().UNetMotionCrossFrameAttnModel(**SMALL_UNET)
+    assert set(m.state_dict()) == set(ou.state_dict())
+    m.load_state_dict(ou.state_dict())
+    ad = m.obtain_i2v_adapter_modules()
+    assert all("i2v_adapter" in k for k in ad.state_dict()) and len(ad.state_dict()) == 80
+    assert len(m.obtain_motion_modules().state_dict()) > 0
+    assert m.attn_processor_names() == ou.attn_processor_names()
+    m.freeze_unet_params()
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert trainable and all(".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n for n in trainable)
+
+
+def test_cpu_tensors_fail_loudly():
+    p = pkg()
+    m = p.I2VAdapterTransformerBlock(64, 8, 8, cross_attention_dim=32)
+    with pytest.raises(p.HipLibraryError, match="no CPU fallback"):
+        m(torch.zeros(2, 16, 64), encoder_hidden_states=torch.zeros(2, 7, 32))
+    u = p.UNetMotionCrossFrameAttnModel(**SMALL_UNET)
+    with pytest.raises(p.HipLibraryError, match="no CPU fallback"):
+        u(torch.zeros(1, 2, 4, 16, 16), 10, True, torch.zeros(1, 7, 64))
+    with pytest.raises(p.HipLibraryError):
+        p.kernels.layernorm(torch.zeros(4, 8, dtype=torch.float16), torch.ones(8, dtype=torch.float16),
+                            torch.zeros(8, dtype=torch.float16), 1e-5)
+
+
+def test_constructor_validation_matches_reference():
+    p = pkg()
+    with pytest.raises(ValueError, match="same number of `down_block_types`"):
+        p.UNetMotionCrossFrameAttnModel(down_block_types=("DownBlockMotion",), up_block_types=("UpBlockMotion",) * 2,
+                                        block_out_channels=(32,))
+    with pytest.raises(ValueError, match="block_out_channels"):
+        p.UNetMotionCrossFrameAttnModel(block_out_channels=(32, 64))
+    with pytest.raises(ValueError, match="cross_attention_dim must be specified"):
+        from i2v_adapter_unofficial_amd.unet_motion_cross_frame_attn import get_down_block
+        get_down_block("CrossFrameAttnDownBlockMotion", 1, 32, 32, 128, True, 1e-5, "silu", 4, resnet_groups=8)
+
+
+def test_shard_range_partitions_everything():
+    from i2v_adapter_unofficial_amd.sharding import shard_items, shard_range
+    for n in (0, 1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+    assert shard_items(list(range(64)), 3, 8) == list(range(24, 32))          # config 4: 64 pairs, 8 per GPU
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
