@@ -9,23 +9,58 @@
 //   S^T tile [16 keys x 16 queries] = K[16 x d] * Q^T[d x 16]        A = K fragment (LDS), B = Q fragment (registers)
 //   O^T tile [16 d    x 16 queries] = V^T[16 x 32 keys] * P^T[32 x 16] A = V^T fragment (LDS), B = P (registers)
 // With S^T in the accumulator, lane (g = lane >> 4, c = lane & 15) holds scores of query c for 4 keys: the softmax
-// row reduction is 15 in-register max/adds plus two wavefront shuffles (xor 16, 32), the per-query rescale of O^T is
+// row reduction is in-register max3 chains plus two wavefront shuffles (xor 16, 32), the per-query rescale of O^T is
 // lane-local, and the accumulator of S^T *is* the B operand of the PV product (no LDS round trip, no lane movement):
 // the row->key assignment of S^T tile `kt` is chosen as key = 32 (kt >> 1) + 8 g + 4 (kt & 1) + r so that the 8 values
 // a lane holds for k-step s are keys 32 s + 8 g + 0..7, i.e. one contiguous 16-byte read of a V^T row.
 // V arrives already transposed ([channel][key], written by the projection GEMM's I2V_STORE_VT epilogue).
+//
+// Softmax cost (the d = 40 level is VALU-bound, not MFMA-bound: 64 x 64 scores per 28 MFMAs):
+//   * one FMA per score: s' = s * (scale * log2 e) - m with the running max m taken BEFORE the tile (deferred max,
+//     guide T13): the O / l rescale runs only when a tile's max exceeds m by more than 2^8 (and on the first tile),
+//     so P <= 256 (exact in the fp32 accumulation, 11-bit relative in the fp16 P operand as always);
+//   * the row sum l is not accumulated on the VALU when head_dim leaves a spare row in the 16-row V^T padding
+//     (40 -> 48): that row of the LDS V^T tile is set to 1.0, so the PV MFMA itself produces sum(P~) with the SAME
+//     fp16-rounded P~ that multiplies V (numerator and denominator consistent; P~ packed with one round-toward-zero
+//     v_cvt_pkrtz per pair, whose bias cancels in the ratio).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
 namespace {
 
 constexpr int KV_TILE = 64;
-constexpr int VS = KV_TILE + 8;  // V^T LDS row stride (halfs)
+constexpr int VS = KV_TILE + 8;      // V^T LDS row stride (halfs)
+constexpr float DEFER_THR = 8.0f;    // log2 units
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-template <int DQK, int DPV, int QT>
+// max over lanes l, l ^ 16 (resp. l ^ 32): with both operands = x, v_permlane16_swap leaves (rows 0,0,2,2) in the first
+// result and (rows 1,1,3,3) in the second; v_permlane32_swap leaves (lo, lo) and (hi, hi).
+__device__ __forceinline__ float xor16_max(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+__device__ __forceinline__ uint32_t pack_rtz(float a, float b) {
+  const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);   // v_cvt_pkrtz_f16_f32: two floats -> packed half2, one instruction
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint32_t pack_rn(float a, float b) {
+  const f16x2 h = {(f16)a, (f16)b};
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+// SPARE: head_dim < DPV, i.e. V^T row `head_dim` is free to hold the ones that make the MFMA compute the row sum.
+template <int DQK, int DPV, int QT, bool SPARE>
 __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, const float scale_log2) {
   constexpr int KS = DQK + 8;          // K LDS row stride (halfs)
   constexpr int KSTEPS = DQK / 32;     // k-steps of the QK^T product
@@ -33,8 +68,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
   constexpr int KCH = DQK / 8;         // 16-byte chunks per K row
   constexpr int NKC = (KV_TILE * KCH) / 256;            // K chunks per thread
   constexpr int NVC = (DPV * 8 + 255) / 256;            // V^T chunks per thread (last pass may be partial)
-  __shared__ __attribute__((aligned(16))) f16 sK[KV_TILE * KS];
-  __shared__ __attribute__((aligned(16))) f16 sV[DPV * VS];
+  __shared__ __attribute__((aligned(16))) f16 sKb[2][KV_TILE * KS];   // two stages: one barrier per key tile
+  __shared__ __attribute__((aligned(16))) f16 sVb[2][DPV * VS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
@@ -70,63 +105,106 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
   float mrow[QT], lrow[QT];
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
-    mrow[j] = -INFINITY;
+    mrow[j] = 0.f;   // finite: the first tile always takes the rescale path, which sets the true running max
     lrow[j] = 0.f;
   }
 
+  // ---- K / V^T staging: everything that does not depend on the tile index is hoisted (per-thread source pointers,
+  //      LDS offsets, validity of the chunk inside head_dim); registers of chunks outside head_dim stay 0 (or 1.0
+  //      for the row-sum row) for the whole kernel.  Only the last, partial key tile takes the masked loader.
   f16x8 rk[NKC], rv[NVC];
+  const f16* kptr[NKC];
+  const f16* vptr[NVC];
+  int k_lds[NKC], v_lds[NVC], k_row[NKC], v_key[NVC];
+  bool k_ok[NKC], v_ok[NVC], v_st[NVC];
+#pragma unroll
+  for (int i = 0; i < NKC; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id / KCH, c = id - row * KCH;
+    k_row[i] = row;
+    k_ok[i] = 8 * c < d;
+    kptr[i] = Kg + (int64_t)row * p.k_row_stride + 8 * c;
+    k_lds[i] = row * KS + 8 * c;
+    rk[i] = zero8();
+  }
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id >> 3, c = id & 7;
+    v_key[i] = 8 * c;
+    v_st[i] = row < DPV;
+    v_ok[i] = row < DPV && row < d;
+    vptr[i] = Vg + (int64_t)row * p.vt_row_stride + 8 * c;
+    v_lds[i] = row * VS + 8 * c;
+    f16x8 v = zero8();
+    if (SPARE && row == d) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (f16)1.f;   // masked keys carry P = 0, so 1.0 for every key is right
+    }
+    rv[i] = v;
+  }
+  const int64_t k_tile_stride = (int64_t)KV_TILE * p.k_row_stride;
 
-  auto prefetch = [&](int t) {
+  auto prefetch_full = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NKC; ++i)
+      if (k_ok[i]) rk[i] = ld_global_16B(kptr[i] + t * k_tile_stride);
+#pragma unroll
+    for (int i = 0; i < NVC; ++i)
+      if (v_ok[i]) rv[i] = ld_global_16B(vptr[i] + t * KV_TILE);
+  };
+  auto prefetch_tail = [&](int t) {
     const int key_base = t * KV_TILE;
 #pragma unroll
     for (int i = 0; i < NKC; ++i) {
-      const int id = tid + 256 * i;
-      const int row = id / KCH, c = id - row * KCH;
-      const int key = key_base + row;
-      f16x8 v = zero8();
-      if (key < lk && 8 * c < d) v = ld_global_16B(Kg + (int64_t)key * p.k_row_stride + 8 * c);
-      rk[i] = v;
+      if (k_ok[i]) {
+        f16x8 v = zero8();
+        if (key_base + k_row[i] < lk) v = ld_global_16B(kptr[i] + t * k_tile_stride);
+        rk[i] = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NVC; ++i) {
-      const int id = tid + 256 * i;
-      const int row = id >> 3, c = id & 7;
-      const int key0 = key_base + 8 * c;
-      f16x8 v = zero8();
-      if (row < DPV && row < d && key0 < lk) {
-        v = ld_global_16B(Vg + (int64_t)row * p.vt_row_stride + key0);
-        if (key0 + 8 > lk) {
+      if (v_ok[i]) {
+        const int key0 = key_base + v_key[i];
+        f16x8 v = zero8();
+        if (key0 < lk) {
+          v = ld_global_16B(vptr[i] + t * KV_TILE);
+          if (key0 + 8 > lk) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (key0 + e >= lk) v[e] = (f16)0.f;
+            for (int e = 0; e < 8; ++e)
+              if (key0 + e >= lk) v[e] = (f16)0.f;
+          }
         }
+        rv[i] = v;
       }
-      rv[i] = v;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int stage) {
+    f16* sK = sKb[stage];
+    f16* sV = sVb[stage];
 #pragma unroll
-    for (int i = 0; i < NKC; ++i) {
-      const int id = tid + 256 * i;
-      const int row = id / KCH, c = id - row * KCH;
-      *reinterpret_cast<f16x8*>(&sK[row * KS + 8 * c]) = rk[i];
-    }
+    for (int i = 0; i < NKC; ++i) *reinterpret_cast<f16x8*>(&sK[k_lds[i]]) = rk[i];
 #pragma unroll
-    for (int i = 0; i < NVC; ++i) {
-      const int id = tid + 256 * i;
-      const int row = id >> 3, c = id & 7;
-      if (row < DPV) *reinterpret_cast<f16x8*>(&sV[row * VS + 8 * c]) = rv[i];
-    }
+    for (int i = 0; i < NVC; ++i)
+      if (v_st[i]) *reinterpret_cast<f16x8*>(&sV[v_lds[i]]) = rv[i];
   };
 
   const int ntiles = (lk + KV_TILE - 1) / KV_TILE;
-  prefetch(0);
-  commit();
+  const bool partial = (lk % KV_TILE) != 0;
+  if (ntiles == 1 && partial) prefetch_tail(0); else prefetch_full(0);
+  commit(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  // one key tile: TAIL = the last tile when lk % 64 != 0 (scores of keys >= lk are masked to -inf)
+  auto process = [&](auto tail_c, const int t) {
+    constexpr bool TAIL = decltype(tail_c)::value;
     const bool more = (t + 1) < ntiles;
-    if (more) prefetch(t + 1);
+    if (more) {
+      if (partial && t + 2 == ntiles) prefetch_tail(t + 1); else prefetch_full(t + 1);
+    }
+    const f16* sK = sKb[t & 1];
+    const f16* sV = sVb[t & 1];
 
     // ---- S^T = K Q^T
     f32x4 sacc[4][QT];
@@ -145,58 +223,73 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
       }
     }
 
-    // ---- online softmax (per query column; keys spread over registers and the 4 lane groups)
+    // ---- online softmax with deferred max (per query column; keys over registers and the 4 lane groups)
     const int key_base = t * KV_TILE;
-    const bool tail = key_base + KV_TILE > lk;
+    const bool first = t == 0;
     f16x8 pf[QT][2];
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
       float sv[4][4];
-      float mx = -INFINITY;
+      const float mprev = mrow[j];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = sacc[kt][j][r] * scale_log2;
-          if (tail) {
+          float v = fmaf(sacc[kt][j][r], scale_log2, -mprev);
+          if (TAIL) {
             const int key = key_base + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
             if (key >= lk) v = -INFINITY;
           }
           sv[kt][r] = v;
-          mx = fmaxf(mx, v);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrow[j], mx);
-      const float alpha = fast_exp2(mrow[j] - mnew);
-      mrow[j] = mnew;
+      float mx = max3(max3(sv[0][0], sv[0][1], sv[0][2]), max3(sv[0][3], sv[1][0], sv[1][1]),
+                      max3(sv[1][2], sv[1][3], sv[2][0]));
+      mx = max3(mx, max3(sv[2][1], sv[2][2], sv[2][3]), max3(sv[3][0], sv[3][1], sv[3][2]));
+      mx = fmaxf(mx, sv[3][3]);
+      mx = xor16_max(mx);   // v_permlane16_swap / v_permlane32_swap: cross-lane on the VALU, no LDS round trip
+      mx = xor32_max(mx);
+      if (__any(first || mx > DEFER_THR)) {          // wave-uniform; rare after the first tile
+        const float dlt = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 1.0f : fast_exp2(-dlt);   // O is still zero on the first tile
+        mrow[j] = mprev + dlt;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[kt][r] -= dlt;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[i][j][r] *= alpha;
+        if (!SPARE) lrow[j] *= alpha;
+      }
       float ls = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = fast_exp2(sv[kt][r] - mnew);
-          sv[kt][r] = e;
-          ls += e;
+          sv[kt][r] = fast_exp2(sv[kt][r]);
+          if (!SPARE) ls += sv[kt][r];
         }
-      lrow[j] = lrow[j] * alpha + ls;
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[i][j][r] *= alpha;
+      if (!SPARE) lrow[j] += ls;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        f16x8 pk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pk[r] = (f16)sv[2 * s2][r];
-          pk[4 + r] = (f16)sv[2 * s2 + 1][r];
+        u32x4 w;
+        if (SPARE) {
+          w[0] = pack_rtz(sv[2 * s2][0], sv[2 * s2][1]);
+          w[1] = pack_rtz(sv[2 * s2][2], sv[2 * s2][3]);
+          w[2] = pack_rtz(sv[2 * s2 + 1][0], sv[2 * s2 + 1][1]);
+          w[3] = pack_rtz(sv[2 * s2 + 1][2], sv[2 * s2 + 1][3]);
+        } else {
+          w[0] = pack_rn(sv[2 * s2][0], sv[2 * s2][1]);
+          w[1] = pack_rn(sv[2 * s2][2], sv[2 * s2][3]);
+          w[2] = pack_rn(sv[2 * s2 + 1][0], sv[2 * s2 + 1][1]);
+          w[3] = pack_rn(sv[2 * s2 + 1][2], sv[2 * s2 + 1][3]);
         }
-        pf[j][s2] = pk;
+        pf[j][s2] = __builtin_bit_cast(f16x8, w);
       }
     }
 
-    // ---- O^T += V^T P^T
+    // ---- O^T += V^T P^T   (with SPARE, row `d` of V^T is all ones: O^T[d][q] accumulates the row sum)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -206,18 +299,33 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
         for (int j = 0; j < QT; ++j) o[i][j] = mfma16x16x32(vf, pf[j][s2], o[i][j]);
       }
 
+    if (more) commit((t + 1) & 1);   // the other stage was last read in iteration t - 1 (closed by its barrier)
     __syncthreads();
-    if (more) commit();
-    __syncthreads();
-  }
+  };
+
+  const int nfull = partial ? ntiles - 1 : ntiles;
+  for (int t = 0; t < nfull; ++t) process(std::false_type{}, t);
+  if (partial) process(std::true_type{}, ntiles - 1);
 
   // ---- normalise and store: lane holds O[query l15][d = 16 i + 4 g + r]
   f16* __restrict__ O = reinterpret_cast<f16*>(p.o) + (int64_t)bq * p.o_batch_stride + h * d;
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
-    float lt = lrow[j];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    float lt;
+    if (SPARE) {
+      // the sum sits in O^T row d: tile d >> 4, lane group (d & 15) >> 2, register d & 3
+      float cand = 0.f;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i == (d >> 4) && r == (d & 3)) cand = o[i][j][r];
+      lt = __shfl(cand, (((d & 15) >> 2) << 4) | l15, 64);
+    } else {
+      lt = lrow[j];
+      lt += __shfl_xor(lt, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+    }
     const float inv = 1.0f / lt;
     const int row = q0 + j * 16 + l15;
     if (row >= lq) continue;
@@ -240,25 +348,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
   }
 }
 
-template <int DQK, int DPV>
-int launch_d(const i2v_attn_params& p, hipStream_t s) {
+template <int DQK, int DPV, bool SPARE>
+int launch_q(const i2v_attn_params& p, hipStream_t s) {
   const float scale_log2 = p.scale * 1.4426950408889634f;
   // measured (profiles/r1_tile_sweep.txt): 2 query tiles per wave keep 2 waves / SIMD resident, so one wave's
   // softmax VALU overlaps the other's MFMAs; 4 tiles drop to 1 wave / SIMD and serialise the two pipes.
   int qt = 1;
   if (p.lq >= 128 && DQK <= 96) qt = 2;
   static const int qt_env = getenv("I2V_ATTN_QT") ? atoi(getenv("I2V_ATTN_QT")) : 0;  // tuning override
-  if (qt_env == 1 || qt_env == 2 || (qt_env == 4 && DQK <= 96)) qt = qt_env;
+  if (qt_env == 1 || qt_env == 2) qt = qt_env;
   const dim3 block(256);
   const dim3 grid((unsigned)i2v_cdiv(p.lq, 64 * qt), (unsigned)p.heads, (unsigned)p.batch_q);
-  if (qt == 4) {
-    if constexpr (DQK <= 96) hipLaunchKernelGGL((attn_kernel<DQK, DPV, 4>), grid, block, 0, s, p, scale_log2);
-  } else if (qt == 2) {
-    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2>), grid, block, 0, s, p, scale_log2);
-  } else {
-    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1>), grid, block, 0, s, p, scale_log2);
-  }
+  if (qt == 2)
+    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, SPARE>), grid, block, 0, s, p, scale_log2);
+  else
+    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, SPARE>), grid, block, 0, s, p, scale_log2);
   return i2v_check_launch("i2v_attention_f16");
+}
+
+template <int DQK, int DPV>
+int launch_d(const i2v_attn_params& p, hipStream_t s) {
+  return p.head_dim < DPV ? launch_q<DQK, DPV, true>(p, s) : launch_q<DQK, DPV, false>(p, s);
 }
 
 inline bool al(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

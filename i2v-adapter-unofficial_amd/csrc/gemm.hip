@@ -13,7 +13,7 @@
 // or im2col-on-the-fly over an NHWC image for 3x3 / stride 1|2 / nearest-2x-upsample convolutions.
 #include <cstdlib>
 
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -365,6 +365,11 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     if (p.ldc % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
   }
 
+  // large problems whose N is a multiple of 320 go to the 8-wave LDS-DMA kernel (gemm_big.hip)
+  {
+    const int big = i2v_gemm_big_try(p, vec4, reinterpret_cast<hipStream_t>(stream));
+    if (big != 0) return big < 0 ? big : I2V_OK;
+  }
   // tile selection: modelled time = waves of tiles over 256 CUs x tile area / shape efficiency
   // `eff` is measured relative throughput per tile area on MI355X at the UNet's shapes (tools/kernel_bench.py sweep,
   // profiles/r1_tile_sweep.txt): the loop is latency-bound, so the smaller tiles with 3 blocks / CU win except

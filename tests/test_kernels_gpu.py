@@ -51,6 +51,56 @@ def test_gemm_plain(dev, M, N, K_):
     close(out, (a @ w.T + b + r) * 0.5, name="gemm+bias+residual")
 
 
+@pytest.mark.parametrize("M,N,K_,kind", [
+    (49152, 320, 320, "plain"), (49152, 640, 136, "plain"), (16384, 320, 640, "plain"), (16500, 320, 200, "plain"),
+    (49152, 640, 64, "geglu"), (16384, 320, 64, "rowperm"), (49152, 320, 128, "dual"), (320, 40960, 64, "vt")])
+def test_gemm_big_tiles(dev, M, N, K_, kind):
+    """shapes that take the 8-wave LDS-DMA kernel (N % 320 == 0, >= 128 tiles): 256- and 128-row tiles, M / K tails,
+    every epilogue / store mode."""
+    k = K()
+    g = torch.Generator().manual_seed(M + N + K_)
+    a = h(torch.randn(M, K_, generator=g))
+    w = h(torch.randn(N, K_, generator=g) / math.sqrt(K_))
+    b = h(torch.randn(N, generator=g))
+    ad, wd, bd = a.half().to(dev), w.half().to(dev), b.half().to(dev)
+    if kind == "plain":
+        r = h(torch.randn(M, N, generator=g))
+        close(k.gemm(ad, wd, bd, residual=r.half().to(dev)), a @ w.T + b + r, name="big gemm")
+    elif kind == "geglu":
+        y = a @ w.T + b
+        close(k.gemm(ad, wd, bd, epilogue=k.I2V_EPI_GEGLU), y[:, 0::2] * F.gelu(y[:, 1::2]), name="big geglu")
+    elif kind == "rowperm":
+        B_, F_, HW = 2, 16, M // 32
+        r = h(torch.randn(M, N, generator=g))
+        y = (a @ w.T + b).reshape(B_, HW, F_, N).permute(0, 2, 1, 3).reshape(M, N) + r
+        close(k.gemm(ad, wd, bd, residual=r.half().to(dev), store=k.I2V_STORE_ROWPERM, frames=F_, hw=HW), y,
+              name="big rowperm")
+    elif kind == "dual":
+        a2 = h(torch.randn(M, 64, generator=g))
+        w2 = h(torch.randn(N, K_ + 64, generator=g) / 12)
+        close(k.gemm(ad, w2.half().to(dev), a2=a2.half().to(dev)), torch.cat([a, a2], 1) @ w2.T, name="big dual")
+    else:   # V^T projection: A = weights [C, K], W = tokens [T, K], T = N here
+        vt = k.project_vt(wd, ad, 4096)       # tokens = w (N rows), weight = a (M = 320 channels)
+        ref = (w @ a.T).reshape(N // 4096, 4096, M).permute(0, 2, 1)
+        close(vt[:, :, :4096], ref, name="big vt")
+
+
+@pytest.mark.parametrize("n,hh,ww,cin,cout,stride,up", [(12, 64, 64, 32, 320, 1, False), (12, 32, 32, 64, 320, 1, True),
+                                                         (16, 64, 64, 16, 640, 2, False), (4, 64, 64, 8, 320, 1, False)])
+def test_conv3x3_big_tiles(dev, n, hh, ww, cin, cout, stride, up):
+    k = K()
+    g = torch.Generator().manual_seed(cin + cout)
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = h(torch.randn(cout, generator=g))
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=1)
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().half().to(dev)
+    out = k.conv3x3(xt, wp, b.half().to(dev), stride=stride, upsample=up)
+    close(out.permute(0, 3, 1, 2), ref, name="big conv3x3")
+
+
 def test_gemm_rowvec_gelu(dev):
     k = K()
     g = torch.Generator().manual_seed(3)
