@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libi2v_hip.so")
 ABI_VERSION = 1
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
-I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT = 0, 1, 2
+I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
 I2V_A_PLAIN, I2V_A_CONV3X3 = 0, 1
 
 

@@ -253,7 +253,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
         if (p.epilogue == I2V_EPI_GELU) v[r] = gelu_erf(v[r]);
         v[r] *= oscale;
       }
-      if (p.store_mode == I2V_STORE_VT) {
+      if (p.store_mode == I2V_STORE_VT_T) {
+        // element (m, n) -> ((m / L) * N + n) * ld + m % L   (scalar form; the vector form lives in gemm_big.hip)
+        const int bt = m / p.vt_len, kk = m - bt * p.vt_len;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) C[((int64_t)bt * N + (n + r)) * p.vt_ld + kk] = (f16)v[r];
+      } else if (p.store_mode == I2V_STORE_VT) {
         // element (m, n) -> ((n / L) * M + m) * ld + n % L
         if (vec4) {
           const int bt = n / p.vt_len, kk = n - bt * p.vt_len;
@@ -337,9 +343,15 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     }
   }
   I2V_CHECK_ARG(p.epilogue >= I2V_EPI_NONE && p.epilogue <= I2V_EPI_GEGLU, "i2v_gemm_f16: bad epilogue");
-  I2V_CHECK_ARG(p.store_mode >= I2V_STORE_ROWMAJOR && p.store_mode <= I2V_STORE_VT, "i2v_gemm_f16: bad store_mode");
+  I2V_CHECK_ARG(p.store_mode >= I2V_STORE_ROWMAJOR && p.store_mode <= I2V_STORE_VT_T, "i2v_gemm_f16: bad store_mode");
   if (p.epilogue == I2V_EPI_GEGLU)
-    I2V_CHECK_ARG(p.N % 2 == 0 && p.store_mode != I2V_STORE_VT, "i2v_gemm_f16: GEGLU needs even N, non-VT store");
+    I2V_CHECK_ARG(p.N % 2 == 0 && p.store_mode != I2V_STORE_VT && p.store_mode != I2V_STORE_VT_T,
+                  "i2v_gemm_f16: GEGLU needs even N, non-VT store");
+  if (p.store_mode == I2V_STORE_VT_T) {
+    I2V_CHECK_ARG(p.vt_len > 0 && p.vt_ld >= p.vt_len && p.M % p.vt_len == 0,
+                  "i2v_gemm_f16: VT_T store needs M %% vt_len == 0 and vt_ld >= vt_len");
+    I2V_CHECK_ARG(p.residual == nullptr && p.rowvec == nullptr, "i2v_gemm_f16: VT_T store takes no residual/rowvec");
+  }
   if (p.rowvec) I2V_CHECK_ARG(p.rows_per_vec > 0, "i2v_gemm_f16: rows_per_vec must be positive");
   if (p.store_mode == I2V_STORE_ROWPERM) {
     I2V_CHECK_ARG(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0,
@@ -359,6 +371,9 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   if (p.rowvec && (!aligned_to(p.rowvec, 8) || p.ld_rowvec % 4 != 0)) vec4 = 0;
   if (p.store_mode == I2V_STORE_VT) {
     if (p.vt_len % 4 != 0 || p.vt_ld % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
+  } else if (p.store_mode == I2V_STORE_VT_T) {
+    // here `vec4` means "4 consecutive m (keys) form an aligned 8-byte store" -- only gemm_big.hip uses it
+    vec4 = (p.vt_len % 4 == 0 && p.vt_ld % 4 == 0 && aligned_to(p.c, 8) && p.M % 4 == 0) ? 1 : 0;
   } else if (p.epilogue == I2V_EPI_GEGLU) {
     if (p.ldc % 2 != 0 || !aligned_to(p.c, 4)) vec4 = 0;
   } else {
@@ -370,6 +385,7 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     const int big = i2v_gemm_big_try(p, vec4, reinterpret_cast<hipStream_t>(stream));
     if (big != 0) return big < 0 ? big : I2V_OK;
   }
+  if (p.store_mode == I2V_STORE_VT_T) vec4 = 0;   // the generic kernel stores this mode element by element
   // tile selection: modelled time = waves of tiles over 256 CUs x tile area / shape efficiency
   // `eff` is measured relative throughput per tile area on MI355X at the UNet's shapes (tools/kernel_bench.py sweep,
   // profiles/r1_tile_sweep.txt): the loop is latency-bound, so the smaller tiles with 3 blocks / CU win except

@@ -12,6 +12,7 @@
 // instruction for 8-row group j fetches logical chunk (l & 7) ^ ((row >> 1) & 7) of row 8 j + (l >> 3) (guide rule 21).
 // Masked lanes (row >= M, k >= K, conv halo) fetch from a zero page instead, because LDS-DMA cannot skip a lane.
 #include <cstdlib>
+#include <utility>
 
 #include "gemm_common.h"
 
@@ -31,8 +32,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int AMODE>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int vec4) {
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int BM, int AMODE, int EPI, int STORE>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n) {
   constexpr int BN = BIG_BN;
   constexpr int WM = BM / 2, MI = WM / 16, NI = 5;
   constexpr int AG = BM / 64;  // 8-row (1 KiB) A groups per wave: (BM / 8) groups over 8 waves
@@ -167,39 +177,127 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const f16x8*>(sw + gemm_swz(wn * 80 + i * 16 + l15, ks * 4 + g));
 #pragma unroll
       for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const f16x8*>(sa + gemm_swz(wm * WM + j * 16 + l15, ks * 4 + g));
+      // D = W_frag * A_frag: lane owns 4 consecutive n of one row m.  For the transposed V^T store the operands are
+      // swapped (D = A_frag * W_frag): lane owns 4 consecutive m (keys) of one channel n = an 8-byte run of a V^T row.
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = mfma16x16x32(wf[i], af[j], acc[i][j]);
+        for (int j = 0; j < MI; ++j)
+          acc[i][j] = (STORE == I2V_STORE_VT_T) ? mfma16x16x32(af[j], wf[i], acc[i][j])
+                                                : mfma16x16x32(wf[i], af[j], acc[i][j]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // all fragment reads of stage `cur` done before it is refilled
   }
 
   // ---------------------------------------------------------------- epilogue (lane: row m, 4 consecutive n)
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m0 + wm * WM + j * 16 + l15;
-    if (m >= M) continue;
-    const GemmRow row = gemm_make_row(p, m);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      gemm_store4(p, vec4, row, n0 + wn * 80 + i * 16 + g * 4, v);
-    }
+  // The (epilogue, store mode) pair is a template parameter and the accumulator indices are compile-time constants
+  // (static_for): with the generic runtime-switched store the 8 x 5 loop was not unrolled, the 160 accumulators went
+  // through scratch memory and every tile paid ~50 us for it.
+  const f16* __restrict__ bias = reinterpret_cast<const f16*>(p.bias);
+  const f16* __restrict__ resid = reinterpret_cast<const f16*>(p.residual);
+  const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(p.rowvec);
+  f16* __restrict__ C = reinterpret_cast<f16*>(p.c);
+  const float oscale = p.out_scale;
+  if (STORE == I2V_STORE_VT_T) {
+    // accumulator rows = m (4 g + r), column = n (l15): element (m, n) -> C[((m / L) * N + n) * ld + m % L]
+    static_for<NI>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int n = n0 + wn * 80 + i * 16 + l15;
+      const float bn = bias ? (float)bias[n] : 0.f;
+      static_for<MI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int m = m0 + wm * WM + j * 16 + 4 * g;
+        if (m < M) {   // M % 4 == 0 and vt_len % 4 == 0: the 4 keys are in range and in one batch
+          const int bt = m / p.vt_len, kk = m - bt * p.vt_len;
+          const f16x4 o4 = {(f16)((acc[i][j][0] + bn) * oscale), (f16)((acc[i][j][1] + bn) * oscale),
+                            (f16)((acc[i][j][2] + bn) * oscale), (f16)((acc[i][j][3] + bn) * oscale)};
+          *reinterpret_cast<f16x4*>(C + ((int64_t)bt * N + n) * p.vt_ld + kk) = o4;
+        }
+      });
+    });
+    return;
   }
+  const int ncol0 = n0 + wn * 80 + g * 4;
+  f16x4 b4[NI];
+  static_for<NI>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    b4[i] = bias ? *reinterpret_cast<const f16x4*>(bias + ncol0 + i * 16) : f16x4{0, 0, 0, 0};
+  });
+  static_for<MI>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int m = m0 + wm * WM + j * 16 + l15;
+    if (m < M) {
+      int64_t m_out = m;
+      if (STORE == I2V_STORE_ROWPERM) {
+        const int per = p.hw * p.frames;
+        const int b = m / per, rem = m - b * per;
+        const int pix = rem / p.frames, f = rem - pix * p.frames;
+        m_out = (int64_t)(b * p.frames + f) * p.hw + pix;
+      }
+      const f16* rv = rowvec ? rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
+      const f16* rs = resid ? resid + m_out * p.ldr : nullptr;
+      static_for<NI>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int n = ncol0 + i * 16;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (float)b4[i][r];
+        if (rv) {
+          const f16x4 t4 = *reinterpret_cast<const f16x4*>(rv + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)t4[r];
+        }
+        if (rs) {
+          const f16x4 r4 = *reinterpret_cast<const f16x4*>(rs + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
+        }
+        if (EPI == I2V_EPI_GEGLU) {
+          const f16x2 o2 = {(f16)(v[0] * gelu_erf(v[1]) * oscale), (f16)(v[2] * gelu_erf(v[3]) * oscale)};
+          *reinterpret_cast<f16x2*>(C + m_out * p.ldc + (n >> 1)) = o2;
+        } else {
+          const f16x4 o4 = {(f16)(v[0] * oscale), (f16)(v[1] * oscale), (f16)(v[2] * oscale), (f16)(v[3] * oscale)};
+          if (STORE == I2V_STORE_VT) {
+            const int bt = n / p.vt_len, kk = n - bt * p.vt_len;
+            *reinterpret_cast<f16x4*>(C + ((int64_t)bt * M + m) * p.vt_ld + kk) = o4;
+          } else {
+            *reinterpret_cast<f16x4*>(C + m_out * p.ldc + n) = o4;
+          }
+        }
+      });
+    }
+  });
+}
+
+template <int BM, int AMODE>
+int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
+  const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BIG_BN;
+  const dim3 grid(tiles_m * tiles_n), block(512);
+  if (p.epilogue == I2V_EPI_GEGLU) {
+    if constexpr (AMODE == I2V_A_PLAIN)
+      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p, tiles_n);
+  } else if (p.store_mode == I2V_STORE_ROWPERM) {
+    if constexpr (AMODE == I2V_A_PLAIN)
+      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_ROWPERM>), grid, block, 0, s, p, tiles_n);
+  } else if (p.store_mode == I2V_STORE_VT) {
+    if constexpr (AMODE == I2V_A_PLAIN)
+      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_VT>), grid, block, 0, s, p, tiles_n);
+  } else if (p.store_mode == I2V_STORE_VT_T) {
+    if constexpr (AMODE == I2V_A_PLAIN)
+      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_VT_T>), grid, block, 0, s, p, tiles_n);
+  } else {
+    hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p, tiles_n);
+  }
+  const int rc = i2v_check_launch("i2v_gemm_f16(big)");
+  return rc < 0 ? rc : 1;
 }
 
 template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
-  const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BIG_BN;
-  const dim3 grid(tiles_m * tiles_n), block(512);
-  if (p.a_mode == I2V_A_CONV3X3)
-    hipLaunchKernelGGL((gemm_big_kernel<BM, I2V_A_CONV3X3>), grid, block, 0, s, p, tiles_n, vec4);
-  else
-    hipLaunchKernelGGL((gemm_big_kernel<BM, I2V_A_PLAIN>), grid, block, 0, s, p, tiles_n, vec4);
-  const int rc = i2v_check_launch("i2v_gemm_f16(big)");
-  return rc < 0 ? rc : 1;
+  (void)vec4;
+  if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, I2V_A_CONV3X3>(p, s);
+  return launch_big_mode<BM, I2V_A_PLAIN>(p, s);
 }
 
 }  // namespace
@@ -208,15 +306,22 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   static const int mode = getenv("I2V_GEMM_BIG") ? atoi(getenv("I2V_GEMM_BIG")) : -1;  // 0 off, 256 / 128 force
   if (mode == 0) return 0;
   if (p.N % BIG_BN != 0) return 0;
+  // the specialised epilogue handles the vector (8-byte) forms only; anything else stays on the generic kernel
+  if (!vec4 || p.epilogue == I2V_EPI_GELU) return 0;
+  if (p.a_mode == I2V_A_CONV3X3 && (p.epilogue != I2V_EPI_NONE || p.store_mode != I2V_STORE_ROWMAJOR)) return 0;
+  if (p.epilogue == I2V_EPI_GEGLU && p.store_mode != I2V_STORE_ROWMAJOR) return 0;
   const int64_t tn = p.N / BIG_BN;
   const int64_t t256 = i2v_cdiv(p.M, 256) * tn, t128 = i2v_cdiv(p.M, 128) * tn;
   if (mode == 256) return launch_big<256>(p, vec4, s);
   if (mode == 128) return launch_big<128>(p, vec4, s);
-  // measured (profiles/r1_tile_sweep.txt, "big" columns): with one 8-wave block per CU and one K tile of DMA in
-  // flight the kernel needs a long K loop to amortise its prologue / epilogue; short-K plain GEMMs (K <= 640) are
-  // latency-bound and run faster as 3 small blocks per CU in gemm.hip.  The im2col conv always has K >= 9 * cin.
-  if (p.a_mode != I2V_A_CONV3X3 && p.K < 1280) return 0;
-  if (t256 >= 192) return launch_big<256>(p, vec4, s);   // >= 0.75 wave of 256-row tiles over the 256 CUs
-  if (t128 >= 128) return launch_big<128>(p, vec4, s);
+  static const int min_k = getenv("I2V_GEMM_BIG_MINK") ? atoi(getenv("I2V_GEMM_BIG_MINK")) : 128;
+  if (p.a_mode != I2V_A_CONV3X3 && p.K < min_k) return 0;   // a single K tile cannot hide its own DMA latency
+  // one 8-wave block per CU: a tile count just above a multiple of 256 wastes most of the last round.  Pick the
+  // tile height by (fill of the last round) x (measured relative rate: 256-row 1.0, 128-row 0.82,
+  // profiles/r1_tile_sweep.txt); below 45 % the 3-blocks-per-CU kernel of gemm.hip is faster.
+  const double e256 = (double)t256 / (double)(i2v_cdiv(t256, 256) * 256);
+  const double e128 = 0.82 * (double)t128 / (double)(i2v_cdiv(t128, 256) * 256);
+  if (e256 >= e128 && e256 >= 0.45) return launch_big<256>(p, vec4, s);
+  if (e128 >= 0.45) return launch_big<128>(p, vec4, s);
   return 0;
 }

@@ -12,8 +12,8 @@ import torch
 
 from . import _lib
 from ._lib import (I2V_A_CONV3X3, I2V_A_PLAIN, I2V_EPI_GEGLU, I2V_EPI_GELU, I2V_EPI_NONE, I2V_STORE_ROWMAJOR,
-                   I2V_STORE_ROWPERM, I2V_STORE_VT, AttnParams, GemmParams, GnParams, HipLibraryError, LnParams,
-                   TAttnParams)
+                   I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T, AttnParams, GemmParams, GnParams,
+                   HipLibraryError, LnParams, TAttnParams)
 
 f16 = torch.float16
 
@@ -78,12 +78,13 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
             raise ValueError("bias must be a contiguous vector of N elements")
         p.bias = _p(bias)
     n_out = N // 2 if epilogue == I2V_EPI_GEGLU else N
-    if store == I2V_STORE_VT:
-        if out is None or vt_len <= 0 or vt_ld < vt_len or N % vt_len != 0:
-            raise ValueError("VT store needs an `out` buffer, vt_len > 0, vt_ld >= vt_len and N % vt_len == 0")
+    if store in (I2V_STORE_VT, I2V_STORE_VT_T):
+        tokens, chans = (N, M) if store == I2V_STORE_VT else (M, N)
+        if out is None or vt_len <= 0 or vt_ld < vt_len or tokens % vt_len != 0:
+            raise ValueError("VT store needs an `out` buffer, vt_len > 0, vt_ld >= vt_len and tokens % vt_len == 0")
         _req(out, "out")
-        if not out.is_contiguous() or out.numel() < (N // vt_len) * M * vt_ld:
-            raise ValueError("VT `out` must be contiguous with at least (N / vt_len) * M * vt_ld elements")
+        if not out.is_contiguous() or out.numel() < (tokens // vt_len) * chans * vt_ld:
+            raise ValueError("VT `out` must be contiguous with at least (tokens / vt_len) * channels * vt_ld elements")
         p.c, p.ldc = _p(out), vt_ld
         p.vt_len, p.vt_ld = vt_len, vt_ld
     else:
@@ -172,7 +173,12 @@ def project_vt(tokens, w_v, batch_len, out=None):
     Cc = w_v.shape[0]
     if out is None:
         out = torch.empty((T // batch_len, Cc, ld), dtype=f16, device=tokens.device)
-    gemm(w_v, tokens, store=I2V_STORE_VT, vt_len=batch_len, vt_ld=ld, out=out)
+    if Cc % 320 == 0 and batch_len % 4 == 0 and T >= 8192:
+        # natural operand order (A = tokens): eligible for the 256-row LDS-DMA tile kernel, which transposes in its
+        # MFMA operand order (I2V_STORE_VT_T)
+        gemm(tokens, w_v, store=I2V_STORE_VT_T, vt_len=batch_len, vt_ld=ld, out=out)
+    else:
+        gemm(w_v, tokens, store=I2V_STORE_VT, vt_len=batch_len, vt_ld=ld, out=out)
     return out
 
 

@@ -61,9 +61,12 @@ enum {
   I2V_STORE_ROWPERM = 1,  /* rows arrive in (b, pixel, frame) order and are stored (and the residual
                              is read) in (b, frame, pixel) order: m = (b*hw + p)*frames + f ->
                              m' = (b*frames + f)*hw + p            (motion-module exit)   */
-  I2V_STORE_VT = 2        /* transposed, batched: element (m, n) -> C[((n / vt_len) * M + m) * vt_ld
+  I2V_STORE_VT = 2,       /* transposed, batched: element (m, n) -> C[((n / vt_len) * M + m) * vt_ld
                              + n % vt_len]; used with A = weight [C, K], W = tokens [T, K] to emit
                              V^T[batch][channel][key] for the attention kernels                     */
+  I2V_STORE_VT_T = 3      /* the same V^T[batch][channel][key] output from the NATURAL operand order
+                             (A = tokens [T, K], W = weight [C, K]): element (m, n) -> C[((m / vt_len) * N + n)
+                             * vt_ld + m % vt_len]; lets large V projections run on the 256-row tile kernel  */
 };
 
 enum {
@@ -92,7 +95,7 @@ typedef struct i2v_gemm_params {
   int32_t epilogue;     /* I2V_EPI_*                                                                 */
   int32_t store_mode;   /* I2V_STORE_*                                                               */
   int32_t frames, hw;   /* I2V_STORE_ROWPERM                                                         */
-  int32_t vt_len, vt_ld;/* I2V_STORE_VT                                                              */
+  int32_t vt_len, vt_ld;/* I2V_STORE_VT / I2V_STORE_VT_T                                             */
   float out_scale;
   /* I2V_A_CONV3X3 geometry: input image [n_img, in_h, in_w, cin] fp16 (pixel stride = lda elements),
      3x3 kernel, padding 1, `stride` 1 or 2; `upsample` = 1 applies nearest-2x to the input first

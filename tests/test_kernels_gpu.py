@@ -85,6 +85,20 @@ def test_gemm_big_tiles(dev, M, N, K_, kind):
         close(vt[:, :, :4096], ref, name="big vt")
 
 
+@pytest.mark.parametrize("batches,L,C,Kd", [(4, 6, 24, 16), (2, 64, 320, 64), (3, 4096, 640, 64), (5, 16, 320, 320)])
+def test_gemm_store_vt_t(dev, batches, L, C, Kd):
+    """V^T from the natural operand order (A = tokens): generic kernel (small) and 256-row tile kernel (large)."""
+    k = K()
+    g = torch.Generator().manual_seed(19 + L)
+    tok = h(torch.randn(batches * L, Kd, generator=g))
+    wv = h(torch.randn(C, Kd, generator=g) / math.sqrt(Kd))
+    ld = k.pad8(L)
+    out = torch.zeros((batches, C, ld), dtype=torch.float16, device=dev)
+    k.gemm(tok.half().to(dev), wv.half().to(dev), store=k.I2V_STORE_VT_T, vt_len=L, vt_ld=ld, out=out)
+    ref = (tok @ wv.T).reshape(batches, L, C).permute(0, 2, 1)
+    close(out[:, :, :L], ref, name="store VT_T")
+
+
 @pytest.mark.parametrize("n,hh,ww,cin,cout,stride,up", [(12, 64, 64, 32, 320, 1, False), (12, 32, 32, 64, 320, 1, True),
                                                          (16, 64, 64, 16, 640, 2, False), (4, 64, 64, 8, 320, 1, False)])
 def test_conv3x3_big_tiles(dev, n, hh, ww, cin, cout, stride, up):
