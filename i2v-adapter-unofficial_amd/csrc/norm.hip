@@ -4,7 +4,17 @@
 
 namespace {
 
-constexpr int GN_ROWS_PER_CHUNK = 256;
+// Rows (pixels) of one image handled by one statistics workgroup.  The grid is (chunks, images): it needs ~1000+
+// workgroups to cover the 256 CUs (a 16 x 16 level with 32 images used to launch 32 workgroups and ran 8x below the
+// HBM rate), but the per-chunk partial sums must stay a small fraction of the data (>= 16 rows per chunk).
+static inline int gn_rows_per_chunk(int n_img, int hw) {
+  const int want_chunks = (int)i2v_cdiv(1024, n_img);
+  int rpc = (int)i2v_cdiv(hw, want_chunks);
+  rpc = (rpc + 7) / 8 * 8;
+  if (rpc < 16) rpc = 16;
+  if (rpc > 256) rpc = 256;
+  return rpc;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -15,12 +25,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------- GroupNorm
 // pass 1: per (image, row-chunk, channel) partial sum / sum of squares.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
-                                                       int c2, int hw, float* __restrict__ partial) {
+                                                       int c2, int hw, int rpc, float* __restrict__ partial) {
   __shared__ float red[256 * 16];
   const int C = c1 + c2, nvec = C / 8;
   const int chunk = blockIdx.x, img = blockIdx.y, nchunk = gridDim.x;
-  const int row_begin = chunk * GN_ROWS_PER_CHUNK;
-  const int row_end = min(hw, row_begin + GN_ROWS_PER_CHUNK);
+  const int row_begin = chunk * rpc;
+  const int row_end = min(hw, row_begin + rpc);
   const int tid = threadIdx.x;
   const int cols_per_pass = nvec < 256 ? nvec : 256;
   const int rows_par = 256 / cols_per_pass;
@@ -219,7 +229,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 }  // namespace
 
 extern "C" int64_t i2v_groupnorm_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels) {
-  const int64_t nchunk = i2v_cdiv(hw, GN_ROWS_PER_CHUNK);
+  const int64_t nchunk = i2v_cdiv(hw, gn_rows_per_chunk(n_img, hw));
   return ((int64_t)n_img * nchunk * channels * 2 + (int64_t)n_img * channels * 2) * (int64_t)sizeof(float);
 }
 
@@ -240,12 +250,13 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(al16(p.x) && al16(p.y) && (!p.x2 || al16(p.x2)) && al16(p.workspace) && al16(p.gamma) && al16(p.beta),
                 "i2v_groupnorm_f16: pointers must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nchunk = (int)i2v_cdiv(p.hw, GN_ROWS_PER_CHUNK);
+  const int rpc = gn_rows_per_chunk(p.n_img, p.hw);
+  const int nchunk = (int)i2v_cdiv(p.hw, rpc);
   float* partial = reinterpret_cast<float*>(p.workspace);
   float* coef = partial + (int64_t)p.n_img * nchunk * C * 2;
   const f16* x1 = reinterpret_cast<const f16*>(p.x);
   const f16* x2 = reinterpret_cast<const f16*>(p.x2);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, partial);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(64), 0, s, partial, nchunk, C,
                      p.groups, p.frames_per_stat, p.hw, p.eps, reinterpret_cast<const f16*>(p.gamma),
                      reinterpret_cast<const f16*>(p.beta), coef);
