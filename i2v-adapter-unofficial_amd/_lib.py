@@ -36,6 +36,7 @@ class GemmParams(C.Structure):
         ("out_scale", C.c_float),
         ("n_img", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("cin", C.c_int32),
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -92,6 +93,7 @@ SIGNATURES = {
     "i2v_abi_version": (C.c_int, []),
     "i2v_last_error": (C.c_char_p, []),
     "i2v_gemm_f16": (C.c_int, [C.POINTER(GemmParams), _P]),
+    "i2v_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmParams)]),
     "i2v_attention_f16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "i2v_temporal_attention_f16": (C.c_int, [C.POINTER(TAttnParams), _P]),
     "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

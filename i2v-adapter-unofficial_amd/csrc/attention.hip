@@ -1,28 +1,29 @@
 // Flash-style attention forward for gfx950: K1 cross-frame adapter attention (all frames of a clip attend to the
 // frame-0 K/V), K2 spatial self-attention, K3 text / IP-Adapter cross-attention.
 //
-// One workgroup = 4 waves; each wave owns QT 16-row query tiles of one (batch, head); the 64-key K tile and the
-// 64-key V^T tile are staged once per workgroup in LDS and shared by the 4 waves (for K1 the same frame-0 K/V
-// tile is additionally shared through L2 by the workgroups of all frames of the clip: kv batch = q batch / group).
+// One workgroup = 4 waves; each wave owns QT 16-row query tiles of one (batch, head); the KVT-key K tile and V^T tile
+// are staged once per workgroup in LDS and shared by the 4 waves (for K1 the same frame-0 K/V tile is additionally
+// shared through L2 by the workgroups of all frames of the clip: kv batch = q batch / group).
 //
 // MFMA orientation (v_mfma_f32_16x16x32_f16, D = A * B):
 //   S^T tile [16 keys x 16 queries] = K[16 x d] * Q^T[d x 16]        A = K fragment (LDS), B = Q fragment (registers)
 //   O^T tile [16 d    x 16 queries] = V^T[16 x 32 keys] * P^T[32 x 16] A = V^T fragment (LDS), B = P (registers)
 // With S^T in the accumulator, lane (g = lane >> 4, c = lane & 15) holds scores of query c for 4 keys: the softmax
-// row reduction is in-register max3 chains plus two wavefront shuffles (xor 16, 32), the per-query rescale of O^T is
-// lane-local, and the accumulator of S^T *is* the B operand of the PV product (no LDS round trip, no lane movement):
-// the row->key assignment of S^T tile `kt` is chosen as key = 32 (kt >> 1) + 8 g + 4 (kt & 1) + r so that the 8 values
-// a lane holds for k-step s are keys 32 s + 8 g + 0..7, i.e. one contiguous 16-byte read of a V^T row.
-// V arrives already transposed ([channel][key], written by the projection GEMM's I2V_STORE_VT epilogue).
+// row reduction is in-register max3 chains plus two cross-lane VALU swaps (v_permlane16/32_swap), the per-query rescale
+// of O^T is lane-local, and the accumulator of S^T *is* the B operand of the PV product (no LDS round trip, no lane
+// movement): the row->key assignment of S^T tile `kt` is key = 32 (kt >> 1) + 8 g + 4 (kt & 1) + r so that the 8
+// values a lane holds for k-step s are keys 32 s + 8 g + 0..7, i.e. one contiguous 16-byte read of a V^T row.
+// V arrives already transposed ([channel][key], written by the projection GEMM's VT epilogue).
 //
-// Softmax cost (the d = 40 level is VALU-bound, not MFMA-bound: 64 x 64 scores per 28 MFMAs):
+// Softmax cost (the d = 40 level is VALU-bound, not MFMA-bound; rocprof PMC: VALU 81 % busy, MFMA 24 %):
 //   * one FMA per score: s' = s * (scale * log2 e) - m with the running max m taken BEFORE the tile (deferred max,
 //     guide T13): the O / l rescale runs only when a tile's max exceeds m by more than 2^8 (and on the first tile),
 //     so P <= 256 (exact in the fp32 accumulation, 11-bit relative in the fp16 P operand as always);
 //   * the row sum l is not accumulated on the VALU when head_dim leaves a spare row in the 16-row V^T padding
 //     (40 -> 48): that row of the LDS V^T tile is set to 1.0, so the PV MFMA itself produces sum(P~) with the SAME
 //     fp16-rounded P~ that multiplies V (numerator and denominator consistent; P~ packed with one round-toward-zero
-//     v_cvt_pkrtz per pair, whose bias cancels in the ratio).
+//     v_cvt_pkrtz per pair, whose bias cancels in the ratio);
+//   * everything tile-invariant of the K / V^T staging is hoisted, the partial last key tile is peeled.
 #include <cstdlib>
 #include <type_traits>
 
@@ -30,8 +31,6 @@
 
 namespace {
 
-constexpr int KV_TILE = 64;
-constexpr int VS = KV_TILE + 8;      // V^T LDS row stride (halfs)
 constexpr float DEFER_THR = 8.0f;    // log2 units
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -59,16 +58,21 @@ __device__ __forceinline__ uint32_t pack_rn(float a, float b) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
-// SPARE: head_dim < DPV, i.e. V^T row `head_dim` is free to hold the ones that make the MFMA compute the row sum.
-template <int DQK, int DPV, int QT, bool SPARE>
+// KVT: keys per tile (64 or 128).  SPARE: head_dim < DPV, i.e. V^T row `head_dim` is free to hold the ones that make
+// the MFMA compute the row sum.
+template <int DQK, int DPV, int QT, int KVT, bool SPARE>
 __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, const float scale_log2) {
   constexpr int KS = DQK + 8;          // K LDS row stride (halfs)
+  constexpr int VS = KVT + 8;          // V^T LDS row stride (halfs)
   constexpr int KSTEPS = DQK / 32;     // k-steps of the QK^T product
   constexpr int DT = DPV / 16;         // d tiles of O^T
+  constexpr int NKT = KVT / 16;        // 16-key S^T tiles per key tile
+  constexpr int NS2 = KVT / 32;        // k-steps of the PV product
   constexpr int KCH = DQK / 8;         // 16-byte chunks per K row
-  constexpr int NKC = (KV_TILE * KCH) / 256;            // K chunks per thread
-  constexpr int NVC = (DPV * 8 + 255) / 256;            // V^T chunks per thread (last pass may be partial)
-  __shared__ __attribute__((aligned(16))) f16 sKb[2][KV_TILE * KS];   // two stages: one barrier per key tile
+  constexpr int VCH = KVT / 8;         // 16-byte chunks per V^T row
+  constexpr int NKC = (KVT * KCH) / 256;                // K chunks per thread
+  constexpr int NVC = (DPV * VCH + 255) / 256;          // V^T chunks per thread (last pass may be partial)
+  __shared__ __attribute__((aligned(16))) f16 sKb[2][KVT * KS];   // two stages: one barrier per key tile
   __shared__ __attribute__((aligned(16))) f16 sVb[2][DPV * VS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
 #pragma unroll
   for (int i = 0; i < NVC; ++i) {
     const int id = tid + 256 * i;
-    const int row = id >> 3, c = id & 7;
+    const int row = id / VCH, c = id - row * VCH;
     v_key[i] = 8 * c;
     v_st[i] = row < DPV;
     v_ok[i] = row < DPV && row < d;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
     }
     rv[i] = v;
   }
-  const int64_t k_tile_stride = (int64_t)KV_TILE * p.k_row_stride;
+  const int64_t k_tile_stride = (int64_t)KVT * p.k_row_stride;
 
   auto prefetch_full = [&](int t) {
 #pragma unroll
@@ -151,10 +155,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
       if (k_ok[i]) rk[i] = ld_global_16B(kptr[i] + t * k_tile_stride);
 #pragma unroll
     for (int i = 0; i < NVC; ++i)
-      if (v_ok[i]) rv[i] = ld_global_16B(vptr[i] + t * KV_TILE);
+      if (v_ok[i]) rv[i] = ld_global_16B(vptr[i] + t * KVT);
   };
   auto prefetch_tail = [&](int t) {
-    const int key_base = t * KV_TILE;
+    const int key_base = t * KVT;
 #pragma unroll
     for (int i = 0; i < NKC; ++i) {
       if (k_ok[i]) {
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
         const int key0 = key_base + v_key[i];
         f16x8 v = zero8();
         if (key0 < lk) {
-          v = ld_global_16B(vptr[i] + t * KV_TILE);
+          v = ld_global_16B(vptr[i] + t * KVT);
           if (key0 + 8 > lk) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -190,13 +194,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
       if (v_st[i]) *reinterpret_cast<f16x8*>(&sV[v_lds[i]]) = rv[i];
   };
 
-  const int ntiles = (lk + KV_TILE - 1) / KV_TILE;
-  const bool partial = (lk % KV_TILE) != 0;
+  const int ntiles = (lk + KVT - 1) / KVT;
+  const bool partial = (lk % KVT) != 0;
   if (ntiles == 1 && partial) prefetch_tail(0); else prefetch_full(0);
   commit(0);
   __syncthreads();
 
-  // one key tile: TAIL = the last tile when lk % 64 != 0 (scores of keys >= lk are masked to -inf)
+  // one key tile: TAIL = the last tile when lk % KVT != 0 (scores of keys >= lk are masked to -inf)
   auto process = [&](auto tail_c, const int t) {
     constexpr bool TAIL = decltype(tail_c)::value;
     const bool more = (t + 1) < ntiles;
@@ -207,13 +211,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
     const f16* sV = sVb[t & 1];
 
     // ---- S^T = K Q^T
-    f32x4 sacc[4][QT];
+    f32x4 sacc[NKT][QT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int j = 0; j < QT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       const int krow = 32 * (kt >> 1) + 8 * (l15 >> 2) + 4 * (kt & 1) + (l15 & 3);
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
@@ -224,15 +228,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
     }
 
     // ---- online softmax with deferred max (per query column; keys over registers and the 4 lane groups)
-    const int key_base = t * KV_TILE;
+    const int key_base = t * KVT;
     const bool first = t == 0;
-    f16x8 pf[QT][2];
+    f16x8 pf[QT][NS2];
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
-      float sv[4][4];
+      float sv[NKT][4];
       const float mprev = mrow[j];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaf(sacc[kt][j][r], scale_log2, -mprev);
@@ -242,10 +246,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
           }
           sv[kt][r] = v;
         }
-      float mx = max3(max3(sv[0][0], sv[0][1], sv[0][2]), max3(sv[0][3], sv[1][0], sv[1][1]),
-                      max3(sv[1][2], sv[1][3], sv[2][0]));
-      mx = max3(mx, max3(sv[2][1], sv[2][2], sv[2][3]), max3(sv[3][0], sv[3][1], sv[3][2]));
-      mx = fmaxf(mx, sv[3][3]);
+      float mx = max3(sv[0][0], sv[0][1], fmaxf(sv[0][2], sv[0][3]));
+#pragma unroll
+      for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(max3(mx, sv[kt][0], sv[kt][1]), fmaxf(sv[kt][2], sv[kt][3]));
       mx = xor16_max(mx);   // v_permlane16_swap / v_permlane32_swap: cross-lane on the VALU, no LDS round trip
       mx = xor32_max(mx);
       if (__any(first || mx > DEFER_THR)) {          // wave-uniform; rare after the first tile
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
         const float alpha = first ? 1.0f : fast_exp2(-dlt);   // O is still zero on the first tile
         mrow[j] = mprev + dlt;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) sv[kt][r] -= dlt;
 #pragma unroll
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
       }
       float ls = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           sv[kt][r] = fast_exp2(sv[kt][r]);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
         }
       if (!SPARE) lrow[j] += ls;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
+      for (int s2 = 0; s2 < NS2; ++s2) {
         u32x4 w;
         if (SPARE) {
           w[0] = pack_rtz(sv[2 * s2][0], sv[2 * s2][1]);
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
 
     // ---- O^T += V^T P^T   (with SPARE, row `d` of V^T is all ones: O^T[d][q] accumulates the row sum)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < NS2; ++s2)
 #pragma unroll
       for (int i = 0; i < DT; ++i) {
         const f16x8 vf = *reinterpret_cast<const f16x8*>(&sV[(i * 16 + l15) * VS + 32 * s2 + 8 * g]);
@@ -355,14 +358,26 @@ int launch_q(const i2v_attn_params& p, hipStream_t s) {
   // softmax VALU overlaps the other's MFMAs; 4 tiles drop to 1 wave / SIMD and serialise the two pipes.
   int qt = 1;
   if (p.lq >= 128 && DQK <= 96) qt = 2;
-  static const int qt_env = getenv("I2V_ATTN_QT") ? atoi(getenv("I2V_ATTN_QT")) : 0;  // tuning override
+  static const int qt_env = getenv("I2V_ATTN_QT") ? atoi(getenv("I2V_ATTN_QT")) : 0;   // tuning overrides
+  static const int kvt_env = getenv("I2V_ATTN_KVT") ? atoi(getenv("I2V_ATTN_KVT")) : 0;
   if (qt_env == 1 || qt_env == 2) qt = qt_env;
+  int kvt = 64;   // 128-key tiles (half the barriers per key) measured 2-4 % slower: the loop is VALU-bound, not sync-bound
+  if (kvt_env == 64 || (kvt_env == 128 && DQK <= 64)) kvt = kvt_env;
   const dim3 block(256);
   const dim3 grid((unsigned)i2v_cdiv(p.lq, 64 * qt), (unsigned)p.heads, (unsigned)p.batch_q);
+  if constexpr (DQK <= 64) {
+    if (kvt == 128) {
+      if (qt == 2)
+        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, 128, SPARE>), grid, block, 0, s, p, scale_log2);
+      else
+        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, 128, SPARE>), grid, block, 0, s, p, scale_log2);
+      return i2v_check_launch("i2v_attention_f16");
+    }
+  }
   if (qt == 2)
-    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, SPARE>), grid, block, 0, s, p, scale_log2);
+    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, 64, SPARE>), grid, block, 0, s, p, scale_log2);
   else
-    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, SPARE>), grid, block, 0, s, p, scale_log2);
+    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, 64, SPARE>), grid, block, 0, s, p, scale_log2);
   return i2v_check_launch("i2v_attention_f16");
 }
 

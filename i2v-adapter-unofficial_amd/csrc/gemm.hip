@@ -307,7 +307,31 @@ int launch(const i2v_gemm_params& p, int vec4, hipStream_t s) {
 
 inline bool aligned_to(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// 8-byte vector epilogue is legal when every lane group of 4 consecutive n is complete and aligned
+int vector_epilogue_ok(const i2v_gemm_params& p) {
+  int vec4 = (p.N % 4 == 0) ? 1 : 0;
+  if (p.bias && !aligned_to(p.bias, 8)) vec4 = 0;
+  if (p.residual && (!aligned_to(p.residual, 8) || p.ldr % 4 != 0)) vec4 = 0;
+  if (p.rowvec && (!aligned_to(p.rowvec, 8) || p.ld_rowvec % 4 != 0)) vec4 = 0;
+  if (p.store_mode == I2V_STORE_VT) {
+    if (p.vt_len % 4 != 0 || p.vt_ld % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
+  } else if (p.store_mode == I2V_STORE_VT_T) {
+    // here `vec4` means "4 consecutive m (keys) form an aligned 8-byte store" -- only gemm_big.hip uses it
+    vec4 = (p.vt_len % 4 == 0 && p.vt_ld % 4 == 0 && aligned_to(p.c, 8) && p.M % 4 == 0) ? 1 : 0;
+  } else if (p.epilogue == I2V_EPI_GEGLU) {
+    if (p.ldc % 2 != 0 || !aligned_to(p.c, 4)) vec4 = 0;
+  } else {
+    if (p.ldc % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
+  }
+  return vec4;
+}
+
 }  // namespace
+
+extern "C" int64_t i2v_gemm_workspace_bytes(const i2v_gemm_params* pp) {
+  if (pp == nullptr || pp->M <= 0 || pp->N <= 0 || pp->K <= 0) return 0;
+  return i2v_gemm_big_workspace_bytes(*pp, vector_epilogue_ok(*pp));
+}
 
 extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(pp != nullptr, "i2v_gemm_f16: null params");
@@ -364,21 +388,7 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     I2V_CHECK_ARG(p.residual == nullptr && p.rowvec == nullptr, "i2v_gemm_f16: VT store takes no residual/rowvec");
   }
 
-  // 8-byte vector epilogue is legal when every lane group of 4 consecutive n is complete and aligned
-  int vec4 = (p.N % 4 == 0) ? 1 : 0;
-  if (p.bias && !aligned_to(p.bias, 8)) vec4 = 0;
-  if (p.residual && (!aligned_to(p.residual, 8) || p.ldr % 4 != 0)) vec4 = 0;
-  if (p.rowvec && (!aligned_to(p.rowvec, 8) || p.ld_rowvec % 4 != 0)) vec4 = 0;
-  if (p.store_mode == I2V_STORE_VT) {
-    if (p.vt_len % 4 != 0 || p.vt_ld % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
-  } else if (p.store_mode == I2V_STORE_VT_T) {
-    // here `vec4` means "4 consecutive m (keys) form an aligned 8-byte store" -- only gemm_big.hip uses it
-    vec4 = (p.vt_len % 4 == 0 && p.vt_ld % 4 == 0 && aligned_to(p.c, 8) && p.M % 4 == 0) ? 1 : 0;
-  } else if (p.epilogue == I2V_EPI_GEGLU) {
-    if (p.ldc % 2 != 0 || !aligned_to(p.c, 4)) vec4 = 0;
-  } else {
-    if (p.ldc % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
-  }
+  int vec4 = vector_epilogue_ok(p);
 
   // large problems whose N is a multiple of 320 go to the 8-wave LDS-DMA kernel (gemm_big.hip)
   {

@@ -108,8 +108,20 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
     p.epilogue, p.store_mode = epilogue, store
     p.frames, p.hw = frames, hw
     p.out_scale = out_scale
+    ws = _attach_splitk_workspace(lib, p, a.device)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16")
+    del ws
     return out
+
+
+def _attach_splitk_workspace(lib, p, device):
+    """Small-M / long-K problems split K over workgroups; the fp32 partial tiles live in a caller-owned scratch."""
+    need = lib.i2v_gemm_workspace_bytes(C.byref(p))
+    if need <= 0:
+        return None
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    p.workspace, p.workspace_bytes = _p(ws), need
+    return ws
 
 
 def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
@@ -158,7 +170,9 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     p.out_scale = out_scale
     p.n_img, p.in_h, p.in_w, p.cin = n, h, wd, cin
     p.out_h, p.out_w, p.stride, p.upsample = oh, ow, stride, 1 if upsample else 0
+    ws = _attach_splitk_workspace(lib, p, x.device)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16(conv3x3)")
+    del ws
     return out
 
 

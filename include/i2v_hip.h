@@ -101,9 +101,16 @@ typedef struct i2v_gemm_params {
      3x3 kernel, padding 1, `stride` 1 or 2; `upsample` = 1 applies nearest-2x to the input first
      (Upsample2D).  M = n_img * out_h * out_w. */
   int32_t n_img, in_h, in_w, cin, out_h, out_w, stride, upsample;
+  /* optional fp32 scratch for split-K (small M, long K: the 8 x 8 level's convolutions): when it holds at least
+     i2v_gemm_workspace_bytes(p) bytes the K loop is split over several workgroups whose fp32 partial tiles are
+     summed by a second kernel that applies the epilogue; NULL / too small => no split. */
+  void* workspace;
+  int64_t workspace_bytes;
 } i2v_gemm_params;
 
 int i2v_gemm_f16(const i2v_gemm_params* p, i2v_stream_t stream);
+/* bytes of `workspace` with which i2v_gemm_f16 would split K for this problem (0: it would not split). */
+int64_t i2v_gemm_workspace_bytes(const i2v_gemm_params* p);
 
 /* ------------------------------------------------------------------------------------------------
  * Flash-style attention forward (MFMA QK^T / PV, wavefront-shuffle online softmax).

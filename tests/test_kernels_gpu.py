@@ -85,6 +85,27 @@ def test_gemm_big_tiles(dev, M, N, K_, kind):
         close(vt[:, :, :4096], ref, name="big vt")
 
 
+def test_gemm_and_conv_split_k(dev):
+    """small M, long K (the 8 x 8 level): K split over workgroups + fp32 reduce kernel with the fused epilogue."""
+    k = K()
+    g = torch.Generator().manual_seed(23)
+    M, N, K_ = 2048, 1280, 5120
+    a, w = h(torch.randn(M, K_, generator=g)), h(torch.randn(N, K_, generator=g) / math.sqrt(K_))
+    b, r = h(torch.randn(N, generator=g)), h(torch.randn(M, N, generator=g))
+    out = k.gemm(a.half().to(dev), w.half().to(dev), b.half().to(dev), residual=r.half().to(dev))
+    close(out, a @ w.T + b + r, name="split-K gemm")
+    n, hh, ww, cin, cout = 32, 8, 8, 320, 1280
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    wc = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    bc = h(torch.randn(cout, generator=g))
+    rv = h(torch.randn(n, cout, generator=g))
+    ref = F.conv2d(x, wc, bc, padding=1) + rv[:, :, None, None]
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    wp = wc.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().half().to(dev)
+    out = k.conv3x3(xt, wp, bc.half().to(dev), rowvec=rv.half().to(dev), rows_per_vec=hh * ww)
+    close(out.permute(0, 3, 1, 2), ref, name="split-K conv")
+
+
 @pytest.mark.parametrize("batches,L,C,Kd", [(4, 6, 24, 16), (2, 64, 320, 64), (3, 4096, 640, 64), (5, 16, 320, 320)])
 def test_gemm_store_vt_t(dev, batches, L, C, Kd):
     """V^T from the natural operand order (A = tokens): generic kernel (small) and 256-row tile kernel (large)."""
@@ -227,7 +248,7 @@ def _attn_ref(q, k_, v, heads, group):
     (2, 1, 2, 8, 64, 64), (4, 2, 4, 16, 100, 100), (2, 1, 2, 32, 256, 256), (8, 4, 8, 40, 256, 256),
     (2, 1, 8, 40, 1024, 1024), (2, 1, 2, 64, 130, 77), (2, 1, 8, 80, 256, 77), (2, 2, 4, 160, 64, 64),
     (1, 1, 2, 160, 300, 200), (3, 1, 2, 24, 16, 4), (2, 1, 3, 48, 40, 129), (2, 1, 2, 96, 128, 64),
-    (2, 1, 1, 128, 128, 192)])
+    (2, 1, 1, 128, 128, 192), (2, 1, 2, 40, 200, 700), (2, 2, 2, 64, 130, 513), (1, 1, 2, 16, 64, 640)])
 def test_attention(dev, bq, group, heads, d, lq, lk):
     k = K()
     g = torch.Generator().manual_seed(bq * 100 + d + lq)
