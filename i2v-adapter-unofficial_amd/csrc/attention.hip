@@ -16,9 +16,13 @@
 // V arrives already transposed ([channel][key], written by the projection GEMM's VT epilogue).
 //
 // Softmax cost (the d = 40 level is VALU-bound, not MFMA-bound; rocprof PMC: VALU 81 % busy, MFMA 24 %):
-//   * one FMA per score: s' = s * (scale * log2 e) - m with the running max m taken BEFORE the tile (deferred max,
-//     guide T13): the O / l rescale runs only when a tile's max exceeds m by more than 2^8 (and on the first tile),
-//     so P <= 256 (exact in the fp32 accumulation, 11-bit relative in the fp16 P operand as always);
+//   * no arithmetic between the QK^T MFMA and exp2: scale * log2 e is folded into the Q fragments once per workgroup,
+//     and -m (the running max, taken BEFORE the tile: deferred max, guide T13) is the initial accumulator of the MFMA
+//     chain, which therefore ends with s' = s * scale * log2 e - m.  The O / l rescale runs only when a tile's max
+//     exceeds m by more than 2^8 (and on the first tile), so P <= 256 (exact in the fp32 accumulation, 11-bit
+//     relative in the fp16 P operand as always);
+//   * K / V^T tiles are prefetched with raw buffer loads (scalar tile offset, hardware range check instead of exec
+//     masks): the hot loop's prefetch costs no VALU and nothing waits on it before the tile's MFMAs;
 //   * the row sum l is not accumulated on the VALU when head_dim leaves a spare row in the 16-row V^T padding
 //     (40 -> 48): that row of the LDS V^T tile is set to 1.0, so the PV MFMA itself produces sum(P~) with the SAME
 //     fp16-rounded P~ that multiplies V (numerator and denominator consistent; P~ packed with one round-toward-zero
@@ -60,8 +64,12 @@ __device__ __forceinline__ uint32_t pack_rn(float a, float b) {
 
 // KVT: keys per tile (64 or 128).  SPARE: head_dim < DPV, i.e. V^T row `head_dim` is free to hold the ones that make
 // the MFMA compute the row sum.
+// The head_dim 40 variant (the 64 x 64 level: 80 % of the attention time) is held to 128 VGPRs = 4 waves / SIMD (its
+// few spills land outside the key loop): +5 % over the 154-VGPR / 3-wave build.  d = 64 spills inside the loop at 128.
 template <int DQK, int DPV, int QT, int KVT, bool SPARE>
-__global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, const float scale_log2) {
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(DQK == 64 && DPV == 48 && QT == 2 && KVT == 64 ? 4 : 1)))
+void attn_kernel(const i2v_attn_params p, const float scale_log2) {
   constexpr int KS = DQK + 8;          // K LDS row stride (halfs)
   constexpr int VS = KVT + 8;          // V^T LDS row stride (halfs)
   constexpr int KSTEPS = DQK / 32;     // k-steps of the QK^T product
@@ -97,6 +105,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
       const int dd = 32 * s + 8 * g;
       f16x8 v = zero8();
       if (row < lq && dd < d) v = ld_global_16B(Q + (int64_t)row * p.q_row_stride + dd);
+      // fold scale * log2(e) into Q once, so that the QK^T accumulator already holds base-2 logits
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * scale_log2);
       qf[qt][s] = v;
     }
   }
@@ -106,82 +117,74 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
   for (int i = 0; i < DT; ++i)
 #pragma unroll
     for (int j = 0; j < QT; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow[QT], lrow[QT];
+  // negm[j] = -(running max of query column j) in all four registers: it is the INITIAL ACCUMULATOR of the QK^T MFMA
+  // chain, so the chain ends with s - m and the softmax needs neither a multiply nor a subtraction per score
+  f32x4 negm[QT];
+  float lrow[QT];
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
-    mrow[j] = 0.f;   // finite: the first tile always takes the rescale path, which sets the true running max
+    negm[j] = f32x4{0.f, 0.f, 0.f, 0.f};   // finite: the first tile always takes the rescale path (sets the true max)
     lrow[j] = 0.f;
   }
 
   // ---- K / V^T staging: everything that does not depend on the tile index is hoisted (per-thread source pointers,
   //      LDS offsets, validity of the chunk inside head_dim); registers of chunks outside head_dim stay 0 (or 1.0
   //      for the row-sum row) for the whole kernel.  Only the last, partial key tile takes the masked loader.
+  //      Loads are raw buffer loads through wave-uniform descriptors of this (batch, head)'s K and V^T slices: a
+  //      32-bit per-lane byte offset computed once + a scalar tile offset, and the hardware range check instead of
+  //      exec masks (a lane whose chunk lies outside head_dim carries an out-of-range offset and receives 0; K rows
+  //      of keys >= lk are past the end of the slice and come back 0 too).  The hot loop therefore issues its
+  //      prefetch with no VALU work and no branches, and nothing waits on it before the tile's MFMAs.
+  constexpr int OOB = 0x40000000;      // > any slice extent (checked on the host), no wrap with the tile offset
   f16x8 rk[NKC], rv[NVC];
-  const f16* kptr[NKC];
-  const f16* vptr[NVC];
-  int k_lds[NKC], v_lds[NVC], k_row[NKC], v_key[NVC];
-  bool k_ok[NKC], v_ok[NVC], v_st[NVC];
+  int k_off[NKC], v_off[NVC], k_lds[NKC], v_lds[NVC];
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<f16*>(Kg), 0, (int)(((int64_t)(lk - 1) * p.k_row_stride + d) * 2), 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<f16*>(Vg), 0, (int)(((int64_t)(d - 1) * p.vt_row_stride + ((lk + 7) & ~7)) * 2), 0x00020000);
 #pragma unroll
   for (int i = 0; i < NKC; ++i) {
     const int id = tid + 256 * i;
     const int row = id / KCH, c = id - row * KCH;
-    k_row[i] = row;
-    k_ok[i] = 8 * c < d;
-    kptr[i] = Kg + (int64_t)row * p.k_row_stride + 8 * c;
+    k_off[i] = 8 * c < d ? (int)((row * p.k_row_stride + 8 * c) * 2) : OOB;
     k_lds[i] = row * KS + 8 * c;
-    rk[i] = zero8();
   }
 #pragma unroll
   for (int i = 0; i < NVC; ++i) {
     const int id = tid + 256 * i;
     const int row = id / VCH, c = id - row * VCH;
-    v_key[i] = 8 * c;
-    v_st[i] = row < DPV;
-    v_ok[i] = row < DPV && row < d;
-    vptr[i] = Vg + (int64_t)row * p.vt_row_stride + 8 * c;
-    v_lds[i] = row * VS + 8 * c;
-    f16x8 v = zero8();
-    if (SPARE && row == d) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (f16)1.f;   // masked keys carry P = 0, so 1.0 for every key is right
-    }
-    rv[i] = v;
+    v_off[i] = row < d ? (int)((row * p.vt_row_stride + 8 * c) * 2) : OOB;
+    // rows d < row < DPV are rewritten with the zeros the range check returns; lanes past the tile, and the lanes of
+    // the all-ones row-sum row (written once below), park their store in the 16-byte pad of some row
+    const bool real = row < DPV && !(SPARE && row == d);
+    v_lds[i] = real ? row * VS + 8 * c : (tid % DPV) * VS + KVT;
   }
-  const int64_t k_tile_stride = (int64_t)KVT * p.k_row_stride;
+  if (SPARE && tid < 2 * VCH) {   // masked keys carry P = 0, so 1.0 for every key is right
+    f16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
+    *reinterpret_cast<f16x8*>(&sVb[tid / VCH][d * VS + 8 * (tid % VCH)]) = ones;
+  }
+  const int k_tile_bytes = (int)(KVT * p.k_row_stride * 2);
 
-  auto prefetch_full = [&](int t) {
+  auto issue = [&](int t) {
+    const int ks = t * k_tile_bytes, vs = t * (KVT * 2);
 #pragma unroll
     for (int i = 0; i < NKC; ++i)
-      if (k_ok[i]) rk[i] = ld_global_16B(kptr[i] + t * k_tile_stride);
+      rk[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_off[i], ks, 0));
 #pragma unroll
     for (int i = 0; i < NVC; ++i)
-      if (v_ok[i]) rv[i] = ld_global_16B(vptr[i] + t * KVT);
+      rv[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_off[i], vs, 0));
   };
-  auto prefetch_tail = [&](int t) {
-    const int key_base = t * KVT;
-#pragma unroll
-    for (int i = 0; i < NKC; ++i) {
-      if (k_ok[i]) {
-        f16x8 v = zero8();
-        if (key_base + k_row[i] < lk) v = ld_global_16B(kptr[i] + t * k_tile_stride);
-        rk[i] = v;
-      }
-    }
+  // the last, partial key tile: V^T entries of keys >= lk continue into row padding / the next row, so they are
+  // zeroed by hand (P = 0 for those keys, but 0 * garbage must not be NaN)
+  auto mask_tail_v = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NVC; ++i) {
-      if (v_ok[i]) {
-        const int key0 = key_base + v_key[i];
-        f16x8 v = zero8();
-        if (key0 < lk) {
-          v = ld_global_16B(vptr[i] + t * KVT);
-          if (key0 + 8 > lk) {
+      const int key0 = t * KVT + 8 * ((tid + 256 * i) % VCH);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (key0 + e >= lk) v[e] = (f16)0.f;
-          }
-        }
-        rv[i] = v;
-      }
+      for (int e = 0; e < 8; ++e)
+        if (key0 + e >= lk) rv[i][e] = (f16)0.f;
     }
   };
   auto commit = [&](int stage) {
@@ -190,32 +193,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
 #pragma unroll
     for (int i = 0; i < NKC; ++i) *reinterpret_cast<f16x8*>(&sK[k_lds[i]]) = rk[i];
 #pragma unroll
-    for (int i = 0; i < NVC; ++i)
-      if (v_st[i]) *reinterpret_cast<f16x8*>(&sV[v_lds[i]]) = rv[i];
+    for (int i = 0; i < NVC; ++i) *reinterpret_cast<f16x8*>(&sV[v_lds[i]]) = rv[i];
   };
 
   const int ntiles = (lk + KVT - 1) / KVT;
   const bool partial = (lk % KVT) != 0;
-  if (ntiles == 1 && partial) prefetch_tail(0); else prefetch_full(0);
+  issue(0);
+  if (ntiles == 1 && partial) mask_tail_v(0);
   commit(0);
   __syncthreads();
 
-  // one key tile: TAIL = the last tile when lk % KVT != 0 (scores of keys >= lk are masked to -inf)
-  auto process = [&](auto tail_c, const int t) {
+  // one key tile: TAIL = the last tile when lk % KVT != 0 (scores of keys >= lk are masked to -inf); MORE = a next
+  // tile exists and is prefetched into registers while this one is computed
+  auto process = [&](auto tail_c, auto more_c, const int t) {
     constexpr bool TAIL = decltype(tail_c)::value;
-    const bool more = (t + 1) < ntiles;
-    if (more) {
-      if (partial && t + 2 == ntiles) prefetch_tail(t + 1); else prefetch_full(t + 1);
-    }
+    constexpr bool more = decltype(more_c)::value;
+    if (more) issue(t + 1);
     const f16* sK = sKb[t & 1];
     const f16* sV = sVb[t & 1];
 
     // ---- S^T = K Q^T
     f32x4 sacc[NKT][QT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int j = 0; j < QT; ++j) sacc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int krow = 32 * (kt >> 1) + 8 * (l15 >> 2) + 4 * (kt & 1) + (l15 & 3);
@@ -223,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
       for (int s = 0; s < KSTEPS; ++s) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(&sK[krow * KS + 32 * s + 8 * g]);
 #pragma unroll
-        for (int j = 0; j < QT; ++j) sacc[kt][j] = mfma16x16x32(kf, qf[j][s], sacc[kt][j]);
+        for (int j = 0; j < QT; ++j) sacc[kt][j] = mfma16x16x32(kf, qf[j][s], s == 0 ? negm[j] : sacc[kt][j]);
       }
     }
 
@@ -234,12 +232,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
       float sv[NKT][4];
-      const float mprev = mrow[j];
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = fmaf(sacc[kt][j][r], scale_log2, -mprev);
+          float v = sacc[kt][j][r];   // = s * scale * log2(e) - m_prev
           if (TAIL) {
             const int key = key_base + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
             if (key >= lk) v = -INFINITY;
@@ -254,7 +251,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
       if (__any(first || mx > DEFER_THR)) {          // wave-uniform; rare after the first tile
         const float dlt = first ? mx : fmaxf(mx, 0.f);
         const float alpha = first ? 1.0f : fast_exp2(-dlt);   // O is still zero on the first tile
-        mrow[j] = mprev + dlt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) negm[j][r] -= dlt;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -302,13 +300,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const i2v_attn_params p, cons
         for (int j = 0; j < QT; ++j) o[i][j] = mfma16x16x32(vf, pf[j][s2], o[i][j]);
       }
 
-    if (more) commit((t + 1) & 1);   // the other stage was last read in iteration t - 1 (closed by its barrier)
-    __syncthreads();
+    if (more) {
+      if (partial && t + 2 == ntiles) mask_tail_v(t + 1);
+      commit((t + 1) & 1);   // the other stage was last read in iteration t - 1 (closed by its barrier)
+      __syncthreads();
+    }
   };
 
-  const int nfull = partial ? ntiles - 1 : ntiles;
-  for (int t = 0; t < nfull; ++t) process(std::false_type{}, t);
-  if (partial) process(std::true_type{}, ntiles - 1);
+  for (int t = 0; t + 1 < ntiles; ++t) process(std::false_type{}, std::true_type{}, t);
+  if (partial)
+    process(std::true_type{}, std::false_type{}, ntiles - 1);
+  else
+    process(std::false_type{}, std::false_type{}, ntiles - 1);
 
   // ---- normalise and store: lane holds O[query l15][d = 16 i + 4 g + r]
   f16* __restrict__ O = reinterpret_cast<f16*>(p.o) + (int64_t)bq * p.o_batch_stride + h * d;
@@ -407,6 +410,10 @@ extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream)
   I2V_CHECK_ARG(p.o_row_stride % 4 == 0 && p.o_batch_stride % 4 == 0, "i2v_attention_f16: o strides must be multiples of 4");
   I2V_CHECK_ARG(al(p.q, 16) && al(p.k, 16) && al(p.vt, 16) && al(p.o, 8), "i2v_attention_f16: pointer alignment");
   I2V_CHECK_ARG(p.heads <= 65535 && p.batch_q <= 65535, "i2v_attention_f16: heads / batch_q exceed the grid limits");
+  // the kernel addresses one (batch, head) slice of K and of V^T with 32-bit byte offsets (buffer loads)
+  I2V_CHECK_ARG(p.k_row_stride > 0 && ((int64_t)p.lk + 128) * p.k_row_stride * 2 < (1ll << 30) &&
+                    p.vt_row_stride > 0 && ((int64_t)p.head_dim * p.vt_row_stride + 256) * 2 < (1ll << 30),
+                "i2v_attention_f16: one (batch, head) slice of K / V^T must span less than 1 GiB");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int d = p.head_dim;
   if (d <= 16) return launch_d<32, 16>(p, s);

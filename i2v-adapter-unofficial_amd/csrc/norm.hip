@@ -93,28 +93,41 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
 }
 
 // pass 2: one wave per (stat group, channel group): mean / rstd, then per-(image, channel) scale & shift.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C, int groups,
-                                                         int fps, int hw, float eps, const f16* __restrict__ gamma,
-                                                         const f16* __restrict__ beta, float* __restrict__ coef) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C,
+                                                          int groups, int fps, int hw, float eps,
+                                                          const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                          float* __restrict__ coef) {
+  __shared__ float red[8];
   const int sg = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
   const int cpg = C / groups;
   const int total = fps * nchunk * cpg;
   float s = 0.f, q = 0.f;
-  for (int i = lane; i < total; i += 64) {
+  // the motion modules normalise over all frames of a clip (fps = 16): thousands of partials per group, each an
+  // 8-byte strided load, so keep many of them in flight per workgroup
+#pragma unroll 4
+  for (int i = lane; i < total; i += 256) {
     const int c = i % cpg, t = i / cpg;
     const int ch = t % nchunk, f = t / nchunk;
-    const float* src = partial + ((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 2;
-    s += src[0];
-    q += src[1];
+    const float2 v = *reinterpret_cast<const float2*>(
+        partial + ((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 2);
+    s += v.x;
+    q += v.y;
   }
   s = wave_sum(s);
   q = wave_sum(q);
+  if ((lane & 63) == 0) {
+    red[(lane >> 6) * 2] = s;
+    red[(lane >> 6) * 2 + 1] = q;
+  }
+  __syncthreads();
+  s = red[0] + red[2] + red[4] + red[6];
+  q = red[1] + red[3] + red[5] + red[7];
   const float cnt = (float)fps * (float)hw * (float)cpg;
   const float mean = s / cnt;
   float var = q / cnt - mean * mean;
   var = var < 0.f ? 0.f : var;
   const float rstd = rsqrtf(var + eps);
-  for (int i = lane; i < fps * cpg; i += 64) {
+  for (int i = lane; i < fps * cpg; i += 256) {
     const int c = grp * cpg + i % cpg, f = i / cpg;
     const float ga = (float)gamma[c] * rstd;
     float* dst = coef + ((int64_t)(sg * fps + f) * C + c) * 2;
@@ -257,7 +270,7 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   const f16* x1 = reinterpret_cast<const f16*>(p.x);
   const f16* x2 = reinterpret_cast<const f16*>(p.x2);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(64), 0, s, partial, nchunk, C,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, partial, nchunk, C,
                      p.groups, p.frames_per_stat, p.hw, p.eps, reinterpret_cast<const f16*>(p.gamma),
                      reinterpret_cast<const f16*>(p.beta), coef);
   const int64_t total = (int64_t)p.n_img * p.hw * (C / 8);
