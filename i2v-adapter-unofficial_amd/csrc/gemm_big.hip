@@ -18,13 +18,14 @@
 
 namespace {
 
-__device__ __attribute__((aligned(64))) f16 g_zero_page[64];  // zero-initialised: source for masked LDS-DMA lanes
-
 constexpr int BIG_BN = 320;
 
-__device__ __forceinline__ void glds16(const f16* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// buffer_load_dwordx4 ... offen lds: 16 bytes per lane, global -> LDS at (wave-uniform LDS base) + 16 * lane; a lane
+// whose offset fails the descriptor's range check writes zeros.  (A plain function on purpose: called directly from the
+// kernel template, the builtin makes hipcc's host pass drop the kernel's launch stub without a diagnostic.)
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0,
+                                           0);
 }
 
 template <int N>
@@ -43,14 +44,30 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // SPLIT: blockIdx.y selects a range of `kps` K tiles; the fp32 accumulators go to p.workspace[split][M][N] and
 // splitk_reduce_kernel applies the epilogue (small-M / long-K problems that cannot fill the chip with output tiles).
-template <int BM, int AMODE, int EPI, int STORE, bool SPLIT = false>
+//
+// Pipeline depth: NS LDS stages of BK-deep tiles, NS - 1 tiles' DMA in flight.  (BK, NS) = (64, 2) keeps one 72 KiB
+// tile in flight; (32, 4) keeps three 36 KiB tiles (1.5x the bytes, issued in finer steps) for the same 144 KiB.
+// The LDS image is made of 128-byte units: one row of a BK = 64 tile, or two consecutive rows of a BK = 32 tile
+// (chunks 0-3 = even row, 4-7 = odd row); unit u stores chunk c at c ^ ((u >> 1) & 7).
+template <int BK>
+__device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
+  const int u = BK == 64 ? row : row >> 1;
+  const int c8 = BK == 64 ? kchunk : ((row & 1) << 2) + kchunk;
+  return u * 128 + ((c8 ^ ((u >> 1) & 7)) << 4);
+}
+
+template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) {
   constexpr int BN = BIG_BN;
   constexpr int WM = BM / 2, MI = WM / 16, NI = 5;
-  constexpr int AG = BM / 64;  // 8-row (1 KiB) A groups per wave: (BM / 8) groups over 8 waves
-  constexpr int WG = 5;        // W groups per wave: 40 over 8 waves
-  constexpr int STAGE = (BM + BN) * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr int AG = BM * BK / 4096;        // 1 KiB (8-unit) A groups per wave: BM * BK * 2 / 1024 groups over 8 waves
+  constexpr int WGT = BN * BK * 2 / 1024;   // W groups per tile (40 or 20)
+  constexpr int WG = (WGT + 7) / 8;         // per wave; for BK = 32 the third one exists for waves 0-3 only
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int KSTEPS = BK / 32;
+  constexpr int LEAD = NS - 1;              // tiles in flight
+  // + 1 KiB that swallows the DMA of W groups past the tile (every wave issues the same count: one vmcnt for all)
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 1024];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,92 +81,98 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const f16* __restrict__ A2 = reinterpret_cast<const f16*>(p.a2);
   const f16* __restrict__ W = reinterpret_cast<const f16*>(p.w);
   const int ksp = (A2 != nullptr) ? p.k_split : K;
-  const f16* zero = g_zero_page;
 
-  // ---- per-lane DMA source description: lane -> (row of the 8-row group, logical 16-byte chunk)
+  // ---- DMA sources.  Every operand is addressed through a wave-uniform buffer descriptor with a 32-bit per-lane
+  //      byte offset (slice extents < 2 GiB, K and k_split multiples of BK: checked on the host).  A lane that must
+  //      contribute zeros (row >= M, conv halo) carries an out-of-range offset: the range check of buffer_load ... lds
+  //      writes 0 to LDS for it (LDS-DMA cannot skip a lane).  Per K tile only the scalar offset changes, so the
+  //      plain-GEMM prefetch costs no VALU work and no 64-bit address registers.
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int RSTEP = BK == 64 ? 64 : 128;   // tile rows between a wave's consecutive 1 KiB groups
   const int lr = lane >> 3, lc = lane & 7;
-  int a_k[AG];          // k offset (halfs) of this lane's chunk inside a K tile
-  bool a_ok[AG];
-  int64_t a_off[AG], a_off2[AG];   // plain: row offsets in the two sources
-  int c_pix[AG], c_oy[AG], c_ox[AG], c_tap[AG], c_ci[AG];   // conv: output pixel + running (tap, channel) of the chunk
+  const int u0 = 8 * wave + lr;                // 128-byte unit of group 0; group i is unit u0 + 64 i, same swizzle
+  const int c8 = lc ^ ((u0 >> 1) & 7);         // logical chunk this lane fetches (swizzle on the SOURCE side)
+  const int r0 = BK == 64 ? u0 : 2 * u0 + (c8 >> 2);
+  const int lane_k = (BK == 64 ? c8 : (c8 & 3)) * 8;   // k offset (halfs) of the chunk inside a K tile
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W), 0,
+                                                      (int)(((int64_t)(N - 1) * p.ldw + K) * 2), 0x00020000);
+  const unsigned w_voff = (unsigned)(((n0 + r0) * (int)p.ldw + lane_k) * 2);
+  const int64_t a_extent = AMODE == I2V_A_CONV3X3 ? ((int64_t)p.n_img * p.in_h * p.in_w - 1) * p.lda + p.cin
+                                                  : (int64_t)(M - 1) * p.lda + ksp;
+  const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(A), 0, (int)(a_extent * 2), 0x00020000);
+  const auto rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<f16*>(A2 ? A2 : A), 0, A2 ? (int)(((int64_t)(M - 1) * p.lda2 + (K - ksp)) * 2) : 0, 0x00020000);
+  unsigned a_voff[AG];                         // plain: byte offset of (row, lane_k) in A, or OOB
+  int c_pix[AG], c_oy[AG], c_ox[AG];           // conv: first pixel of the row's image, output pixel coordinates
 #pragma unroll
   for (int i = 0; i < AG; ++i) {
-    const int r = 8 * (wave + 8 * i) + lr;
-    const int clog = lc ^ ((r >> 1) & 7);
-    const int m = m0 + r;
-    a_k[i] = clog * 8;
-    a_ok[i] = m < M;
+    const int m = m0 + r0 + RSTEP * i;
+    const bool ok = m < M;
     if (AMODE == I2V_A_CONV3X3) {
       const int ohw = p.out_h * p.out_w;
-      const int mm = a_ok[i] ? m : 0;
+      const int mm = ok ? m : 0;
       const int img = mm / ohw, rem = mm - img * ohw;
       c_pix[i] = img * p.in_h * p.in_w;
-      c_oy[i] = rem / p.out_w;
-      c_ox[i] = rem - c_oy[i] * p.out_w;
-      const int k_first = a_k[i] + (SPLIT ? (int)blockIdx.y * kps * 64 : 0);
-      c_tap[i] = k_first / p.cin;
-      c_ci[i] = k_first - c_tap[i] * p.cin;
-      a_off[i] = a_off2[i] = 0;
+      c_oy[i] = ok ? rem / p.out_w : -4;       // row >= M: every tap falls outside the image
+      c_ox[i] = rem - (rem / p.out_w) * p.out_w;
+      a_voff[i] = 0;
     } else {
-      a_off[i] = (int64_t)m * p.lda;
-      a_off2[i] = (int64_t)m * p.lda2;
-      c_pix[i] = c_oy[i] = c_ox[i] = c_tap[i] = c_ci[i] = 0;
+      a_voff[i] = ok ? (unsigned)((m * (int)p.lda + lane_k) * 2) : OOB;
+      c_pix[i] = c_oy[i] = c_ox[i] = 0;
     }
   }
-  int w_k[WG];
-  bool w_ok[WG];
-  int64_t w_off[WG];
-#pragma unroll
-  for (int i = 0; i < WG; ++i) {
-    const int r = 8 * (wave + 8 * i) + lr;
-    const int clog = lc ^ ((r >> 1) & 7);
-    const int n = n0 + r;
-    w_k[i] = clog * 8;
-    w_ok[i] = n < N;
-    w_off[i] = (int64_t)n * p.ldw;
+  // conv: (tap, first channel) of the K tile being issued; cin % BK == 0, so a tile never straddles two taps
+  int s_tap = 0, s_ci = 0;
+  if (AMODE == I2V_A_CONV3X3 && SPLIT) {
+    const int k_first = (int)blockIdx.y * kps * BK;
+    s_tap = k_first / p.cin;
+    s_ci = k_first - s_tap * p.cin;
   }
 
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
-    char* sw = sa + BM * 128;
-    const int kb = kt * 64;
+    char* sw = sa + BM * BK * 2;
+    const int kb = kt * BK;
+    if (AMODE == I2V_A_CONV3X3) {
+      const int dy = s_tap / 3, dx = s_tap - dy * 3;
 #pragma unroll
-    for (int i = 0; i < AG; ++i) {
-      const f16* src = zero;
-      if (AMODE == I2V_A_CONV3X3) {
-        // (tap, ci) of this lane's chunk were advanced incrementally; tap >= 9 <=> k >= K
-        if (a_ok[i] && c_tap[i] < 9) {
-          const int dy = c_tap[i] / 3, dx = c_tap[i] - dy * 3;
-          int iy, ix;
-          bool ok;
-          if (p.upsample) {
-            const int uy = c_oy[i] - 1 + dy, ux = c_ox[i] - 1 + dx;
-            ok = (uy >= 0) && (ux >= 0) && (uy < 2 * p.in_h) && (ux < 2 * p.in_w);
-            iy = uy >> 1;
-            ix = ux >> 1;
-          } else {
-            iy = c_oy[i] * p.stride - 1 + dy;
-            ix = c_ox[i] * p.stride - 1 + dx;
-            ok = (iy >= 0) && (ix >= 0) && (iy < p.in_h) && (ix < p.in_w);
-          }
-          if (ok) src = A + (int64_t)(c_pix[i] + iy * p.in_w + ix) * p.lda + c_ci[i];
+      for (int i = 0; i < AG; ++i) {
+        int iy, ix;
+        bool ok;
+        if (p.upsample) {
+          const int uy = c_oy[i] - 1 + dy, ux = c_ox[i] - 1 + dx;
+          ok = (uy >= 0) && (ux >= 0) && (uy < 2 * p.in_h) && (ux < 2 * p.in_w);
+          iy = uy >> 1;
+          ix = ux >> 1;
+        } else {
+          iy = c_oy[i] * p.stride - 1 + dy;
+          ix = c_ox[i] * p.stride - 1 + dx;
+          ok = (iy >= 0) && (ix >= 0) && (iy < p.in_h) && (ix < p.in_w);
         }
-        c_ci[i] += 64;
-        while (c_ci[i] >= p.cin) {
-          c_ci[i] -= p.cin;
-          c_tap[i] += 1;
-        }
-      } else {
-        const int k = kb + a_k[i];
-        if (a_ok[i] && k < K) src = (k < ksp) ? (A + a_off[i] + k) : (A2 + a_off2[i] + (k - ksp));
+        const unsigned voff = ok ? (unsigned)(((c_pix[i] + iy * p.in_w + ix) * (int)p.lda + s_ci + lane_k) * 2) : OOB;
+        bdma16(rs_a, sa + (wave + 8 * i) * 1024, voff, 0);
       }
-      glds16(src, sa + (wave + 8 * i) * 1024);
+      s_ci += BK;
+      if (s_ci >= p.cin) {
+        s_ci -= p.cin;
+        s_tap += 1;
+      }
+    } else if (kb < ksp) {
+#pragma unroll
+      for (int i = 0; i < AG; ++i) bdma16(rs_a, sa + (wave + 8 * i) * 1024, a_voff[i], kb * 2);
+    } else {   // second source of a channel-concatenated A (skip connections)
+#pragma unroll
+      for (int i = 0; i < AG; ++i) {
+        const int m = m0 + r0 + RSTEP * i;
+        const unsigned voff = m < M ? (unsigned)((m * (int)p.lda2 + lane_k) * 2) : OOB;
+        bdma16(rs_a2, sa + (wave + 8 * i) * 1024, voff, (kb - ksp) * 2);
+      }
     }
 #pragma unroll
     for (int i = 0; i < WG; ++i) {
-      const int k = kb + w_k[i];
-      const f16* src = (w_ok[i] && k < K) ? (W + w_off[i] + k) : zero;
-      glds16(src, sw + (wave + 8 * i) * 1024);
+      const bool in_tile = (WGT % 8 == 0) || (wave + 8 * i < WGT);   // wave-uniform
+      bdma16(rs_w, in_tile ? sw + (wave + 8 * i) * 1024 : smem + NS * STAGE, in_tile ? w_voff : OOB,
+             (RSTEP * i * (int)p.ldw + kb) * 2);
     }
   };
 
@@ -159,40 +182,80 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt_all = (K + 63) / 64;
+  const int nkt_all = (K + BK - 1) / BK;
   const int kt0 = SPLIT ? (int)blockIdx.y * kps : 0;
   const int nkt = SPLIT ? min(nkt_all, kt0 + kps) : nkt_all;
-  issue(kt0, 0);
-  for (int kt = kt0; kt < nkt; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < nkt) {
-      issue(kt + 1, cur ^ 1);       // stage cur^1 was last read in iteration kt-1, closed by its trailing barrier
-      wait_vmcnt<AG + WG>();        // everything older than the tile just issued (= tile kt) has landed
-    } else {
+#pragma unroll
+  for (int s = 0; s < LEAD; ++s)
+    if (kt0 + s < nkt) issue(kt0 + s, s);
+  auto sync_tile = [&](int kt) {
+    // tile kt has landed once at most the LEAD - 1 tiles issued after it are outstanding (in the tail fewer exist)
+    if (kt + LEAD - 1 < nkt)
+      wait_vmcnt<(LEAD - 1) * (AG + WG)>();
+    else
       wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();   // every wave's share of tile kt is in LDS
-
+    // one barrier per K tile: every wave's share of tile kt is in LDS, and every wave has finished reading tile
+    // kt - 1, whose stage is the one refilled next
+    __builtin_amdgcn_s_barrier();
+  };
+  auto prefetch = [&](int kt) {
+    if (kt + LEAD < nkt) issue(kt + LEAD, (kt - kt0 + LEAD) % NS);
+  };
+  auto read_frags = [&](int cur, int ks, f16x8 (&wf)[NI], f16x8 (&af)[MI]) {
     const char* sa = smem + cur * STAGE;
-    const char* sw = sa + BM * 128;
+    const char* sw = sa + BM * BK * 2;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 wf[NI], af[MI];
+    for (int i = 0; i < NI; ++i)
+      wf[i] = *reinterpret_cast<const f16x8*>(sw + big_lds_addr<BK>(wn * 80 + i * 16 + l15, ks * 4 + g));
 #pragma unroll
-      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const f16x8*>(sw + gemm_swz(wn * 80 + i * 16 + l15, ks * 4 + g));
+    for (int j = 0; j < MI; ++j)
+      af[j] = *reinterpret_cast<const f16x8*>(sa + big_lds_addr<BK>(wm * WM + j * 16 + l15, ks * 4 + g));
+  };
+  // D = W_frag * A_frag: lane owns 4 consecutive n of one row m.  For the transposed V^T store the operands are
+  // swapped (D = A_frag * W_frag): lane owns 4 consecutive m (keys) of one channel n = an 8-byte run of a V^T row.
+  auto mma = [&](const f16x8 (&wf)[NI], const f16x8 (&af)[MI]) {
 #pragma unroll
-      for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const f16x8*>(sa + gemm_swz(wm * WM + j * 16 + l15, ks * 4 + g));
-      // D = W_frag * A_frag: lane owns 4 consecutive n of one row m.  For the transposed V^T store the operands are
-      // swapped (D = A_frag * W_frag): lane owns 4 consecutive m (keys) of one channel n = an 8-byte run of a V^T row.
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+      for (int j = 0; j < MI; ++j)
+        acc[i][j] = (STORE == I2V_STORE_VT_T) ? mfma16x16x32(af[j], wf[i], acc[i][j])
+                                              : mfma16x16x32(wf[i], af[j], acc[i][j]);
+  };
+
+  // The two waves of a SIMD (wave w and w + 4: wm = 0 and wm = 1) run half a K tile out of phase: the wm = 1 group
+  // reads the fragments of a tile's last k-step BEFORE the tile barrier but issues their MFMAs AFTER it, i.e. while the
+  // wm = 0 group is reading the next tile's first fragments; from there on one wave's LDS reads coincide with the
+  // other's MFMAs for the whole tile, instead of both waves reading, then both computing.
+  if (!STAGGER || wm == 0) {
+    for (int kt = kt0; kt < nkt; ++kt) {
+      sync_tile(kt);
+      prefetch(kt);
+      const int cur = (kt - kt0) % NS;
 #pragma unroll
-        for (int j = 0; j < MI; ++j)
-          acc[i][j] = (STORE == I2V_STORE_VT_T) ? mfma16x16x32(af[j], wf[i], acc[i][j])
-                                                : mfma16x16x32(wf[i], af[j], acc[i][j]);
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        f16x8 wf[NI], af[MI];
+        read_frags(cur, ks, wf, af);
+        mma(wf, af);
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // all fragment reads of stage `cur` done before it is refilled
+  } else {
+    f16x8 pwf[NI], paf[MI];
+    for (int kt = kt0; kt < nkt; ++kt) {
+      sync_tile(kt);
+      const int cur = (kt - kt0) % NS;
+      if (kt > kt0) mma(pwf, paf);   // before the DMA address arithmetic: the pending fragments die here
+      prefetch(kt);
+#pragma unroll
+      for (int ks = 0; ks + 1 < KSTEPS; ++ks) {
+        f16x8 wf[NI], af[MI];
+        read_frags(cur, ks, wf, af);
+        mma(wf, af);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // strict read / MFMA phases: the overlap comes from the partner wave
+      read_frags(cur, KSTEPS - 1, pwf, paf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads have left LDS before the stage can be refilled
+    }
+    if (nkt > kt0) mma(pwf, paf);
   }
 
   // ---------------------------------------------------------------- epilogue (lane: row m, 4 consecutive n)
@@ -289,34 +352,41 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   });
 }
 
-template <int BM, int AMODE>
+template <int BM, int BK, int NS, int AMODE>
 int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BIG_BN;
   const dim3 grid(tiles_m * tiles_n), block(512);
   if (p.epilogue == I2V_EPI_GEGLU) {
     if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p, tiles_n, 0);
+      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p,
+                         tiles_n, 0);
   } else if (p.store_mode == I2V_STORE_ROWPERM) {
     if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_ROWPERM>), grid, block, 0, s, p, tiles_n, 0);
+      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWPERM>), grid, block, 0, s, p,
+                         tiles_n, 0);
   } else if (p.store_mode == I2V_STORE_VT) {
     if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_VT>), grid, block, 0, s, p, tiles_n, 0);
+      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_VT>), grid, block, 0, s, p, tiles_n,
+                         0);
   } else if (p.store_mode == I2V_STORE_VT_T) {
     if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_VT_T>), grid, block, 0, s, p, tiles_n, 0);
+      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_VT_T>), grid, block, 0, s, p,
+                         tiles_n, 0);
   } else {
-    hipLaunchKernelGGL((gemm_big_kernel<BM, AMODE, I2V_EPI_NONE, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p, tiles_n, 0);
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p,
+                       tiles_n, 0);
   }
   const int rc = i2v_check_launch("i2v_gemm_f16(big)");
   return rc < 0 ? rc : 1;
 }
 
+// Pipeline shape: two 64-deep stages.  Four 32-deep stages (three tiles in flight, <BM, 32, 4, ...>) measured 5-12 %
+// slower on every shape of the step (profiles/r1_tile_sweep.txt): the loop is not bound by DMA latency.
 template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   (void)vec4;
-  if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, I2V_A_CONV3X3>(p, s);
-  return launch_big_mode<BM, I2V_A_PLAIN>(p, s);
+  if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, 64, 2, I2V_A_CONV3X3>(p, s);
+  return launch_big_mode<BM, 64, 2, I2V_A_PLAIN>(p, s);
 }
 
 // ---- split-K: sum the fp32 partial tiles and apply the fused epilogue (bias / time-embedding vector / residual)
@@ -356,10 +426,10 @@ int launch_split(const i2v_gemm_params& p, int vec4, int splits, int kps, hipStr
   const int tiles_m = (int)i2v_cdiv(p.M, 128), tiles_n = p.N / BIG_BN;
   const dim3 grid(tiles_m * tiles_n, splits), block(512);
   if (p.a_mode == I2V_A_CONV3X3)
-    hipLaunchKernelGGL((gemm_big_kernel<128, I2V_A_CONV3X3, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
+    hipLaunchKernelGGL((gemm_big_kernel<128, 64, 2, I2V_A_CONV3X3, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
                        tiles_n, kps);
   else
-    hipLaunchKernelGGL((gemm_big_kernel<128, I2V_A_PLAIN, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
+    hipLaunchKernelGGL((gemm_big_kernel<128, 64, 2, I2V_A_PLAIN, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
                        tiles_n, kps);
   const int64_t groups = (int64_t)p.M * (p.N / 4);
   const int blocks = (int)(i2v_cdiv(groups, 256) < 2048 ? i2v_cdiv(groups, 256) : 2048);
@@ -381,6 +451,15 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   static const int mode = getenv("I2V_GEMM_BIG") ? atoi(getenv("I2V_GEMM_BIG")) : -1;  // 0 off, 256 / 128 force
   if (mode == 0) return 0;
   if (p.N % BIG_BN != 0) return 0;
+  // the kernel addresses each operand through a buffer descriptor with 32-bit byte offsets (< 2 GiB per operand) and
+  // moves whole BK-deep K tiles (K, the concat split and the conv channel count must be multiples of 64)
+  if (p.K % 64 != 0 || (p.a2 != nullptr && p.k_split % 64 != 0)) return 0;
+  if ((int64_t)p.N * p.ldw >= (1ll << 30)) return 0;
+  if (p.a_mode == I2V_A_CONV3X3) {
+    if (p.cin % 64 != 0 || (int64_t)p.n_img * p.in_h * p.in_w * p.lda >= (1ll << 30)) return 0;
+  } else if ((int64_t)p.M * p.lda >= (1ll << 30) || (int64_t)p.M * p.lda2 >= (1ll << 30)) {
+    return 0;
+  }
   // the specialised epilogue handles the vector (8-byte) forms only; anything else stays on the generic kernel
   if (!vec4 || p.epilogue == I2V_EPI_GELU) return 0;
   if (p.a_mode == I2V_A_CONV3X3 && (p.epilogue != I2V_EPI_NONE || p.store_mode != I2V_STORE_ROWMAJOR)) return 0;
