@@ -1,6 +1,7 @@
 // Large-tile MFMA GEMM / implicit-GEMM conv for gfx950: BM x 320 x 64 tiles, 8 waves (2 x 4, per-wave (BM/2) x 80),
-// operands staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS with no VGPR / ds_write pass), two LDS stages,
-// the next K tile's DMA in flight under the current tile's MFMAs behind a counted vmcnt and raw s_barriers.
+// operands staged by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS with no VGPR / ds_write pass), two LDS stages,
+// the next K tile's DMA in flight under the current tile's MFMAs, one raw s_barrier per K tile, and the two waves of
+// each SIMD running half a K tile out of phase so that one wave's LDS reads overlap the other's MFMAs.
 //
 // Why this shape (measured in round 1, profiles/r1_tile_sweep.txt): the 128-wide register-staged kernel of gemm.hip is
 // bound by the LDS write path (ds_write_b128 ~79 B/clk/CU) and by L2->CU operand bandwidth (43-65 FLOP/B per tile vs
@@ -10,7 +11,8 @@
 // LDS image: rows of 128 B, chunk c of row r at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 fragments).  LDS-DMA
 // writes lane-linearly (wave base + 16 * lane), so the swizzle is applied on the SOURCE side: lane l of the
 // instruction for 8-row group j fetches logical chunk (l & 7) ^ ((row >> 1) & 7) of row 8 j + (l >> 3) (guide rule 21).
-// Masked lanes (row >= M, k >= K, conv halo) fetch from a zero page instead, because LDS-DMA cannot skip a lane.
+// Masked lanes (row >= M, conv halo) carry an out-of-range buffer offset: LDS-DMA cannot skip a lane, but the
+// descriptor's range check makes it write zeros.
 #include <cstdlib>
 #include <utility>
 
@@ -472,11 +474,11 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   if (p.a_mode != I2V_A_CONV3X3 && p.K < min_k) return 0;   // a single K tile cannot hide its own DMA latency
   // one 8-wave block per CU: a tile count just above a multiple of 256 wastes most of the last round.  Pick the
   // tile height by (fill of the last round) x (measured relative rate: 256-row 1.0, 128-row 0.82,
-  // profiles/r1_tile_sweep.txt); below 45 % the 3-blocks-per-CU kernel of gemm.hip is faster.
+  // profiles/r1_tile_sweep.txt); below 40 % the 3-blocks-per-CU kernel of gemm.hip is faster.
   const double e256 = (double)t256 / (double)(i2v_cdiv(t256, 256) * 256);
   const double e128 = 0.82 * (double)t128 / (double)(i2v_cdiv(t128, 256) * 256);
-  if (e256 >= e128 && e256 >= 0.45) return launch_big<256>(p, vec4, s);
-  if (e128 >= 0.45) return launch_big<128>(p, vec4, s);
+  if (e256 >= e128 && e256 >= 0.40) return launch_big<256>(p, vec4, s);
+  if (e128 >= 0.40) return launch_big<128>(p, vec4, s);
   // too few output tiles for the chip: split K when the caller supplied the fp32 scratch
   int kps = 0;
   const int splits = splitk_plan(p, vec4, &kps);

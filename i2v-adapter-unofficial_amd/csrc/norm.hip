@@ -175,64 +175,74 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
-// one wave per row; the row lives in registers (NV 16-byte vectors per lane) so the variance is an exact
-// second pass over registers.
-template <int NV>
+// one wave per R consecutive rows; the rows live in registers (NV 16-byte vectors per lane and row) so the variance
+// is an exact second pass over registers.  R > 1 is memory-level parallelism: a 320-channel row is one 640-byte load
+// per wave, and with one row per wave a CU had ~20 KB in flight (3.2 TB/s measured); gamma / beta are read once per wave.
+template <int NV, int R>
 __global__ __launch_bounds__(256) void ln_kernel(const i2v_ln_params p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= p.rows) return;
+  const int row0 = (blockIdx.x * 4 + wave) * R;
+  if (row0 >= p.rows) return;
   const int nvec = p.C / 8;
-  const f16* x = reinterpret_cast<const f16*>(p.x) + (int64_t)row * p.ldx;
-  float v[NV][8];
-  float s = 0.f;
+  const f16* x = reinterpret_cast<const f16*>(p.x);
+  float v[R][NV][8];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int vi = lane + 64 * i;
-    if (vi < nvec) {
-      const f16x8 t = ld_global_16B(x + vi * 8);
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+    const bool live = row0 + r < p.rows;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[i][e] = (float)t[e];
-        s += v[i][e];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-    }
-  }
-  const float mean = wave_sum(s) / (float)p.C;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    if (lane + 64 * i < nvec) {
+    for (int i = 0; i < NV; ++i) {
+      const int vi = lane + 64 * i;
+      f16x8 t = zero8();
+      if (live && vi < nvec) t = ld_global_16B(x + (int64_t)(row0 + r) * p.ldx + vi * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float d = v[i][e] - mean;
-        q += d * d;
+        v[r][i][e] = (float)t[e];
+        s[r] += v[r][i][e];
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+  float mean[R], rstd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    mean[r] = wave_sum(s[r]) / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + 64 * i < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[r][i][e] - mean[r];
+          q += d * d;
+        }
+      }
+    }
+    rstd[r] = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+  }
   const f16* gamma = reinterpret_cast<const f16*>(p.gamma);
   const f16* beta = reinterpret_cast<const f16*>(p.beta);
-  const f16* pe = p.pe ? reinterpret_cast<const f16*>(p.pe) + (int64_t)(row % p.pe_period) * p.ld_pe : nullptr;
-  f16* y = reinterpret_cast<f16*>(p.y) + (int64_t)row * p.ldy;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int vi = lane + 64 * i;
     if (vi < nvec) {
       const f16x8 ga = ld_global_16B(gamma + vi * 8), be = ld_global_16B(beta + vi * 8);
-      f16x8 pv = zero8();
-      if (pe) pv = ld_global_16B(pe + vi * 8);
-      f16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float r = (v[i][e] - mean) * rstd * (float)ga[e] + (float)be[e];
-        if (pe) r += (float)pv[e];
-        o[e] = (f16)r;
+      for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row < p.rows) {
+          f16x8 pv = zero8();
+          if (p.pe) pv = ld_global_16B(reinterpret_cast<const f16*>(p.pe) + (int64_t)(row % p.pe_period) * p.ld_pe + vi * 8);
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = (v[r][i][e] - mean[r]) * rstd[r] * (float)ga[e] + (float)be[e];
+            if (p.pe) t += (float)pv[e];
+            o[e] = (f16)t;
+          }
+          *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.y) + (int64_t)row * p.ldy + vi * 8) = o;
+        }
       }
-      *reinterpret_cast<f16x8*>(y + vi * 8) = o;
     }
   }
 }
@@ -290,17 +300,18 @@ extern "C" int i2v_layernorm_f16(const i2v_ln_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(al16(p.x) && al16(p.y) && al16(p.gamma) && al16(p.beta), "i2v_layernorm_f16: 16-byte alignment");
   if (p.pe) I2V_CHECK_ARG(p.pe_period > 0 && p.ld_pe % 8 == 0 && al16(p.pe), "i2v_layernorm_f16: bad pe arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)i2v_cdiv(p.rows, 4)), block(256);
+  const dim3 block(256);
   const int nv = (int)i2v_cdiv(p.C / 8, 64);
+  // rows per wave: 4 for C <= 512, 2 up to 1536, then 1 (the rows must fit the register file)
   switch (nv) {
-    case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL(ln_kernel<2>, grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL(ln_kernel<3>, grid, block, 0, s, p); break;
-    case 4: hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, p); break;
-    case 5: hipLaunchKernelGGL(ln_kernel<5>, grid, block, 0, s, p); break;
-    case 6: hipLaunchKernelGGL(ln_kernel<6>, grid, block, 0, s, p); break;
-    case 7: hipLaunchKernelGGL(ln_kernel<7>, grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL(ln_kernel<8>, grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((ln_kernel<1, 4>), dim3((unsigned)i2v_cdiv(p.rows, 16)), block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((ln_kernel<2, 2>), dim3((unsigned)i2v_cdiv(p.rows, 8)), block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((ln_kernel<3, 2>), dim3((unsigned)i2v_cdiv(p.rows, 8)), block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((ln_kernel<4, 1>), dim3((unsigned)i2v_cdiv(p.rows, 4)), block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((ln_kernel<5, 1>), dim3((unsigned)i2v_cdiv(p.rows, 4)), block, 0, s, p); break;
+    case 6: hipLaunchKernelGGL((ln_kernel<6, 1>), dim3((unsigned)i2v_cdiv(p.rows, 4)), block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL((ln_kernel<7, 1>), dim3((unsigned)i2v_cdiv(p.rows, 4)), block, 0, s, p); break;
+    default: hipLaunchKernelGGL((ln_kernel<8, 1>), dim3((unsigned)i2v_cdiv(p.rows, 4)), block, 0, s, p); break;
   }
   return i2v_check_launch("i2v_layernorm_f16");
 }

@@ -30,6 +30,14 @@ __global__ __launch_bounds__(256) void tattn_kernel(const i2v_tattn_params p, co
     const f16* K = Kb + (int64_t)pix * F * p.k_row_stride + h * d;
     const f16* Vt = Vb + ((int64_t)pix * C + h * d) * p.vt_ld;
 
+    // V^T does not depend on the softmax: its loads are issued with the Q / K loads, one memory round trip per item
+    f16x8 vfr[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int ch = i * 16 + l15;
+      vfr[i] = (ch < d && 8 * g < F) ? ld_global_16B(Vt + (int64_t)ch * p.vt_ld + 8 * g) : zero8();
+    }
+
     f32x4 sacc[2][NQT];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -94,15 +102,11 @@ __global__ __launch_bounds__(256) void tattn_kernel(const i2v_tattn_params p, co
 
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
-      const int ch = i * 16 + l15;
-      f16x8 vf = zero8();
-      if (ch < d && 8 * g < F) {
-        vf = ld_global_16B(Vt + (int64_t)ch * p.vt_ld + 8 * g);
-        if (8 * g + 8 > F) {
+      f16x8 vf = vfr[i];
+      if (8 * g + 8 > F) {   // frames past F inside the last 16-byte run: padding, not data
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (8 * g + e >= F) vf[e] = (f16)0.f;
-        }
+        for (int e = 0; e < 8; ++e)
+          if (8 * g + e >= F) vf[e] = (f16)0.f;
       }
 #pragma unroll
       for (int j = 0; j < NQT; ++j) {
