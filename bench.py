@@ -217,6 +217,16 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom, "achieved": d["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": d["gbps"] / HBM_PEAK_GBPS, "traffic": None, "launches": d["calls"],
                         "avg_launch_us": d["ms"] * 1e3 / d["calls"], "bytes_per_launch": d["bytes"] / d["calls"]}
+            # HBM-side bytes per launch of that class: PMC counters cannot be read from inside the process, so this
+            # is the committed result of the separate rocprofv3 --pmc passes over this same command
+            # (tools/pmc_traffic.sh -> profiles/r1_traffic.json), valid for the default workload only
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
+            if os.path.exists(tpath) and args.frames == 16 and args.size == 512:
+                with open(tpath) as f:
+                    tcls = json.load(f).get("classes", {})
+                if dom in tcls:
+                    roof["traffic"] = tcls[dom]["bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
     used_graph = graph is not None
     graph = None
