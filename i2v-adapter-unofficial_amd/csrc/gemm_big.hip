@@ -59,7 +59,8 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
 }
 
 template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BM == 128 && BK == 32 ? 4 : 1)))
+void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) {
   constexpr int BN = BIG_BN;
   constexpr int WM = BM / 2, MI = WM / 16, NI = 5;
   constexpr int AG = BM * BK / 4096;        // 1 KiB (8-unit) A groups per wave: BM * BK * 2 / 1024 groups over 8 waves
@@ -308,6 +309,83 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     constexpr int i = decltype(ic)::value;
     b4[i] = bias ? *reinterpret_cast<const f16x4*>(bias + ncol0 + i * 16) : f16x4{0, 0, 0, 0};
   });
+  if ((STORE == I2V_STORE_ROWMAJOR || STORE == I2V_STORE_ROWPERM) && (EPI != I2V_EPI_GEGLU || (!rowvec && !resid))) {
+    // Row-contiguous stores through LDS.  In the accumulator layout a store (or residual load) instruction touches 16
+    // rows x 32 bytes; with 40 of each per wave the tile's epilogue was bound by the address/line rate of the memory
+    // pipe (a K = 320 tile spent ~2/3 of its time here: 3.5 TB/s for a GEMM that an elementwise add of the same
+    // bytes does at 6.2).  Each wave therefore transposes its 16 x 80 fp32 block through a private LDS slab (no
+    // barrier beyond the one that retires the K loop's stages; LDS executes one wave's operations in order) and
+    // re-reads it so that a lane owns 8 consecutive columns of one row: 16-byte residual / time-embedding loads and
+    // stores, 160 contiguous bytes per row, half the instructions.  Rounding is unchanged (fp32 until the final cast).
+    constexpr int OC = EPI == I2V_EPI_GEGLU ? 40 : 80;   // output columns per wave
+    constexpr int LDS_LD = OC + 4;                        // floats; 84 / 44: 16 rows start on 16 distinct bank groups
+    constexpr int TPR = OC / 8, NT = 16 * TPR;            // 8-column tasks per row / per 16-row block
+    __builtin_amdgcn_s_barrier();                         // every wave has left the K loop: the stages are free
+    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * LDS_LD);
+    const int out_col0 = EPI == I2V_EPI_GEGLU ? (n0 >> 1) + wn * 40 : n0 + wn * 80;
+    // bias (and the GEGLU gate, in place: registers 0 / 1 of each accumulator become the two outputs) first, as a
+    // pure register pass: fused with the staging below, the GELU temporaries pushed accumulators into scratch
+    static_for<MI>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      static_for<NI>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)b4[i][r];
+        if (EPI == I2V_EPI_GEGLU) {
+          acc[i][j][0] = acc[i][j][0] * gelu_erf(acc[i][j][1]) * oscale;
+          acc[i][j][1] = acc[i][j][2] * gelu_erf(acc[i][j][3]) * oscale;
+        }
+      });
+    });
+    static_for<MI>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      static_for<NI>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (EPI == I2V_EPI_GEGLU)
+          *reinterpret_cast<float2*>(stg + l15 * LDS_LD + i * 8 + 2 * g) = float2{acc[i][j][0], acc[i][j][1]};
+        else
+          *reinterpret_cast<f32x4*>(stg + l15 * LDS_LD + i * 16 + 4 * g) = acc[i][j];
+      });
+#pragma unroll
+      for (int q = 0; q < (NT + 63) / 64; ++q) {
+        const int t = lane + 64 * q;
+        const int row = t / TPR, c = t - row * TPR;
+        const int m = m0 + wm * WM + j * 16 + row;
+        if (t < NT && m < M) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          int64_t m_out = m;
+          if (STORE == I2V_STORE_ROWPERM) {
+            const int per = p.hw * p.frames;
+            const int b = m / per, rem = m - b * per;
+            const int pix = rem / p.frames, f = rem - pix * p.frames;
+            m_out = (int64_t)(b * p.frames + f) * p.hw + pix;
+          }
+          const int n = out_col0 + c * 8;
+          if (EPI != I2V_EPI_GEGLU) {
+            if (rowvec) {
+              const f16x8 t8 = ld_global_16B(rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec + n);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)t8[e];
+            }
+            if (resid) {
+              const f16x8 r8 = ld_global_16B(resid + m_out * p.ldr + n);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= oscale;
+          }
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+          *reinterpret_cast<f16x8*>(C + m_out * p.ldc + n) = o;
+        }
+      }
+    });
+    return;
+  }
   static_for<MI>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const int m = m0 + wm * WM + j * 16 + l15;
@@ -388,6 +466,8 @@ template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   (void)vec4;
   if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, 64, 2, I2V_A_CONV3X3>(p, s);
+  static const int bk32 = getenv("I2V_GEMM_BK32") ? atoi(getenv("I2V_GEMM_BK32")) : 0;
+  if (bk32 && BM == 128) return launch_big_mode<128, 32, 2, I2V_A_PLAIN>(p, s);
   return launch_big_mode<BM, 64, 2, I2V_A_PLAIN>(p, s);
 }
 
@@ -466,6 +546,13 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   if (!vec4 || p.epilogue == I2V_EPI_GELU) return 0;
   if (p.a_mode == I2V_A_CONV3X3 && (p.epilogue != I2V_EPI_NONE || p.store_mode != I2V_STORE_ROWMAJOR)) return 0;
   if (p.epilogue == I2V_EPI_GEGLU && p.store_mode != I2V_STORE_ROWMAJOR) return 0;
+  if (p.store_mode == I2V_STORE_ROWMAJOR || p.store_mode == I2V_STORE_ROWPERM) {
+    // the row-contiguous epilogue moves 16 bytes per lane
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (p.ldc % 8 != 0 || !a16(p.c)) return 0;
+    if (p.residual && (p.ldr % 8 != 0 || !a16(p.residual))) return 0;
+    if (p.rowvec && (p.ld_rowvec % 8 != 0 || !a16(p.rowvec))) return 0;
+  }
   const int64_t tn = p.N / BIG_BN;
   const int64_t t256 = i2v_cdiv(p.M, 256) * tn, t128 = i2v_cdiv(p.M, 128) * tn;
   if (mode == 256) return launch_big<256>(p, vec4, s);
