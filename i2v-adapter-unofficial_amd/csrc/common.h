@@ -43,13 +43,17 @@ __device__ __forceinline__ f32x4 mfma16x16x32(f16x8 a, f16x8 b, f32x4 c) {
 
 // erf GELU: 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the fp16
 // output rounding): one v_rcp, one v_exp and five FMAs instead of libm erff's ~40 instructions in the GEMM epilogue.
+// Arranged as gelu(x) = max(x, 0) - |x| h(|x|) with h = 0.5 erfc(|x| / sqrt 2) = 0.5 poly(t) exp(-x^2 / 2): the
+// constants (1/sqrt 2 into p, 0.5 into the coefficients, log2 e / 2 into the exp2 argument) are folded, |x| and the
+// negations are free source modifiers, and there is no sign select: 11 plain VALU + rcp + exp2 per value (the GEGLU
+// epilogue of a K = 320 GEMM spends as long in this function as in its MFMAs).
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly =
-      t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float poly = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
+  const float y = x * 0.84932180028801904272f;            // sqrt(log2(e) / 2): exp(-x^2 / 2) = exp2(-y^2)
+  const float h = poly * __builtin_amdgcn_exp2f(-(y * y));
+  return fmaf(-ax, h, fmaxf(x, 0.0f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -284,8 +284,46 @@ void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) 
     });
     return;
   }
+  if (STORE == I2V_STORE_VT_T && p.vt_len % 8 == 0 && M % 8 == 0 && p.vt_ld % 8 == 0 &&
+      (reinterpret_cast<uintptr_t>(p.c) & 15) == 0) {
+    // accumulator rows = m (4 g + r), column = n (l15): element (m, n) -> C[((m / L) * N + n) * ld + m % L].
+    // Through LDS like the row-major stores: per 16-channel block the wave's [16 channels][WM keys] fp32 slab is
+    // re-read so that a lane owns 8 consecutive keys of one channel: 16-byte stores, WM * 2 contiguous bytes per V^T row
+    // (the direct form stores 16 rows x 32 bytes per instruction).
+    constexpr int LDS_LD = WM + 4;   // floats: 16 rows start on 16 distinct bank groups
+    constexpr int TPR = WM / 8, NT = 16 * TPR;
+    __builtin_amdgcn_s_barrier();    // every wave has left the K loop: the stages are free
+    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * LDS_LD);
+    static_for<NI>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<MI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        *reinterpret_cast<f32x4*>(stg + l15 * LDS_LD + j * 16 + 4 * g) = acc[i][j];
+      });
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) {
+        const int t = lane + 64 * q;
+        const int row = t / TPR, c = t - row * TPR;
+        const int n = n0 + wn * 80 + i * 16 + row;
+        const int m = m0 + wm * WM + c * 8;
+        if (m < M) {   // M % 8 == 0 and vt_len % 8 == 0: the 8 keys are in range and in one batch
+          const float bn = bias ? (float)bias[n] : 0.f;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
+          const int bt = m / p.vt_len, kk = m - bt * p.vt_len;
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (f16)((lo[e] + bn) * oscale);
+            o[4 + e] = (f16)((hi[e] + bn) * oscale);
+          }
+          *reinterpret_cast<f16x8*>(C + ((int64_t)bt * N + n) * p.vt_ld + kk) = o;
+        }
+      }
+    });
+    return;
+  }
   if (STORE == I2V_STORE_VT_T) {
-    // accumulator rows = m (4 g + r), column = n (l15): element (m, n) -> C[((m / L) * N + n) * ld + m % L]
     static_for<NI>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const int n = n0 + wn * 80 + i * 16 + l15;

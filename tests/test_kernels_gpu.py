@@ -53,7 +53,9 @@ def test_gemm_plain(dev, M, N, K_):
 
 @pytest.mark.parametrize("M,N,K_,kind", [
     (49152, 320, 320, "plain"), (49152, 640, 136, "plain"), (16384, 320, 640, "plain"), (16500, 320, 200, "plain"),
-    (49152, 640, 64, "geglu"), (16384, 320, 64, "rowperm"), (49152, 320, 128, "dual"), (320, 40960, 64, "vt")])
+    (49152, 640, 64, "geglu"), (16384, 320, 64, "rowperm"), (49152, 320, 128, "dual"), (320, 40960, 64, "vt"),
+    # M tails through the LDS-staged row-contiguous epilogue (K % 64 == 0 keeps them on the 8-wave kernel)
+    (16500, 320, 192, "plain"), (33000, 640, 128, "geglu"), (16416, 320, 128, "rowperm"), (40000, 960, 320, "plain")])
 def test_gemm_big_tiles(dev, M, N, K_, kind):
     """shapes that take the 8-wave LDS-DMA kernel (N % 320 == 0, >= 128 tiles): 256- and 128-row tiles, M / K tails,
     every epilogue / store mode."""
