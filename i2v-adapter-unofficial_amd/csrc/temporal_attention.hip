@@ -9,6 +9,8 @@
 // softmax over the keys with two wavefront shuffles, O^T = V^T P^T with one 16x16x32 MFMA per 16 channels
 // (the S^T accumulator is the B operand; key rows are permuted as in attention.hip so that a lane's 8 keys are
 // one contiguous 16-byte run of a V^T row).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -121,9 +123,128 @@ __global__ __launch_bounds__(256) void tattn_kernel(const i2v_tattn_params p, co
   }
 }
 
+// Narrow-channel variant (C <= 640, frames <= 16: the 64 x 64 and 32 x 32 levels).  With head_dim 40 a head's slice of
+// a token row is 80 bytes, so the per-wave fragment loads above touch 16 rows x 64-80 bytes per instruction and the
+// kernel ran at 3.4 TB/s.  Here one workgroup owns ONE pixel with all its heads: the pixel's q / k rows ([F][C],
+// whole rows) and V^T block ([C][vt_ld], contiguous) are copied to LDS with 16 bytes per lane over whole rows, the
+// waves take their heads' fragments from LDS (row strides padded so the 16 rows of a fragment read start on distinct
+// bank groups), and O goes back through LDS for whole-row 16-byte stores.
+template <int DQK, int DPV>
+__global__ __launch_bounds__(256) void tattn_lds_kernel(const i2v_tattn_params p, const float scale_log2) {
+  constexpr int KSTEPS = DQK / 32, DT = DPV / 16;
+  extern __shared__ __attribute__((aligned(16))) f16 tsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int F = p.frames, d = p.head_dim, C = p.heads * p.head_dim;
+  const int RS = C + 8, VS = p.vt_ld + 8;          // padded LDS row strides (halfs)
+  f16* sq = tsm;
+  f16* sk = sq + 16 * RS;
+  f16* so = sk + 16 * RS;
+  f16* sv = so + 16 * RS;
+  const int cpr = C / 8, vpr = p.vt_ld / 8;         // 16-byte chunks per row
+  const f16* __restrict__ Qb = reinterpret_cast<const f16*>(p.q);
+  const f16* __restrict__ Kb = reinterpret_cast<const f16*>(p.k);
+  const f16* __restrict__ Vb = reinterpret_cast<const f16*>(p.vt);
+  f16* __restrict__ Ob = reinterpret_cast<f16*>(p.o);
+
+  for (int pix = blockIdx.x; pix < p.n_pixels; pix += gridDim.x) {
+    for (int t = tid; t < F * cpr; t += 256) {
+      const int f = t / cpr, c = t - f * cpr;
+      *reinterpret_cast<f16x8*>(sq + f * RS + c * 8) = ld_global_16B(Qb + ((int64_t)pix * F + f) * p.q_row_stride + c * 8);
+      *reinterpret_cast<f16x8*>(sk + f * RS + c * 8) = ld_global_16B(Kb + ((int64_t)pix * F + f) * p.k_row_stride + c * 8);
+    }
+    for (int t = tid; t < C * vpr; t += 256) {
+      const int ch = t / vpr, c = t - ch * vpr;
+      *reinterpret_cast<f16x8*>(sv + ch * VS + c * 8) = ld_global_16B(Vb + ((int64_t)pix * C + ch) * p.vt_ld + c * 8);
+    }
+    __syncthreads();
+
+    for (int h = wave; h < p.heads; h += 4) {
+      f32x4 sacc[2];
+      sacc[0] = sacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int dd = 32 * s + 8 * g;
+        const bool in = dd < d;
+        const f16x8 qf = (l15 < F && in) ? *reinterpret_cast<const f16x8*>(sq + l15 * RS + h * d + dd) : zero8();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const int f = 8 * (l15 >> 2) + 4 * kt + (l15 & 3);
+          const f16x8 kf = (f < F && in) ? *reinterpret_cast<const f16x8*>(sk + f * RS + h * d + dd) : zero8();
+          sacc[kt] = mfma16x16x32(kf, qf, sacc[kt]);
+        }
+      }
+      float sv8[2][4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 8 * g + 4 * kt + r;
+          const float v = key < F ? sacc[kt][r] * scale_log2 : -INFINITY;
+          sv8[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv8[kt][r] = __builtin_amdgcn_exp2f(sv8[kt][r] - mx);
+          ls += sv8[kt][r];
+        }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      const float inv = 1.0f / ls;
+      f16x8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (f16)(sv8[0][r] * inv);
+        pf[4 + r] = (f16)(sv8[1][r] * inv);
+      }
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const int ch = i * 16 + l15;
+        f16x8 vf = (ch < d && 8 * g < F) ? *reinterpret_cast<const f16x8*>(sv + (h * d + ch) * VS + 8 * g) : zero8();
+        if (8 * g + 8 > F) {   // frames past F inside the last 16-byte run: padding, not data
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (8 * g + e >= F) vf[e] = (f16)0.f;
+        }
+        const f32x4 oacc = mfma16x16x32(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f});
+        const int dd = i * 16 + 4 * g;
+        if (l15 < F && dd < d) {
+          const f16x4 ov = {(f16)oacc[0], (f16)oacc[1], (f16)oacc[2], (f16)oacc[3]};
+          *reinterpret_cast<f16x4*>(so + l15 * RS + h * d + dd) = ov;
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < F * cpr; t += 256) {
+      const int f = t / cpr, c = t - f * cpr;
+      *reinterpret_cast<f16x8*>(Ob + ((int64_t)pix * F + f) * p.o_row_stride + c * 8) =
+          *reinterpret_cast<const f16x8*>(so + f * RS + c * 8);
+    }
+    // the next iteration's first barrier orders these reads of `so` before its writes
+  }
+}
+
 template <int DQK, int DPV>
 int launch_t(const i2v_tattn_params& p, hipStream_t s) {
   const float scale_log2 = p.scale * 1.4426950408889634f;
+  const int C = p.heads * p.head_dim;
+  static const int lds_off = getenv("I2V_TATTN_LDS") ? (atoi(getenv("I2V_TATTN_LDS")) == 0) : 0;
+  if (!lds_off && p.frames <= 16 && C <= 640 && p.o_row_stride % 8 == 0 &&
+      (reinterpret_cast<uintptr_t>(p.o) & 15) == 0) {
+    const size_t lds = (size_t)(3 * 16 * (C + 8) + C * (p.vt_ld + 8)) * sizeof(f16);
+    if (lds <= 64 * 1024) {
+    int64_t blocks = p.n_pixels < 256 * 8 ? p.n_pixels : 256 * 8;
+    hipLaunchKernelGGL((tattn_lds_kernel<DQK, DPV>), dim3((unsigned)blocks), dim3(256), lds, s, p, scale_log2);
+    return i2v_check_launch("i2v_temporal_attention_f16");
+    }
+  }
   const int64_t items64 = (int64_t)p.n_pixels * p.heads;
   const int n_items = (int)items64;
   int64_t blocks = i2v_cdiv(items64, 4);

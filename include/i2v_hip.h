@@ -122,6 +122,10 @@ int64_t i2v_gemm_workspace_bytes(const i2v_gemm_params* p);
  *      (second call with accumulate = 1, acc_scale = ip scale)
  * V is passed TRANSPOSED: vt[b][h*d + i][key] (see I2V_STORE_VT), row stride vt_row_stride >= lk rounded
  * up to 8; entries past lk may hold garbage (they are masked in-kernel).  head_dim % 8 == 0, <= 160.
+ * One (batch, head) slice of K ((lk + 128) * k_row_stride elements) and of V^T (head_dim * vt_row_stride) must
+ * span less than 1 GiB (the kernel addresses them with 32-bit buffer offsets); larger inputs are rejected with
+ * I2V_ERR_INVALID_ARG.  Numerics: scale * log2(e) is folded into the fp16 Q fragments (one extra fp16
+ * rounding of Q), softmax in base 2 with fp32 accumulation, P rounded to fp16 for the PV product.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct i2v_attn_params {
   const void* q;  int64_t q_row_stride, q_batch_stride;
