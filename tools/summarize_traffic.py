@@ -15,7 +15,7 @@ def classify(name):
         return "conv3x3" if m.group(3) == "1" else "gemm"
     if "splitk_reduce" in name:
         return "splitk_reduce"
-    if "tattn_kernel" in name:
+    if "tattn" in name:
         return "temporal_attention"
     if "attn_kernel" in name:
         return "attention"
