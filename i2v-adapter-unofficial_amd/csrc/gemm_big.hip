@@ -59,8 +59,7 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
 }
 
 template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BM == 128 && BK == 32 ? 4 : 1)))
-void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) {
+__global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) {
   constexpr int BN = BIG_BN;
   constexpr int WM = BM / 2, MI = WM / 16, NI = 5;
   constexpr int AG = BM * BK / 4096;        // 1 KiB (8-unit) A groups per wave: BM * BK * 2 / 1024 groups over 8 waves
@@ -504,8 +503,6 @@ template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   (void)vec4;
   if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, 64, 2, I2V_A_CONV3X3>(p, s);
-  static const int bk32 = getenv("I2V_GEMM_BK32") ? atoi(getenv("I2V_GEMM_BK32")) : 0;
-  if (bk32 && BM == 128) return launch_big_mode<128, 32, 2, I2V_A_PLAIN>(p, s);
   return launch_big_mode<BM, 64, 2, I2V_A_PLAIN>(p, s);
 }
 
