@@ -15,6 +15,7 @@ from torch import nn
 
 from . import kernels as K
 from ._lib import (I2V_EPI_GEGLU, I2V_EPI_GELU, I2V_EPI_NONE, I2V_STORE_ROWPERM, HipLibraryError)
+from .checkpoint import PretrainedMixin
 
 f16 = torch.float16
 
@@ -276,7 +277,7 @@ class Attention(HipModule):
         vt = K.project_vt(ctx_text.view(-1, dc), p["wv"], lt)
         o = K.attention(q, k, vt, batch_q=batch_q, lq=lq, lk=lt, heads=self.heads, head_dim=self.dim_head,
                         kv_group=kv_group, scale=self.scale)
-        if ctx_ip is not None:
+        if ctx_ip is not None and self.ip_num_tokens:
             li = ctx_ip.shape[1]
             kip = K.gemm(ctx_ip.view(-1, dc), p["wk_ip"])
             vtip = K.project_vt(ctx_ip.view(-1, dc), p["wv_ip"], li)
@@ -367,12 +368,22 @@ class SinusoidalPositionalEmbedding(nn.Module):
 
     def __init__(self, embed_dim: int, max_seq_length: int = 32):
         super().__init__()
-        position = torch.arange(max_seq_length).unsqueeze(1)
-        div_term = torch.exp(torch.arange(0, embed_dim, 2) * (-math.log(10000.0) / embed_dim))
-        pe = torch.zeros(1, max_seq_length, embed_dim)
+        self.embed_dim, self.max_seq_length = embed_dim, max_seq_length
+        self.register_buffer("pe", self._table(embed_dim, max_seq_length))
+
+    @staticmethod
+    def _table(embed_dim, max_seq_length):
+        position = torch.arange(max_seq_length, device="cpu").unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, embed_dim, 2, device="cpu") * (-math.log(10000.0) / embed_dim))
+        pe = torch.zeros(1, max_seq_length, embed_dim, device="cpu")
         pe[0, :, 0::2] = torch.sin(position * div_term)
         pe[0, :, 1::2] = torch.cos(position * div_term)
-        self.register_buffer("pe", pe)
+        return pe
+
+    def reset_table_(self):
+        """recompute the table in place (modules materialised from the meta device hold garbage here)."""
+        with torch.no_grad():
+            self.pe.copy_(self._table(self.embed_dim, self.max_seq_length).to(self.pe.dtype))
 
 
 class TemporalTransformerBlock(HipModule):
@@ -592,8 +603,9 @@ class UpBlockMotion(nn.Module):
                            hidden_states.dtype)
 
 
-class MotionAdapter(nn.Module):
-    """Weight container with diffusers `MotionAdapter`'s state-dict layout (unet:1028-1036)."""
+class MotionAdapter(PretrainedMixin, nn.Module):
+    """Weight container with diffusers `MotionAdapter`'s state-dict layout (unet:1028-1036) and its
+    `save_pretrained` / `from_pretrained` files (pipe:734,745)."""
 
     def __init__(self, block_out_channels=(320, 640, 1280, 1280), motion_layers_per_block=2,
                  motion_mid_block_layers_per_block=1, motion_num_attention_heads=8, motion_norm_num_groups=32,

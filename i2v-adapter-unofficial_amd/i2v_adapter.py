@@ -17,6 +17,7 @@ from torch import nn
 
 from . import kernels as K
 from .blocks import (Attention, FeedForward, HipModule, _as_f16_matrix, from_tokens, to_tokens, w16)
+from .checkpoint import PretrainedMixin
 
 f16 = torch.float16
 
@@ -40,8 +41,9 @@ def get_block(out_channel, block_depth, num_attention_heads, transformer_layers_
     return block
 
 
-class I2VAdapterModule(nn.Module):
-    """i2v:49-93: the adapter checkpoint container (`down_blocks[].attentions[].transformer_blocks[].i2v_adapter`)."""
+class I2VAdapterModule(PretrainedMixin, nn.Module):
+    """i2v:49-93: the adapter checkpoint container (`down_blocks[].attentions[].transformer_blocks[].i2v_adapter`);
+    `save_pretrained` / `from_pretrained` as the reference's ModelMixin container (pipe:741, unet:1088)."""
 
     def __init__(self, block_depth, block_out_channels, num_attention_heads,
                  transformer_layers_per_block: int = 1, mid_block_depth: int = 1):

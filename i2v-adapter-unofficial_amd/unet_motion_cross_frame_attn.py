@@ -19,6 +19,7 @@ from ._lib import HipLibraryError
 from .blocks import (Attention, DownBlockMotion, Downsample2D, HipModule, ImageProjection, MotionAdapter,
                      ResnetBlock2D, TimestepEmbedding, Timesteps, UpBlockMotion, Upsample2D, _as_f16_matrix,
                      _motion, from_tokens, pack_conv3x3, to_tokens, w16)
+from .checkpoint import PretrainedMixin
 from .i2v_adapter import I2VAdapterModule, I2VAdapterTransformer2DModel
 
 f16 = torch.float16
@@ -272,7 +273,25 @@ class UNet3DConditionOutput:
         self.sample = sample
 
 
-class UNetMotionCrossFrameAttnModel(HipModule):
+class AttnProcessorHIP:
+    """What `attn_processors` reports for an Attention module: the reference holds diffusers processor objects
+    (`AttnProcessor2_0`, `IPAdapterAttnProcessor2_0(hidden_size, cross_attention_dim, num_tokens, scale)`,
+    unet:1258-1279); here the attention arithmetic is the HIP kernel and the processor is a descriptor of the
+    branch configuration (`num_tokens` = 0: plain attention; > 0: + decoupled image cross-attention)."""
+
+    def __init__(self, num_tokens: int = 0, scale: float = 1.0):
+        self.num_tokens, self.scale = num_tokens, scale
+
+    def __repr__(self):
+        if self.num_tokens:
+            return f"IPAdapterAttnProcessorHIP(num_tokens={self.num_tokens}, scale={self.scale})"
+        return "AttnProcessorHIP()"
+
+    def __eq__(self, other):
+        return isinstance(other, AttnProcessorHIP) and (self.num_tokens, self.scale) == (other.num_tokens, other.scale)
+
+
+class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
     """unet:696-1451."""
 
     def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
@@ -387,11 +406,6 @@ class UNetMotionCrossFrameAttnModel(HipModule):
         return next(self.parameters()).device
 
     @classmethod
-    def from_config(cls, config):
-        keys = set(inspect.signature(cls.__init__).parameters) - {"self"}
-        return cls(**{k: v for k, v in dict(config).items() if k in keys})
-
-    @classmethod
     def from_unet2d(cls, unet, motion_adapter, i2v_adapter: Optional[I2VAdapterModule] = None,
                     load_weights: bool = True):
         """unet:883-977."""
@@ -482,6 +496,52 @@ class UNetMotionCrossFrameAttnModel(HipModule):
                            use_motion_mid_block=self.config["use_motion_mid_block"])
         ma.load_state_dict(sd)
         return ma
+
+    def save_i2v_adapter_modules(self, save_directory: str, is_main_process: bool = True,
+                                 safe_serialization: bool = True, variant: Optional[str] = None,
+                                 push_to_hub: bool = False, **kwargs):
+        """unet:1080-1097."""
+        self.obtain_i2v_adapter_modules().save_pretrained(
+            save_directory=save_directory, is_main_process=is_main_process, safe_serialization=safe_serialization,
+            variant=variant, push_to_hub=push_to_hub, **kwargs)
+
+    def save_motion_modules(self, save_directory: str, is_main_process: bool = True,
+                            safe_serialization: bool = True, variant: Optional[str] = None,
+                            push_to_hub: bool = False, **kwargs) -> None:
+        """unet:1099-1116."""
+        self.obtain_motion_modules().save_pretrained(
+            save_directory=save_directory, is_main_process=is_main_process, safe_serialization=safe_serialization,
+            variant=variant, push_to_hub=push_to_hub, **kwargs)
+
+    @property
+    def attn_processors(self) -> Dict[str, AttnProcessorHIP]:
+        """unet:1118-1136: {"<module path>.processor": processor} for every Attention, in registration order."""
+        modules = dict(self.named_modules())
+        out = {}
+        for name in self.attn_processor_names():
+            a = modules[name[: -len(".processor")]]
+            out[name] = AttnProcessorHIP(a.ip_num_tokens, a.ip_scale)
+        return out
+
+    def set_attn_processor(self, processor, _remove_lora=False):
+        """unet:1138-1161.  Accepts one descriptor for all layers or a dict keyed like `attn_processors`.  A
+        descriptor can change the IP branch's scale or switch the branch off (num_tokens = 0); switching it ON
+        needs weights and goes through `_load_ip_adapter_weights`."""
+        names = self.attn_processor_names()
+        if isinstance(processor, dict) and len(processor) != len(names):
+            raise ValueError(
+                f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                f" number of attention layers: {len(names)}. Please make sure to pass {len(names)} processor classes.")
+        modules = dict(self.named_modules())
+        for name in names:
+            proc = processor[name] if isinstance(processor, dict) else processor
+            if not isinstance(proc, AttnProcessorHIP):
+                raise TypeError(f"{name}: expected an AttnProcessorHIP descriptor, got {type(proc).__name__}")
+            a = modules[name[: -len(".processor")]]
+            if proc.num_tokens and a.to_k_ip is None:
+                raise ValueError(f"{name}: the IP-Adapter branch has no weights; load them with "
+                                 "`_load_ip_adapter_weights` first")
+            a.ip_num_tokens, a.ip_scale = proc.num_tokens, proc.scale
 
     def attn_processor_names(self):
         """Enumeration order of the reference's `attn_processors` (unet:1118-1136): one entry per Attention,
@@ -630,7 +690,7 @@ class _Transformer2DSource(I2VAdapterTransformer2DModel):
             del blk.i2v_adapter
 
 
-class UNet2DConditionModel(nn.Module):
+class UNet2DConditionModel(PretrainedMixin, nn.Module):
     def __init__(self, sample_size=None, in_channels=4, out_channels=4,
                  down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
                                    "DownBlock2D"),

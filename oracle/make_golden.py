@@ -73,6 +73,64 @@ def ref_attention_goldens():
         print("wrote ref_attention_" + name, tuple(y.shape))
 
 
+def ref_block_goldens():
+    """More reference-authored code that imports without diffusers (round 2):
+    * `BasicTransformerBlock` (src/modules/attention.py:64-77): x = attn1(LN1(x)) + x; x = attn2(LN2(x), ctx) + x --
+      pins the LayerNorm -> attention -> residual COMPOSITION of the spatial block (i2v:444-445, 468-473, 501,
+      510-533) for both the oracle and the HIP block (their GEGLU feed-forward is switched off by zeroing ff.net.2);
+    * `positional_emb` (src/modules/util.py:4-8): sinusoid frequencies 1 / 10000^(2i / C), [sin | cos] order (the hot
+      path's Timesteps(flip_sin_to_cos=True) is [cos | sin], unet:763);
+    * `ResBlock` (src/modules/resnet.py:19-72): bias-free conv3x3 -> GroupNorm(8) (output captured before the GELU)
+      and the 1x1 `res_conv`: conv + GroupNorm kernels against a reference-authored composition."""
+    sys.path.insert(0, REFERENCE)
+    from src.modules.attention import BasicTransformerBlock
+    from src.modules.resnet import ResBlock
+    from src.modules.util import positional_emb
+    for name, (c, dctx, d, heads, batch, tokens, lctx) in {
+            "d40": (320, 768, 40, 8, 2, 96, 77), "d8": (64, 96, 8, 8, 3, 40, 7)}.items():
+        torch.manual_seed(1000 + c)
+        blk = BasicTransformerBlock(c, dctx, head_dim=d, num_heads=heads).eval()
+        with torch.no_grad():
+            for n, p in blk.named_parameters():
+                if "norm" in n:       # default LayerNorm affine is (1, 0): make it visible
+                    p.add_(0.2 * torch.randn(p.shape))
+                p.copy_(h(p))
+        g = torch.Generator().manual_seed(23)
+        x, ctx = h(torch.randn(batch, tokens, c, generator=g)), h(torch.randn(batch, lctx, dctx, generator=g))
+        with torch.no_grad():
+            y = blk(x, ctx)
+        t = {"x": x, "ctx": ctx, "y": y}
+        t.update({k: v.detach().clone() for k, v in blk.state_dict().items()})
+        save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(OUT, f"ref_transformer_block_{name}.safetensors"),
+                  metadata=dict(heads=str(heads), head_dim=str(d)))
+        print("wrote ref_transformer_block_" + name, tuple(y.shape))
+    tt = torch.tensor([[0.0], [1.0], [2.0], [16.0], [40.0], [481.0], [999.0]])
+    save_file({"t": tt, "emb320": positional_emb(tt, 320).contiguous(), "emb32": positional_emb(tt, 32).contiguous()},
+              os.path.join(OUT, "ref_positional_emb.safetensors"))
+    print("wrote ref_positional_emb")
+    torch.manual_seed(77)
+    rb = ResBlock(64, 128, 32, group_nums=8).eval()
+    with torch.no_grad():
+        for n, p in rb.named_parameters():
+            if n in ("conv1.1.weight", "conv1.1.bias"):
+                p.add_(0.2 * torch.randn(p.shape))
+            p.copy_(h(p))
+    cap = {}
+    rb.conv1[0].register_forward_hook(lambda m, a, o: cap.__setitem__("conv", o.detach()))
+    rb.conv1[1].register_forward_hook(lambda m, a, o: cap.__setitem__("gn", o.detach()))
+    g = torch.Generator().manual_seed(78)
+    x = h(torch.randn(3, 64, 12, 12, generator=g))
+    with torch.no_grad():
+        rb(x, h(torch.randn(3, 32, generator=g)))
+        res = rb.res_conv(x)
+    save_file({"x": x, "conv_w": rb.conv1[0].weight.detach().contiguous(), "gn_w": rb.conv1[1].weight.detach().contiguous(),
+               "gn_b": rb.conv1[1].bias.detach().contiguous(), "y_conv": cap["conv"].contiguous(),
+               "y_conv_gn": cap["gn"].contiguous(), "res_w": rb.res_conv.weight.detach().contiguous(),
+               "res_b": rb.res_conv.bias.detach().contiguous(), "y_res": res.contiguous()},
+              os.path.join(OUT, "ref_resblock_conv_gn.safetensors"), metadata=dict(groups="8", eps="1e-05"))
+    print("wrote ref_resblock_conv_gn")
+
+
 def oracle_goldens():
     from oracle.blocks import DDPMScheduler
     from oracle.i2v_adapter import I2VAdapterTransformerBlock
@@ -130,6 +188,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if os.path.isdir(REFERENCE):
         ref_attention_goldens()
+        ref_block_goldens()
     else:
         print("reference not present: keeping the committed ref_attention_* fixtures")
     oracle_goldens()

@@ -17,6 +17,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 REL_TOL_MODULE = 2e-2
+# SD-1.5 + AnimateDiff motion adapter + I2V-Adapter topology (unet:703-726 defaults with cross_attention_dim = 768):
+# the model bench.py times (BASELINE configs[1..4])
+SD15 = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+            layers_per_block=2, cross_attention_dim=768, num_attention_heads=8, norm_num_groups=32,
+            motion_num_attention_heads=8, motion_max_seq_length=32)
 SMALL_UNET = dict(block_out_channels=(32, 64, 128, 128), num_attention_heads=4, norm_num_groups=8,
                   cross_attention_dim=64, motion_num_attention_heads=4, motion_max_seq_length=32)
 
@@ -40,14 +45,27 @@ def randomize_adapter_out_(module, std=0.02, seed=99):
     return module
 
 
-def compare(got, ref, rel=REL_TOL_MODULE, name=""):
+def log_error(name, err, scale, bound, **extra):
+    """append one measured error to $I2V_PARITY_LOG (JSON lines): the source of the asserted bounds."""
+    path = os.environ.get("I2V_PARITY_LOG")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(name=name, err=err, max_ref=scale, rel=err / max(scale, 1e-30), bound=bound,
+                                    **extra)) + "\n")
+
+
+def compare(got, ref, rel=REL_TOL_MODULE, name="", abs_tol=None):
+    """max|got - ref| <= rel * max|ref|  (or <= abs_tol when given).  Returns (err, max|ref|)."""
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     assert torch.isfinite(got).all(), f"{name}: non-finite values"
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
-    assert err <= rel * scale, f"{name}: max abs err {err:.4e} > {rel} * max|ref| ({scale:.4e})"
+    bound = abs_tol if abs_tol is not None else rel * scale
+    log_error(name, err, scale, bound)
+    assert err <= bound, f"{name}: max abs err {err:.4e} > bound {bound:.4e} (max|ref| {scale:.4e})"
     return err, scale
 
 
@@ -99,6 +117,69 @@ def small_unet_inputs(b=2, f=4, hw=16, lt=7, clip_dim=48, seed=11):
                 timestep=torch.tensor([10, 500][:b] if b <= 2 else list(range(10, 10 + b))),
                 ctx=h(torch.randn(b, lt, SMALL_UNET["cross_attention_dim"], generator=g)),
                 image_embeds=h(torch.randn(b, clip_dim, generator=g)))
+
+
+def host_threads():
+    """oracle thread count: hosts that expose hundreds of hardware threads run the unfused fp32 graph several times
+    slower with all of them than with 16 (measured on the GPU box in round 1)."""
+    n = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    return n
+
+
+def sd15_ip_state_dict(unet, clip_dim=1024, seed=7):
+    """ip-adapter_sd15.bin layout for any UNet of this family: key ids 1, 3, ... in attn_processors
+    order (unet:1276-1279); fp16-representable values."""
+    g = torch.Generator().manual_seed(seed)
+    cross = unet.config["cross_attention_dim"]
+    r = lambda *shape, s=0.05: (torch.randn(*shape, generator=g) * s).half().float()
+    sd = {"image_proj": {"proj.weight": r(4 * cross, clip_dim, s=clip_dim ** -0.5), "proj.bias": r(4 * cross, s=0.1),
+                         "norm.weight": (1 + 0.1 * torch.randn(cross, generator=g)).half().float(),
+                         "norm.bias": r(cross, s=0.1)},
+          "ip_adapter": {}}
+    mods = dict(unet.named_modules())
+    names = [n for n in unet.attn_processor_names() if n.endswith("attn2.processor") and "motion_modules" not in n]
+    for i, n in enumerate(names):
+        a = mods[n[: -len(".processor")]]
+        sd["ip_adapter"][f"{2 * i + 1}.to_k_ip.weight"] = r(a.inner_dim, cross, s=cross ** -0.5)
+        sd["ip_adapter"][f"{2 * i + 1}.to_v_ip.weight"] = r(a.inner_dim, cross, s=cross ** -0.5)
+    return sd
+
+
+def hip_model_random(cls_kwargs, dev, seed=1234, norm_jitter=0.1, cls=None):
+    """HIP module materialised on the GPU (meta -> to_empty -> fp16) with synthetic weights drawn ON the device:
+    torch's default Linear / Conv law, jittered norm affines, adapter to_out ~ N(0, 0.02^2)."""
+    import i2v_adapter_unofficial_amd as pkg
+    from i2v_adapter_unofficial_amd.checkpoint import init_random_weights_
+    cls = cls or pkg.UNetMotionCrossFrameAttnModel
+    with torch.device("meta"):
+        m = cls(**cls_kwargs)
+    m = m.to_empty(device=dev).half()
+    init_random_weights_(m, seed=seed, norm_jitter=norm_jitter)
+    return m.eval()
+
+
+def oracle_from_hip(hip, oracle_cls, cls_kwargs):
+    """CPU oracle with exactly the HIP module's (fp16-representable) weights."""
+    with torch.device("meta"):
+        o = oracle_cls(**cls_kwargs)
+    o = o.to_empty(device="cpu").float()
+    sd = {k: v.detach().float().cpu() for k, v in hip.state_dict().items()
+          if "_ip." not in k and not k.startswith("encoder_hid_proj")}
+    o.load_state_dict(sd)
+    return o.eval()
+
+
+def full_width_pair(dev, seed=1234, ip=False):
+    """(oracle, HIP) SD-1.5-width UNetMotionCrossFrameAttnModel pair: the model bench.py times."""
+    from oracle.unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel as OracleUNet
+    hip = hip_model_random(SD15, dev, seed=seed)
+    ou = oracle_from_hip(hip, OracleUNet, SD15)
+    if ip:
+        ipsd = sd15_ip_state_dict(ou)
+        ou._load_ip_adapter_weights(ipsd)
+        hip._load_ip_adapter_weights(ipsd)
+    return ou, hip
 
 
 def smoke_check():

@@ -47,6 +47,49 @@ def test_hip_attention_vs_reference_golden(dev, path):
     compare(y, t["y"], rel=5e-3, name=os.path.basename(path))
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ref_transformer_block_*.safetensors"))))
+def test_hip_block_vs_reference_basic_transformer_block(dev, path):
+    """the HIP I2VAdapterTransformerBlock (adapter off, feed-forward zeroed) reproduces the reference-authored
+    BasicTransformerBlock (src/modules/attention.py:64-77) on its own weights: LN -> attn -> +x, LN -> cross-attn -> +x."""
+    import i2v_adapter_unofficial_amd as pkg
+    from tests.test_oracle import load_ref_block_into
+    t = load_file(path)
+    with safe_open(path, framework="pt") as f:
+        meta = f.metadata()
+    heads, d = int(meta["heads"]), int(meta["head_dim"])
+    torch.manual_seed(0)
+    blk = load_ref_block_into(pkg.I2VAdapterTransformerBlock(heads * d, heads, d, cross_attention_dim=t["ctx"].shape[-1]), t)
+    blk = blk.to(dev).half().eval()
+    y = blk(t["x"].half().to(dev), enable_cross_frame_attn=False, encoder_hidden_states=t["ctx"].half().to(dev))
+    compare(y, t["y"], rel=4e-3, name=os.path.basename(path))
+
+
+def test_hip_timestep_embedding_vs_reference_positional_emb(dev):
+    from i2v_adapter_unofficial_amd import kernels as K
+    t = load_file(os.path.join(GOLD, "ref_positional_emb.safetensors"))
+    for c in (320, 32):
+        e = K.timestep_embedding(t["t"][:, 0].contiguous().to(dev), c).float().cpu()
+        ref = torch.cat([t[f"emb{c}"][:, c // 2:], t[f"emb{c}"][:, : c // 2]], dim=1)      # [sin | cos] -> [cos | sin]
+        assert (e - ref).abs().max().item() <= 1.5e-3, (c, (e - ref).abs().max())           # fp16 output of |v| <= 1
+
+
+def test_hip_conv_groupnorm_vs_reference_resblock(dev):
+    """bias-free conv3x3 -> GroupNorm(8) and the 1x1 res_conv of the reference-authored ResBlock
+    (src/modules/resnet.py:19-72) through the HIP conv / GroupNorm / GEMM kernels."""
+    from i2v_adapter_unofficial_amd import kernels as K
+    from i2v_adapter_unofficial_amd.blocks import pack_conv3x3
+    t = load_file(os.path.join(GOLD, "ref_resblock_conv_gn.safetensors"))
+    x = K.nchw_to_tokens(t["x"].to(dev))
+    y = K.conv3x3(x, pack_conv3x3(t["conv_w"]).to(dev))
+    compare(K.tokens_to_nchw(y, dtype=torch.float32), t["y_conv"], rel=3e-3, name="ResBlock conv1[0]")
+    z = K.groupnorm(y, t["gn_w"].half().to(dev), t["gn_b"].half().to(dev), 8, 1e-5)
+    compare(K.tokens_to_nchw(z, dtype=torch.float32), t["y_conv_gn"], rel=4e-3, name="ResBlock conv1[0:2]")
+    co, ci = t["res_w"].shape[:2]
+    r = K.gemm(x.view(-1, ci), t["res_w"].reshape(co, ci).half().to(dev), t["res_b"].half().to(dev))
+    compare(K.tokens_to_nchw(r.view(x.shape[0], x.shape[1], x.shape[2], co), dtype=torch.float32), t["y_res"], rel=3e-3,
+            name="ResBlock res_conv")
+
+
 def test_hip_unet_vs_committed_oracle_outputs(dev):
     gold = load_file(os.path.join(GOLD, "oracle_outputs.safetensors"))
     ou = oracle_small_unet()

@@ -94,3 +94,64 @@ def test_shard_range_partitions_everything():
     assert shard_items(list(range(64)), 3, 8) == list(range(24, 32))          # config 4: 64 pairs, 8 per GPU
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_checkpoint_roundtrip_reference_file_layout(tmp_path):
+    """save_pretrained / from_pretrained over diffusers' files (config.json + diffusion_pytorch_model.safetensors):
+    the containers the reference loads at pipe:733-746 and writes at unet:1080-1116."""
+    import json
+    import os
+    p = pkg()
+    torch.manual_seed(3)
+    m = p.UNetMotionCrossFrameAttnModel(**SMALL_UNET)
+    from i2v_adapter_unofficial_amd.checkpoint import init_random_weights_
+    init_random_weights_(m, seed=5, norm_jitter=0.1)
+    # adapter: reference layout = <dir>/i2v_adapter/{config.json, diffusion_pytorch_model.safetensors}
+    m.save_i2v_adapter_modules(str(tmp_path / "i2v_adapter"))
+    m.save_motion_modules(str(tmp_path / "motion_modules"))
+    cfg = json.load(open(tmp_path / "i2v_adapter" / "config.json"))
+    assert cfg["_class_name"] == "I2VAdapterModule" and cfg["block_depth"] == 2 and cfg["num_attention_heads"] == 4
+    assert cfg["block_out_channels"] == [32, 64, 128, 128]
+    assert os.path.isfile(tmp_path / "i2v_adapter" / "diffusion_pytorch_model.safetensors")
+    ad = p.I2VAdapterModule.from_pretrained(str(tmp_path / "i2v_adapter"))
+    mo = p.MotionAdapter.from_pretrained(str(tmp_path), subfolder="motion_modules", torch_dtype=torch.float16)
+    assert next(mo.parameters()).dtype == torch.float16
+    sd = m.state_dict()
+    for k, v in ad.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    for k, v in mo.state_dict().items():
+        assert torch.equal(v.float(), sd[k].half().float()), k
+    # a second model picks the saved parts up through the reference's loaders (unet:1028-1041)
+    m2 = p.UNetMotionCrossFrameAttnModel(**SMALL_UNET)
+    m2.load_i2v_adapter(ad)
+    m2.load_motion_modules(p.MotionAdapter.from_pretrained(str(tmp_path / "motion_modules")))
+    for k, v in m2.state_dict().items():
+        if "i2v_adapter" in k or "motion_modules" in k:
+            assert torch.equal(v, sd[k]), k
+    # whole model + the pickle variant + variant file names
+    m.save_pretrained(str(tmp_path / "unet"), safe_serialization=False, variant="fp16")
+    assert os.path.isfile(tmp_path / "unet" / "diffusion_pytorch_model.fp16.bin")
+    m3 = p.UNetMotionCrossFrameAttnModel.from_pretrained(str(tmp_path / "unet"), variant="fp16")
+    assert all(torch.equal(v, sd[k]) for k, v in m3.state_dict().items())
+    with pytest.raises(EnvironmentError):
+        p.I2VAdapterModule.from_pretrained(str(tmp_path / "nowhere"))
+    # IP-Adapter file (ip-adapter_sd15.bin layout, pipe:783) in both serialisations
+    from i2v_adapter_unofficial_amd.checkpoint import load_ip_adapter_file
+    from tests.parity import sd15_ip_state_dict
+    ipsd = sd15_ip_state_dict(m, clip_dim=48)
+    torch.save(ipsd, tmp_path / "ip-adapter_sd15.bin")
+    back = load_ip_adapter_file(str(tmp_path), weight_name="ip-adapter_sd15.bin")
+    assert set(back) == {"image_proj", "ip_adapter"} and torch.equal(back["ip_adapter"]["31.to_k_ip.weight"],
+                                                                      ipsd["ip_adapter"]["31.to_k_ip.weight"])
+    from safetensors.torch import save_file
+    flat = {f"{a}.{k}": v for a, d in ipsd.items() for k, v in d.items()}
+    save_file(flat, str(tmp_path / "ip-adapter_sd15.safetensors"))
+    back = load_ip_adapter_file(str(tmp_path / "ip-adapter_sd15.safetensors"))
+    assert torch.equal(back["image_proj"]["proj.weight"], ipsd["image_proj"]["proj.weight"])
+    m._load_ip_adapter_weights(back)
+    procs = m.attn_processors
+    assert sum(v.num_tokens == 4 for v in procs.values()) == 16
+    m.set_attn_processor({k: type(v)(0) for k, v in procs.items()})
+    assert all(v.num_tokens == 0 for v in m.attn_processors.values())
+    with pytest.raises(ValueError, match="number of processors"):
+        m.set_attn_processor({"x": procs[next(iter(procs))]})

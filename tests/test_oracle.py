@@ -46,7 +46,56 @@ def test_attention_matches_reference_basic_attention(path):
 
 def test_golden_fixture_count():
     assert len(glob.glob(os.path.join(GOLD, "ref_attention_*.safetensors"))) == 6
-    assert os.path.exists(os.path.join(GOLD, "oracle_outputs.safetensors"))
+    assert len(glob.glob(os.path.join(GOLD, "ref_transformer_block_*.safetensors"))) == 2
+    for f in ("oracle_outputs", "ref_positional_emb", "ref_resblock_conv_gn"):
+        assert os.path.exists(os.path.join(GOLD, f + ".safetensors"))
+
+
+def load_ref_block_into(block, t):
+    """weights of the reference-authored BasicTransformerBlock (src/modules/attention.py:64-77: attn1, attn2, norm1,
+    norm2; `to_out` is a Sequential there, index 0 = the Linear as in diffusers) into a block of this repo, and the
+    GEGLU feed-forward switched off (ff.net.2 = 0 => ff(norm3(x)) + x == x)."""
+    sd = {k: v for k, v in t.items() if k.split(".")[0] in ("attn1", "attn2", "norm1", "norm2")}
+    missing, unexpected = block.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.split(".")[0] in ("norm3", "ff", "i2v_adapter", "pos_embed") for k in missing), missing
+    with torch.no_grad():
+        block.ff.net[2].weight.zero_()
+        block.ff.net[2].bias.zero_()
+    return block
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ref_transformer_block_*.safetensors"))))
+def test_block_composition_matches_reference_basic_transformer_block(path):
+    """LayerNorm -> attention -> residual, twice (i2v:444-445, 468-473, 501, 510-533) == the reference-authored
+    BasicTransformerBlock on the same weights, for the oracle's plain block and its adapter subclass."""
+    from oracle.blocks import BasicTransformerBlock
+    from oracle.i2v_adapter import I2VAdapterTransformerBlock
+    t, meta = _load_ref(path)
+    heads, d = int(meta["heads"]), int(meta["head_dim"])
+    ctx_dim = t["ctx"].shape[-1]
+    for cls in (BasicTransformerBlock, I2VAdapterTransformerBlock):
+        torch.manual_seed(0)
+        blk = load_ref_block_into(cls(heads * d, heads, d, cross_attention_dim=ctx_dim).eval(), t)
+        with torch.no_grad():
+            y = blk(t["x"], encoder_hidden_states=t["ctx"])
+        assert torch.allclose(y, t["y"], atol=5e-6, rtol=1e-5), (cls.__name__, (y - t["y"]).abs().max())
+
+
+def test_sinusoid_matches_reference_positional_emb():
+    """oracle Timesteps (A1: [cos | sin], unet:763) and the motion-module table (A10) use the frequencies of the
+    reference-authored positional_emb (src/modules/util.py:4-8: [sin | cos], 1 / 10000^(2 i / C))."""
+    from oracle.blocks import SinusoidalPositionalEmbedding, Timesteps
+    t = load_file(os.path.join(GOLD, "ref_positional_emb.safetensors"))
+    for c in (320, 32):
+        ref = t[f"emb{c}"]
+        e = Timesteps(c, True, 0)(t["t"][:, 0])
+        assert torch.allclose(e[:, : c // 2], ref[:, c // 2:], atol=2e-4)      # cos half (fp32 sin/cos of t <= 999)
+        assert torch.allclose(e[:, c // 2:], ref[:, : c // 2], atol=2e-4)      # sin half
+    pe = SinusoidalPositionalEmbedding(32, 32).pe[0]                            # interleaved sin / cos, same frequencies
+    ref = t["emb32"]
+    for row, pos in ((0, 0), (1, 1), (2, 2), (3, 16)):
+        assert torch.allclose(pe[pos, 0::2], ref[row, :16], atol=1e-5) and torch.allclose(pe[pos, 1::2], ref[row, 16:], atol=1e-5)
 
 
 def test_add_noise_known_answer():
