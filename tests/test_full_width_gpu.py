@@ -9,7 +9,8 @@
 * full-size PROPERTY tests for configs 2, 3 and 5 (the oracle cannot run those sizes in seconds): finite, frame 0 ==
   condition latents exactly (pipe:699-700), eager == hipGraph bit for bit, run-to-run identical.
 
-Tolerances (measured on MI355X in round 2, gpurun_out/parity_r2.jsonl; asserted bounds <= 3x the measured error):
+Tolerances (measured on MI355X in round 2, profiles/r2_parity_errors.jsonl; asserted bounds <= 3x the measured error:
+UNet forward 1.5e-3 .. 2.1e-3 max-abs at max|ref| 1.3, modules 3.8e-4 .. 6.4e-4 of max|ref|):
 every case also runs the oracle in its fp16-emulating mode (oracle/fp16_emulation.py = the rounding pattern of the
 reference's own fp16 GPU path) and requires the HIP error against the fp32 oracle to stay within that yardstick.
 """
@@ -25,7 +26,7 @@ pytestmark = pytest.mark.gpu
 # by which the HIP error may exceed the fp16-emulated reference's own error
 FWD_ABS_TOL = 6.0e-3
 EMU_FACTOR = 1.25
-MODULE_REL_TOL = 6.0e-3
+MODULE_REL_TOL = 2.0e-3
 
 
 def pkg():
