@@ -1,19 +1,25 @@
 #!/usr/bin/env python
 """Headline benchmark: denoising steps/sec @ 16 f x 512 x 512, SD-1.5 + motion-adapter + I2V-Adapter, fp16.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            BASELINE configs[1] (default), one sample per GPU
+  python bench.py --ip                                      configs[2]: + IP-Adapter image-prompt branch
+  python bench.py --pairs 64 [--batch B]                    configs[3]: 64 (image, prompt) pairs sharded over the ranks,
+                                                            B samples per graph replay, K steps per pair
+  python bench.py --frames 32 --size 768                    configs[4]: 32 f x 768 x 768
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One *step* = one iteration of the reference loop pipe:666-697 for one (image, prompt) sample: frame-0 overwrite,
 CFG duplicate (B = 2), UNet forward, CFG combine, DDIM update -- replayed as one hipGraph.  Inputs are synthetic
-(SURVEY 8d): random-init weights of the SD-1.5 + AnimateDiff + I2V-Adapter architecture (seed 1234, adapter to_out
-~ N(0, 0.02^2)), resident in HBM before the timed region.  Each rank runs its own sample (weak scaling, no per-step
-collective); rank 0 builds the weights and broadcasts them once over RCCL.
+(SURVEY 8d): random-init weights of the SD-1.5 + AnimateDiff + I2V-Adapter architecture (seed 1234, torch's default
+Linear / Conv law drawn on the GPU, adapter to_out ~ N(0, 0.02^2)), resident in HBM before the timed region.  Samples
+are independent: they shard over ranks with no per-step collective; rank 0 draws the weights and broadcasts them once
+as one flat buffer over RCCL.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     live HIP-event timing of the dominant kernel class over one instrumented forward,
-  "cpu_baseline": the CPU oracle (fp32, unfused torch graph = the reference's op graph) timed on the host cores on a
-                  bounded sample (rank 0, N = 1 only).
+  "roofline":     live HIP-event timing of the dominant kernel class over one instrumented eager step,
+  "cpu_baseline": the CPU oracle (fp32, unfused torch graph = the reference's op graph) timed on the host cores on ONE
+                  CFG UNet forward of this same workload (rank 0, N = 1 only), and `parity`: the HIP forward compared
+                  with that oracle forward on the same weights and inputs.
 """
 import argparse
 import json
@@ -27,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic work per step, SURVEY.md Appendix B (2*MAC, B = 2 CFG, K/V of adapter & text counted once per clip)
-FLOPS_PER_STEP = {"cfg2": 40.199e12, "cfg1": 4.299e12}
+FLOPS_PER_STEP = {(16, 512, False): 40.199e12, (16, 512, True): 40.205e12, (8, 256, False): 4.299e12,
+                  (32, 768, False): 225.074e12}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 
@@ -36,55 +43,90 @@ SD15 = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(3
             motion_num_attention_heads=8, motion_max_seq_length=32)
 
 
-def build_weights_cpu(seed=1234):
-    """fp16 state dict of the full architecture with torch default inits under a fixed seed, built with the oracle
-    classes on the CPU (the HIP model has the same keys / shapes); adapter to_out re-drawn N(0, 0.02^2)."""
-    from oracle.unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel as OracleUNet
-    from tests.parity import randomize_adapter_out_
-    torch.manual_seed(seed)
-    o = OracleUNet(**SD15)
-    randomize_adapter_out_(o)
-    return o
-
-
-def build_hip_model(dev, state_dict=None):
+def build_hip_model(dev, seed=None):
+    """SD-1.5-width model materialised on the GPU in fp16; `seed` draws the synthetic weights there."""
     import i2v_adapter_unofficial_amd as pkg
+    from i2v_adapter_unofficial_amd.checkpoint import init_random_weights_
     with torch.device("meta"):
         m = pkg.UNetMotionCrossFrameAttnModel(**SD15)
     m = m.to_empty(device=dev).half()
-    if state_dict is not None:
-        m.load_state_dict(state_dict)
+    if seed is not None:
+        init_random_weights_(m, seed=seed)
     return m.eval()
 
 
-def cpu_baseline(oracle_unet):
-    """Oracle timed on the host cores on a bounded sample: ONE CFG UNet forward (B = 2) at BASELINE config 1's shape
-    (8 f x 256^2 => latents (2, 8, 4, 32, 32), 4.299 TFLOP), scaled to the 16 f x 512^2 step by the FLOP ratio."""
-    g = torch.Generator().manual_seed(3)
-    ctx = torch.randn(2, 77, 768, generator=g)
-    # thread count: the host may expose far more hardware threads than the job may use (256 threads measured 5x
-    # SLOWER than 16 on the GPU box); calibrate on a 1-frame forward and keep the fastest
-    probe = torch.randn(2, 1, 4, 32, 32, generator=g)
-    best_t, cores = None, 1
-    with torch.no_grad():
-        for th in sorted({min(th, os.cpu_count() or 1) for th in (8, 16, 32)}):
-            torch.set_num_threads(th)
+def synthetic_ip_state_dict(model, seed=7, clip_dim=1024):
+    """ip-adapter_sd15.bin layout with synthetic values; key ids 1, 3, ... in attn_processors order."""
+    g = torch.Generator().manual_seed(seed)
+    cross = model.config["cross_attention_dim"]
+    r = lambda *shape, s: torch.randn(*shape, generator=g) * s
+    sd = {"image_proj": {"proj.weight": r(4 * cross, clip_dim, s=clip_dim ** -0.5), "proj.bias": r(4 * cross, s=0.1),
+                         "norm.weight": 1 + r(cross, s=0.1), "norm.bias": r(cross, s=0.1)}, "ip_adapter": {}}
+    mods = dict(model.named_modules())
+    names = [n for n in model.attn_processor_names() if n.endswith("attn2.processor") and "motion_modules" not in n]
+    for i, n in enumerate(names):
+        a = mods[n[: -len(".processor")]]
+        sd["ip_adapter"][f"{2 * i + 1}.to_k_ip.weight"] = r(a.inner_dim, cross, s=cross ** -0.5)
+        sd["ip_adapter"][f"{2 * i + 1}.to_v_ip.weight"] = r(a.inner_dim, cross, s=cross ** -0.5)
+    return sd
+
+
+def sample_inputs(index, frames, h_lat, ip):
+    """synthetic (condition latents, prompt embeds, negative embeds, initial latents[, image embeds]) of pair `index`."""
+    s = 1000 * index
+    rn = lambda seed, *shape: torch.randn(*shape, generator=torch.Generator().manual_seed(s + seed))
+    d = dict(cond=rn(1, 1, 4, h_lat, h_lat), pe=rn(2, 1, 77, 768), ne=rn(3, 1, 77, 768),
+             lat=rn(5, 1, frames, 4, h_lat, h_lat))
+    if ip:
+        d["ie"] = rn(4, 1, 1024)
+    return d
+
+
+def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev):
+    """ONE CFG UNet forward (B = 2) of this workload through the CPU oracle on the host cores, with the HIP model's
+    weights; timed, and compared with the HIP forward of the same inputs."""
+    from oracle import blocks as oblocks
+    from oracle.unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel as OracleUNet
+    import torch.nn.functional as F
+    with torch.device("meta"):
+        ou = OracleUNet(**SD15)
+    ou = ou.to_empty(device="cpu").float()
+    ou.load_state_dict({k: v.detach().float().cpu() for k, v in model.state_dict().items()
+                        if "_ip." not in k and not k.startswith("encoder_hid_proj")})
+    if ip_sd is not None:
+        ou._load_ip_adapter_weights({a: {k: v.half().float() for k, v in d.items()} for a, d in ip_sd.items()})
+    ou.eval()
+    # the reference's attention op is F.scaled_dot_product_attention (AttnProcessor2_0); the oracle's explicit-softmax
+    # form would materialise 2 x 17 GB of scores at the 64 x 64 level
+    orig = oblocks.Attention._sdpa
+    oblocks.Attention._sdpa = lambda self, q, k, v: F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, frames, 4, h_lat, h_lat, generator=g).half().float()
+    ctx = torch.randn(2, 77, 768, generator=g).half().float()
+    added = None
+    added_d = None
+    if ip_sd is not None:
+        ie = torch.randn(2, 1024, generator=g).half().float()
+        added, added_d = {"image_embeds": ie}, {"image_embeds": ie.to(dev)}
+    t = torch.tensor([481, 481])
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    try:
+        with torch.no_grad():
             t0 = time.time()
-            oracle_unet(probe, torch.tensor(500), True, ctx)
+            ref = ou(x, t, True, ctx, added_cond_kwargs=added).sample
             dt = time.time() - t0
-            if best_t is None or dt < best_t:
-                best_t, cores = dt, th
-        torch.set_num_threads(cores)
-        x = torch.randn(2, 8, 4, 32, 32, generator=g)
-        t0 = time.time()
-        oracle_unet(x, torch.tensor(500), True, ctx)
-        dt = time.time() - t0
-    scaled = dt * FLOPS_PER_STEP["cfg2"] / FLOPS_PER_STEP["cfg1"]
-    return {"value": 1.0 / scaled, "unit": "denoising steps/sec", "cores": cores, "kind": "port",
-            "sample": (f"one fp32 CFG UNet forward of the CPU oracle at 8f x 256x256 (4.299 TFLOP) took {dt:.2f} s on "
-                       f"{cores} threads (fastest of 8/16/32 on a {os.cpu_count()}-thread host); scaled by "
-                       "40.199/4.299 to the 16f x 512x512 step"),
-            "oracle_tflops": FLOPS_PER_STEP["cfg1"] / dt / 1e12}
+            got = model(x.to(dev), t.to(dev), True, ctx.to(dev), added_cond_kwargs=added_d).sample.float().cpu()
+    finally:
+        oblocks.Attention._sdpa = orig
+    err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+    base = {"value": 1.0 / dt, "unit": "denoising steps/sec", "cores": cores, "kind": "port",
+            "sample": (f"one fp32 CFG UNet forward (B = 2) of the CPU oracle at {frames}f x {h_lat * 8}x{h_lat * 8} took "
+                       f"{dt:.1f} s on {cores} threads of a {os.cpu_count()}-thread host (torch {torch.__version__}); a "
+                       "step is that forward plus negligible elementwise work")}
+    parity = {"max_abs_err": err, "max_abs_ref": scale, "rel": err / max(scale, 1e-30),
+              "what": "HIP UNet forward vs the fp32 CPU oracle forward timed above (same weights, same inputs)"}
+    return base, parity
 
 
 def main():
@@ -94,6 +136,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ip", action="store_true", help="IP-Adapter image-prompt branch on (BASELINE configs[2])")
+    ap.add_argument("--pairs", type=int, default=0, help="total (image, prompt) pairs sharded over the ranks (configs[3])")
+    ap.add_argument("--batch", type=int, default=1, help="samples per graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -101,9 +146,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -112,59 +156,64 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import i2v_adapter_unofficial_amd as pkg
-    from i2v_adapter_unofficial_amd import kernels as K
     from i2v_adapter_unofficial_amd.profiling import KernelProfile
-    from i2v_adapter_unofficial_amd.sharding import broadcast_model_weights
+    from i2v_adapter_unofficial_amd.sharding import broadcast_model_weights, shard_range
 
-    # ---- weights: rank 0 initialises, one flat RCCL broadcast to the other ranks
-    cpu_base = None
+    # ---- weights: rank 0 draws them on its GPU, one flat RCCL broadcast to the other ranks
     t_start = time.time()
-    if rank == 0:
-        oracle = build_weights_cpu()
-        sd = {k: v.half() for k, v in oracle.state_dict().items()}
-        model = build_hip_model(dev, sd)
-        del sd
-    else:
-        oracle = None
-        model = build_hip_model(dev)
+    model = build_hip_model(dev, seed=1234 if rank == 0 else None)
+    ip = args.ip or args.pairs > 0                     # configs[3] = 64 pairs "each as configs[2]" 
+    ip_sd = None
+    if ip:
+        ip_sd = synthetic_ip_state_dict(model)
+        model._load_ip_adapter_weights(ip_sd)          # same seed on every rank; covered by the broadcast anyway
     if world > 1:
         nbytes = broadcast_model_weights(model, src=0)
         if rank == 0:
             print(f"# broadcast {nbytes / 1e9:.2f} GB of weights over RCCL", file=sys.stderr)
-
     t_built = time.time()
-    # ---- synthetic sample of this rank (SURVEY 8d seeds, offset by rank: independent samples)
-    F, h_lat = args.frames, args.size // 8
-    g = torch.Generator().manual_seed(1000 * rank + 1)
-    cond = torch.randn(1, 4, h_lat, h_lat, generator=g)
-    pe = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(1000 * rank + 2))
-    ne = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(1000 * rank + 3))
-    lat = torch.randn(1, F, 4, h_lat, h_lat, generator=torch.Generator().manual_seed(1000 * rank + 5))
+
+    # ---- this rank's samples (static block partition, no per-step collective)
+    F, h_lat, B = args.frames, args.size // 8, args.batch
+    n_pairs_total = args.pairs if args.pairs > 0 else world * B
+    if n_pairs_total % (world * B) != 0:
+        raise SystemExit(f"--pairs {n_pairs_total} must be a multiple of ranks x batch = {world * B}")
+    lo, hi = shard_range(n_pairs_total, rank, world)
+    mine = [sample_inputs(i, F, h_lat, ip) for i in range(lo, hi)]
+    groups = [mine[i: i + B] for i in range(0, len(mine), B)]
+
     pipe = pkg.I2VAdapterPipeline(unet=model)
     sch = pipe.scheduler
     sch.set_timesteps(25)
     timesteps = sch.timesteps
     n_tab = len(timesteps)
-    st = dict(latents=lat.to(dev), cond=cond.to(dev), copies=2, num_frames=F, guidance=7.5,
-              t_table=timesteps.float().to(dev), coef=sch.step_coefficients(timesteps).to(dev),
-              step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
-              ctx_text=torch.cat([ne, pe]).to(dev, torch.float16).contiguous(), ctx_ip=None)
-    lat0 = st["latents"].clone()
+    st = dict(latents=torch.empty(B, F, 4, h_lat, h_lat, device=dev), cond=torch.empty(B, 4, h_lat, h_lat, device=dev),
+              copies=2, num_frames=F, guidance=7.5, t_table=timesteps.float().to(dev),
+              coef=sch.step_coefficients(timesteps).to(dev), step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
+              ctx_text=torch.empty(2 * B, 77, 768, dtype=torch.float16, device=dev),
+              ctx_ip=torch.empty(2 * B, 4, 768, dtype=torch.float16, device=dev) if ip else None)
 
-    def reset():
-        st["latents"].copy_(lat0)
+    def load_group(grp):
+        """this group's inputs into the static buffers the captured graph reads (async copies on the stream)."""
+        st["latents"].copy_(torch.cat([s["lat"] for s in grp]), non_blocking=True)
+        st["cond"].copy_(torch.cat([s["cond"] for s in grp]), non_blocking=True)
+        st["ctx_text"].copy_(torch.cat([s["ne"] for s in grp] + [s["pe"] for s in grp]).half(), non_blocking=True)
+        if ip:
+            ie = torch.cat([torch.zeros_like(s["ie"]) for s in grp] + [s["ie"] for s in grp])      # pipe:343, 621-622
+            st["ctx_ip"].copy_(model._project_image_embeds({"image_embeds": ie.to(dev)}))
         st["step_idx"].zero_()
 
     with torch.no_grad():
+        load_group(groups[0])
         pipe._step(st)                      # eager warm-up: packs the kernel-layout weights, sizes the allocator
-        reset()
+        load_group(groups[0])
         torch.cuda.synchronize()
         graph = None
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 pipe._step(st)
-            reset()
+            load_group(groups[0])
 
         def run_step():
             if graph is not None:
@@ -173,19 +222,22 @@ def main():
                 pipe._step(st)
 
         for i in range(args.warmup):
+            if i % n_tab == 0 and i:
+                st["step_idx"].zero_()
             run_step()
-        reset()
-        # ---- timed region: exactly K steps between barrier + synchronize on both sides
-        done = 0
+        # ---- timed region: exactly K steps per group between barrier + synchronize on both sides
+        load_group(groups[0])
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        while done < args.steps:
-            if done % n_tab == 0 and done:
-                reset()                     # wrap the 25-entry timestep table: next sample (async copies on the stream)
-            run_step()
-            done += 1
+        for gi, grp in enumerate(groups):
+            if gi:
+                load_group(grp)
+            for done in range(args.steps):
+                if done % n_tab == 0 and done:
+                    st["step_idx"].zero_()  # wrap the 25-entry timestep table (the kernels also clamp the index)
+                run_step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -201,7 +253,7 @@ def main():
         #      the event pairs bracket back-to-back kernels, not host launch gaps
         roof, classes = None, None
         if rank == 0:
-            reset()
+            load_group(groups[0])
             torch.cuda._sleep(int(2.0e8))   # ~0.1 s device-side spin (not one of our kernels): the host runs ahead
             with KernelProfile() as prof:
                 pipe._step(st)
@@ -217,43 +269,52 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom, "achieved": d["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": d["gbps"] / HBM_PEAK_GBPS, "traffic": None, "launches": d["calls"],
                         "avg_launch_us": d["ms"] * 1e3 / d["calls"], "bytes_per_launch": d["bytes"] / d["calls"]}
-            # HBM-side bytes per launch of that class: PMC counters cannot be read from inside the process, so this
-            # is the committed result of the separate rocprofv3 --pmc passes over this same command
-            # (tools/pmc_traffic.sh -> profiles/r1_traffic.json), valid for the default workload only
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
-            if os.path.exists(tpath) and args.frames == 16 and args.size == 512:
+            # HBM-side bytes per launch of that class: PMC counters cannot be read from inside the process, so this is
+            # the committed result of the separate rocprofv3 --pmc passes over this same command
+            # (tools/pmc_traffic.sh -> profiles/r2_traffic.json), valid for the default workload only
+            tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
+            if os.path.exists(tpath) and (F, args.size, ip, B) == (16, 512, False, 1):
                 with open(tpath) as f:
                     tcls = json.load(f).get("classes", {})
                 if dom in tcls:
                     roof["traffic"] = tcls[dom]["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    roof["traffic_source"] = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
     used_graph = graph is not None
     graph = None
     t_gpu_done = time.time()
+    cpu_base, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_base = cpu_baseline(oracle)
+        cpu_base, parity = cpu_baseline_and_parity(model, ip_sd, F, h_lat, dev)
+        if not (parity["max_abs_err"] <= 6e-3):         # tests/test_full_width_gpu.py FWD_ABS_TOL
+            print(f"# PARITY FAILURE: {parity}", file=sys.stderr)
     if rank == 0:
         print(f"# timings: build {t_built - t_start:.1f}s, gpu {t_gpu_done - t_built:.1f}s, cpu baseline "
               f"{time.time() - t_gpu_done:.1f}s", file=sys.stderr)
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
-        step_flops = FLOPS_PER_STEP["cfg2"] if (F == 16 and args.size == 512) else None
+        sample_steps = n_pairs_total * args.steps       # every sample of the job advances K steps
+        ms = elapsed / (len(groups) * args.steps) * 1e3  # one graph replay (B samples' step on one GPU)
+        value = sample_steps / elapsed
+        step_flops = FLOPS_PER_STEP.get((F, args.size, ip))
+        cfg_name = ("configs[3]: batch of pairs, data-parallel" if args.pairs else
+                    "configs[4]" if (F, args.size) == (32, 768) else "configs[2]" if ip else "configs[1]")
         out = {
             "metric": "denoising steps/sec @ 16fx512x512 SD1.5+I2V-Adapter", "value": value,
             "unit": "denoising steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-            "data": "synthetic",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if not args.pairs else "strong",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SD-v1.5 + motion-adapter-v1-5-2 + I2V-Adapter topology, {F}f x {args.size}x{args.size}, "
-                                   "CFG 7.5 (B=2), DDIM 25-step table, fp16, IP off, 1 sample per GPU (BASELINE configs[1])",
-                       "samples_per_gpu": 1, "graph": used_graph, "finite": finite,
+                                   f"CFG 7.5 (B=2 per sample), DDIM 25-step table, fp16, IP {'on' if ip else 'off'}, "
+                                   f"{n_pairs_total} sample(s) over {world} GPU(s), {B} per graph replay (BASELINE {cfg_name})",
+                       "samples_total": n_pairs_total, "samples_per_replay": B, "graph": used_graph, "finite": finite,
                        "unet_forwards_per_cfg_half_per_sec": 2 * value,
                        "step_tflops": None if step_flops is None else step_flops / 1e12,
-                       "achieved_tflops_per_gpu": None if step_flops is None else step_flops / (ms * 1e-3) / 1e12},
+                       "achieved_tflops_per_gpu": None if step_flops is None else
+                       step_flops * sample_steps / elapsed / world / 1e12},
             "roofline": roof,
             "cpu_baseline": cpu_base,
+            "parity": parity,
             "kernel_classes": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                                for k, v in (classes or {}).items()},
         }

@@ -7,8 +7,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libi2v_hip.so")
-ABI_VERSION = 1
+# I2V_LIB_PATH selects another build of the same ABI (same-box A/B of two kernels, tools/ab_bench.sh); the in-tree
+# library is never overwritten by tooling
+LIB_PATH = os.environ.get("I2V_LIB_PATH") or os.path.join(_HERE, "libi2v_hip.so")
+ABI_VERSION = 2
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
 I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
@@ -101,13 +103,15 @@ SIGNATURES = {
     "i2v_layernorm_f16": (C.c_int, [C.POINTER(LnParams), _P]),
     "i2v_nchw_to_tokens": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_tokens_to_nchw": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
-    "i2v_timestep_embedding": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "i2v_timestep_embedding": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     "i2v_silu_f16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "i2v_repeat_rows_f16": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int32, _P]),
     "i2v_copy3d_f16": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_int64, _P]),
     "i2v_ddim_prep": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
-    "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int32, C.c_int32, C.c_int32,
+    "i2v_first_frame_prior_f32": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, _P]),
 }
 

@@ -47,12 +47,15 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const f16* __restri
 }
 
 __global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, const int32_t* __restrict__ t_index,
-                                                                 f16* __restrict__ out, int n, int dim) {
+                                                                 int t_rows, f16* __restrict__ out, int n, int dim) {
   const int half = dim / 2;
   const int total = n * half;
+  // the device-side step counter is clamped to the table: a graph replayed more often than the table is long must not
+  // read past it
+  const int ti = t_index ? min(max(*t_index, 0), t_rows - 1) : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int row = i / half, j = i - row * half;
-    const float tv = t_index ? t[*t_index] : t[row];
+    const float tv = t_index ? t[ti] : t[row];
     // freq_j = exp(-ln(10000) * j / half); embedding = [cos | sin]  (flip_sin_to_cos = True, shift 0)
     const float freq = expf(-9.210340371976184f * (float)j / (float)half);
     const float a = tv * freq;
@@ -115,10 +118,11 @@ __global__ __launch_bounds__(256) void ddim_prep_kernel(float* __restrict__ late
 }
 
 __global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ latents, const f16* __restrict__ np, int64_t ld_np,
-                                                        const float* __restrict__ coef, const int32_t* __restrict__ step_index,
-                                                        float guidance, int b, int f, int c, int hw, int copies) {
+                                                        const float* __restrict__ coef, int n_steps,
+                                                        const int32_t* __restrict__ step_index, float guidance, int b,
+                                                        int f, int c, int hw, int copies) {
   const int64_t total = (int64_t)b * f * c * hw;
-  const float* cf = coef + 4 * (int64_t)(*step_index);
+  const float* cf = coef + 4 * (int64_t)min(max(*step_index, 0), n_steps - 1);
   const float sa_t = cf[0], sb_t = cf[1], sa_p = cf[2], sb_p = cf[3];
   const int64_t bf = (int64_t)b * f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -140,8 +144,45 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ late
   }
 }
 
-__global__ void bump_step_kernel(int32_t* step_index) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *step_index += 1;
+// First-frame-similarity prior + add_noise (pipe:647-656), one pass:
+//   prior = mask * blur3x3(cond) + (1 - mask) * cond,  mask = (u < strength)          (per frame, per element)
+//   latents = sqrt(a_t) * prior + sqrt(1 - a_t) * noise                                 (DDIMScheduler.add_noise)
+// blur = torchvision GaussianBlur(kernel_size=3): separable taps (ke, kc, ke), reflect padding.
+__global__ __launch_bounds__(256) void prior_kernel(const float* __restrict__ cond, const float* __restrict__ u,
+                                                    const float* __restrict__ noise, float* __restrict__ latents, int b,
+                                                    int f, int c, int h, int w, float kc, float ke, float strength,
+                                                    float sa, float sb) {
+  const int64_t total = (int64_t)b * f * c * h * w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % w);
+    int64_t t = i / w;
+    const int y = (int)(t % h);
+    t /= h;
+    const int ch = (int)(t % c);
+    t /= c;
+    const int bb = (int)(t / f);
+    const float* img = cond + ((int64_t)bb * c + ch) * h * w;
+    const float center = img[y * w + x];
+    float v = center;
+    if (u[i] < strength) {
+      // reflect (no edge repeat): index -1 -> 1, n -> n - 2; a 1-pixel axis has nothing to reflect onto
+      const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+      const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+      const float r0 = ke * img[ym * w + xm] + kc * img[ym * w + x] + ke * img[ym * w + xp];
+      const float r1 = ke * img[y * w + xm] + kc * center + ke * img[y * w + xp];
+      const float r2 = ke * img[yp * w + xm] + kc * img[yp * w + x] + ke * img[yp * w + xp];
+      v = ke * r0 + kc * r1 + ke * r2;
+    }
+    latents[i] = sa * v + sb * noise[i];
+  }
+}
+
+// the counter wraps at the end of the table: replay n_steps + k of a captured step restarts the schedule at entry k
+__global__ void bump_step_kernel(int32_t* step_index, int n_steps) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int next = *step_index + 1;
+    *step_index = (next >= n_steps || next < 0) ? 0 : next;
+  }
 }
 
 }  // namespace
@@ -174,12 +215,13 @@ extern "C" int i2v_tokens_to_nchw(const void* src, int64_t ld, void* dst, int32_
   return i2v_check_launch("i2v_tokens_to_nchw");
 }
 
-extern "C" int i2v_timestep_embedding(const float* t, const int32_t* t_index, void* out, int32_t n, int32_t dim,
-                                      i2v_stream_t stream) {
+extern "C" int i2v_timestep_embedding(const float* t, const int32_t* t_index, int32_t t_rows, void* out, int32_t n,
+                                      int32_t dim, i2v_stream_t stream) {
   I2V_CHECK_ARG(t && out && n > 0 && dim > 0 && dim % 2 == 0, "i2v_timestep_embedding: bad arguments");
+  I2V_CHECK_ARG(t_index == nullptr || t_rows > 0, "i2v_timestep_embedding: t_rows must be the length of the table t_index walks");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3(ew_blocks((int64_t)n * dim / 2)), dim3(256), 0, s, t, t_index,
-                     reinterpret_cast<f16*>(out), n, dim);
+                     t_rows, reinterpret_cast<f16*>(out), n, dim);
   return i2v_check_launch("i2v_timestep_embedding");
 }
 
@@ -222,15 +264,28 @@ extern "C" int i2v_ddim_prep(float* latents, const float* cond, void* model_in, 
 }
 
 extern "C" int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, const float* coef,
-                                 int32_t* step_index, float guidance_scale, int32_t b, int32_t f, int32_t c, int32_t hw,
-                                 int32_t cfg_copies, i2v_stream_t stream) {
-  I2V_CHECK_ARG(latents && noise_pred && coef && step_index && b > 0 && f > 0 && c > 0 && hw > 0 && ld_np >= c,
+                                 int32_t n_steps, int32_t* step_index, float guidance_scale, int32_t b, int32_t f,
+                                 int32_t c, int32_t hw, int32_t cfg_copies, i2v_stream_t stream) {
+  I2V_CHECK_ARG(latents && noise_pred && coef && step_index && b > 0 && f > 0 && c > 0 && hw > 0 && ld_np >= c &&
+                    n_steps > 0,
                 "i2v_ddim_cfg_step: bad arguments");
   I2V_CHECK_ARG(cfg_copies == 1 || cfg_copies == 2, "i2v_ddim_cfg_step: cfg_copies must be 1 or 2");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_blocks((int64_t)b * f * c * hw)), dim3(256), 0, s, latents,
-                     reinterpret_cast<const f16*>(noise_pred), ld_np, coef, step_index, guidance_scale, b, f, c, hw,
-                     cfg_copies);
-  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step_index);
+                     reinterpret_cast<const f16*>(noise_pred), ld_np, coef, n_steps, step_index, guidance_scale, b, f, c,
+                     hw, cfg_copies);
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step_index, n_steps);
   return i2v_check_launch("i2v_ddim_cfg_step");
+}
+
+extern "C" int i2v_first_frame_prior_f32(const float* cond, const float* mask_uniform, const float* noise, float* latents,
+                                         int32_t b, int32_t f, int32_t c, int32_t h, int32_t w, float k_center,
+                                         float k_edge, float strength, float sqrt_alpha, float sqrt_one_minus_alpha,
+                                         i2v_stream_t stream) {
+  I2V_CHECK_ARG(cond && mask_uniform && noise && latents && b > 0 && f > 0 && c > 0 && h > 0 && w > 0,
+                "i2v_first_frame_prior_f32: bad arguments");
+  hipLaunchKernelGGL(prior_kernel, dim3(ew_blocks((int64_t)b * f * c * h * w)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), cond, mask_uniform, noise, latents, b, f, c, h, w, k_center,
+                     k_edge, strength, sqrt_alpha, sqrt_one_minus_alpha);
+  return i2v_check_launch("i2v_first_frame_prior_f32");
 }

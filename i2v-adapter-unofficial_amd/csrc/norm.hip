@@ -23,7 +23,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------- GroupNorm
-// pass 1: per (image, row-chunk, channel) partial sum / sum of squares.
+// Statistics are carried as (mean, M2 = sum of squared deviations) partials and merged with Chan's formula, never as
+// E[x^2] - mean^2: real SD activations have channels with |mean| >> std, where the raw-moment form loses its digits to
+// cancellation in fp32 (round-1 form).
+// pass 1: per (image, row-chunk, channel) partial (mean, M2) over the chunk's rows.  Inside a chunk the sums run over
+// data SHIFTED by the channel's value in the chunk's first row (a sample of the same distribution, so the shifted
+// values are of the size of the spread, not of the mean): mean = K + S1 / n, M2 = S2 - S1^2 / n.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
                                                        int c2, int hw, int rpc, float* __restrict__ partial) {
   __shared__ float red[256 * 16];
@@ -40,9 +45,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
 
   for (int col0 = 0; col0 < nvec; col0 += cols_per_pass) {
     const int col = col0 + col_lane;
-    float s[8], q[8];
+    float s[8], q[8], kshift[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = kshift[e] = 0.f;
     if (active && col < nvec) {
       const f16* base;
       int64_t ld;
@@ -56,11 +61,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
         ld = c2;
         coff = (col - nv1) * 8;
       }
+      const f16x8 k8 = ld_global_16B(base + (int64_t)row_begin * ld + coff);   // the same shift for every row lane
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kshift[e] = (float)k8[e];
       for (int r = row_begin + row_lane; r < row_end; r += rows_par) {
         const f16x8 v = ld_global_16B(base + (int64_t)r * ld + coff);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float f = (float)v[e];
+          const float f = (float)v[e] - kshift[e];
           s[e] += f;
           q[e] += f * f;
         }
@@ -81,51 +89,61 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
           q[e] += red[o + 8 + e];
         }
       }
+      const float n = (float)(row_end - row_begin), inv_n = 1.0f / n;
       float* dst = partial + (((int64_t)img * nchunk + chunk) * C + col * 8) * 2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        dst[2 * e] = s[e];
-        dst[2 * e + 1] = q[e];
+        dst[2 * e] = kshift[e] + s[e] * inv_n;                  // mean of this (chunk, channel)
+        dst[2 * e + 1] = fmaxf(q[e] - s[e] * s[e] * inv_n, 0.f);   // M2
       }
     }
     __syncthreads();
   }
 }
 
-// pass 2: one wave per (stat group, channel group): mean / rstd, then per-(image, channel) scale & shift.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();                       // red may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// pass 2: one workgroup per (stat group, channel group): Chan merge of the (mean_i, M2_i, n_i) partials in a fixed
+// order (deterministic), then per-(image, channel) scale & shift.
+//   mean = sum n_i mean_i / N;   M2 = sum M2_i + sum n_i (mean_i - mean)^2;   var = M2 / N
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C,
-                                                          int groups, int fps, int hw, float eps,
+                                                          int groups, int fps, int hw, int rpc, float eps,
                                                           const f16* __restrict__ gamma, const f16* __restrict__ beta,
                                                           float* __restrict__ coef) {
-  __shared__ float red[8];
+  __shared__ float red[4];
   const int sg = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
   const int cpg = C / groups;
   const int total = fps * nchunk * cpg;
-  float s = 0.f, q = 0.f;
+  const float cnt = (float)fps * (float)hw * (float)cpg;
   // the motion modules normalise over all frames of a clip (fps = 16): thousands of partials per group, each an
   // 8-byte strided load, so keep many of them in flight per workgroup
+  float s = 0.f;
 #pragma unroll 4
   for (int i = lane; i < total; i += 256) {
     const int c = i % cpg, t = i / cpg;
     const int ch = t % nchunk, f = t / nchunk;
+    const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc);
+    s += n_i * partial[((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 2];
+  }
+  const float mean = block_sum_256(s, red) / cnt;
+  float m2 = 0.f;
+#pragma unroll 4
+  for (int i = lane; i < total; i += 256) {
+    const int c = i % cpg, t = i / cpg;
+    const int ch = t % nchunk, f = t / nchunk;
+    const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc);
     const float2 v = *reinterpret_cast<const float2*>(
         partial + ((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 2);
-    s += v.x;
-    q += v.y;
+    const float dm = v.x - mean;
+    m2 += v.y + n_i * dm * dm;
   }
-  s = wave_sum(s);
-  q = wave_sum(q);
-  if ((lane & 63) == 0) {
-    red[(lane >> 6) * 2] = s;
-    red[(lane >> 6) * 2 + 1] = q;
-  }
-  __syncthreads();
-  s = red[0] + red[2] + red[4] + red[6];
-  q = red[1] + red[3] + red[5] + red[7];
-  const float cnt = (float)fps * (float)hw * (float)cpg;
-  const float mean = s / cnt;
-  float var = q / cnt - mean * mean;
-  var = var < 0.f ? 0.f : var;
+  const float var = block_sum_256(m2, red) / cnt;
   const float rstd = rsqrtf(var + eps);
   for (int i = lane; i < fps * cpg; i += 256) {
     const int c = grp * cpg + i % cpg, f = i / cpg;
@@ -281,7 +299,7 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   const f16* x2 = reinterpret_cast<const f16*>(p.x2);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, partial, nchunk, C,
-                     p.groups, p.frames_per_stat, p.hw, p.eps, reinterpret_cast<const f16*>(p.gamma),
+                     p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
                      reinterpret_cast<const f16*>(p.beta), coef);
   const int64_t total = (int64_t)p.n_img * p.hw * (C / 8);
   const int blocks = (int)(i2v_cdiv(total, 256) < 4096 ? i2v_cdiv(total, 256) : 4096);

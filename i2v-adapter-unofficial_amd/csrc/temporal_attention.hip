@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void tattn_kernel(const i2v_tattn_params p, co
   }
 }
 
-// Narrow-channel variant (C <= 640, frames <= 16: the 64 x 64 and 32 x 32 levels).  With head_dim 40 a head's slice of
+// Narrow-channel variant (frames <= 16 and a pixel's q / k / o rows + V^T block within 64 KiB of LDS: C <= 320, i.e. the
+// 64 x 64 level; at C = 640 the block is 93 KB = one workgroup per CU, and the register kernel above already streams
+// that level at 4.3-4.6 TB/s, so it stays there).  With head_dim 40 a head's slice of
 // a token row is 80 bytes, so the per-wave fragment loads above touch 16 rows x 64-80 bytes per instruction and the
 // kernel ran at 3.4 TB/s.  Here one workgroup owns ONE pixel with all its heads: the pixel's q / k rows ([F][C],
 // whole rows) and V^T block ([C][vt_ld], contiguous) are copied to LDS with 16 bytes per lane over whole rows, the
@@ -236,14 +238,13 @@ int launch_t(const i2v_tattn_params& p, hipStream_t s) {
   const float scale_log2 = p.scale * 1.4426950408889634f;
   const int C = p.heads * p.head_dim;
   static const int lds_off = getenv("I2V_TATTN_LDS") ? (atoi(getenv("I2V_TATTN_LDS")) == 0) : 0;
-  if (!lds_off && p.frames <= 16 && C <= 640 && p.o_row_stride % 8 == 0 &&
+  // 64 KiB = the dynamic-LDS size a kernel may request without hipFuncSetAttribute, and two workgroups per CU
+  const size_t lds = (size_t)(3 * 16 * (C + 8) + C * (p.vt_ld + 8)) * sizeof(f16);
+  if (!lds_off && p.frames <= 16 && lds <= 64 * 1024 && p.o_row_stride % 8 == 0 &&
       (reinterpret_cast<uintptr_t>(p.o) & 15) == 0) {
-    const size_t lds = (size_t)(3 * 16 * (C + 8) + C * (p.vt_ld + 8)) * sizeof(f16);
-    if (lds <= 64 * 1024) {
     int64_t blocks = p.n_pixels < 256 * 8 ? p.n_pixels : 256 * 8;
     hipLaunchKernelGGL((tattn_lds_kernel<DQK, DPV>), dim3((unsigned)blocks), dim3(256), lds, s, p, scale_log2);
     return i2v_check_launch("i2v_temporal_attention_f16");
-    }
   }
   const int64_t items64 = (int64_t)p.n_pixels * p.heads;
   const int n_items = (int)items64;

@@ -353,7 +353,8 @@ def timestep_embedding(t, dim, t_index=None):
     if t_index is not None:
         _req(t_index, "t_index", dtype=torch.int32)
     out = torch.empty((n, dim), dtype=f16, device=t.device)
-    _lib.check(lib.i2v_timestep_embedding(_p(t), _p(t_index), _p(out), n, dim, _stream()), "i2v_timestep_embedding")
+    _lib.check(lib.i2v_timestep_embedding(_p(t), _p(t_index), t.numel(), _p(out), n, dim, _stream()),
+               "i2v_timestep_embedding")
     return out
 
 
@@ -388,6 +389,31 @@ def copy3d(src, dst):
     return dst
 
 
+def first_frame_prior(cond, mask_uniform, noise, sigma, strength, sqrt_alpha, sqrt_one_minus_alpha):
+    """latents = sqrt_alpha * (mask * blur3x3_sigma(cond) + (1 - mask) * cond) + sqrt_one_minus_alpha * noise with
+    mask = (mask_uniform < strength): the first-frame-similarity prior + add_noise of pipe:647-656 in one kernel.
+    cond fp32 [B, C, H, W]; mask_uniform / noise fp32 [B, F, C, H, W]; returns fp32 [B, F, C, H, W]."""
+    import math
+    lib = _lib.load()
+    for t, name in ((cond, "cond"), (mask_uniform, "mask_uniform"), (noise, "noise")):
+        _req(t, name, dtype=torch.float32)
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+    if cond.dim() != 4 or noise.dim() != 5 or mask_uniform.shape != noise.shape or \
+            (noise.shape[0], noise.shape[2], noise.shape[3], noise.shape[4]) != tuple(cond.shape):
+        raise ValueError(f"cond {tuple(cond.shape)} / mask {tuple(mask_uniform.shape)} / noise {tuple(noise.shape)} mismatch")
+    if not sigma > 0:
+        raise ValueError("sigma must be positive")
+    b, f, c, h, w = noise.shape
+    e = math.exp(-0.5 / (sigma * sigma))                      # torchvision _get_gaussian_kernel1d, kernel_size 3
+    kc, ke = 1.0 / (1.0 + 2.0 * e), e / (1.0 + 2.0 * e)
+    out = torch.empty_like(noise)
+    _lib.check(lib.i2v_first_frame_prior_f32(_p(cond), _p(mask_uniform), _p(noise), _p(out), b, f, c, h, w, kc, ke,
+                                             float(strength), float(sqrt_alpha), float(sqrt_one_minus_alpha),
+                                             _stream()), "i2v_first_frame_prior_f32")
+    return out
+
+
 def ddim_prep(latents, cond, c_pad, cfg_copies):
     """latents fp32 [B, F, C, H, W] (frame 0 overwritten in place with cond [B, C, H, W]) ->
     model input tokens fp16 [cfg_copies * B * F, H, W, c_pad]."""
@@ -407,7 +433,8 @@ def ddim_prep(latents, cond, c_pad, cfg_copies):
 
 def ddim_cfg_step(latents, noise_pred, coef, step_index, guidance_scale, cfg_copies):
     """In-place DDIM update of latents fp32 [B, F, C, H, W] from noise_pred tokens fp16
-    [cfg_copies * B * F, H, W, ld]; coef fp32 [steps, 4]; step_index device int32 scalar (incremented)."""
+    [cfg_copies * B * F, H, W, ld]; coef fp32 [steps, 4]; step_index device int32 scalar (advanced by one, wrapping
+    to 0 at the end of the table)."""
     lib = _lib.load()
     _req(latents, "latents", dtype=torch.float32)
     _req(noise_pred, "noise_pred")
@@ -419,7 +446,7 @@ def ddim_cfg_step(latents, noise_pred, coef, step_index, guidance_scale, cfg_cop
         raise ValueError(f"noise_pred must be contiguous [{cfg_copies * b * f}, {h}, {w}, >={c}]")
     if coef.dim() != 2 or coef.shape[1] != 4 or not coef.is_contiguous():
         raise ValueError("coef must be contiguous [steps, 4]")
-    _lib.check(lib.i2v_ddim_cfg_step(_p(latents), _p(noise_pred), noise_pred.shape[3], _p(coef), _p(step_index),
-                                     float(guidance_scale), b, f, c, h * w, cfg_copies, _stream()),
+    _lib.check(lib.i2v_ddim_cfg_step(_p(latents), _p(noise_pred), noise_pred.shape[3], _p(coef), coef.shape[0],
+                                     _p(step_index), float(guidance_scale), b, f, c, h * w, cfg_copies, _stream()),
                "i2v_ddim_cfg_step")
     return latents

@@ -29,17 +29,18 @@ class I2VAdapterPipelineOutput:
         self.frames = frames
 
 
-def gaussian_blur3(x: torch.Tensor, sigma: float) -> torch.Tensor:
-    """torchvision GaussianBlur(kernel_size=3) for one sigma (pipe:112,648): separable 3-tap kernel, reflect pad.
-    Runs once per sample on the host, before the loop."""
-    xs = torch.linspace(-1.0, 1.0, 3)
-    pdf = torch.exp(-0.5 * (xs / sigma) ** 2)
-    k1 = pdf / pdf.sum()
-    k2 = (k1[:, None] * k1[None, :]).to(x.dtype)
-    c = x.shape[-3]
-    shp = x.shape
-    x4 = torch.nn.functional.pad(x.reshape(-1, c, shp[-2], shp[-1]), (1, 1, 1, 1), mode="reflect")
-    return torch.nn.functional.conv2d(x4, k2.expand(c, 1, 3, 3), groups=c).reshape(shp)
+def draw_blur_sigma(generator=None, sigma_min: float = 0.1, sigma_max: float = 2.0) -> float:
+    """torchvision GaussianBlur(kernel_size=3) (pipe:112) draws sigma ~ U(0.1, 2.0) once per call
+    (`GaussianBlur.get_params`); the reference uses the unseeded global RNG, here the draw takes a generator."""
+    gdev = generator.device if generator is not None else torch.device("cpu")
+    return float(torch.empty(1, device=gdev).uniform_(sigma_min, sigma_max, generator=generator).item())
+
+
+def _draw(fn, shape, generator, device):
+    """one seeded draw on the generator's own device (host generators reproduce the CPU oracle's numbers bit for bit;
+    a torch.Generator(device="cuda") keeps the whole prior on the GPU), moved to `device`."""
+    gdev = generator.device if generator is not None else torch.device("cpu")
+    return fn(shape, generator=generator, dtype=torch.float32, device=gdev).to(device)
 
 
 class I2VAdapterPipeline:
@@ -70,6 +71,15 @@ class I2VAdapterPipeline:
         self.unet.load_i2v_adapter(i2v_adapter)
         self.i2v_adapter = i2v_adapter
 
+    def load_ip_adapter(self, pretrained_model_name_or_path_or_dict, subfolder: Optional[str] = None,
+                        weight_name: Optional[str] = None, **_unused):
+        """diffusers IPAdapterMixin.load_ip_adapter as called at pipe:783: reads ip-adapter_sd15.{bin,safetensors} and
+        installs the decoupled cross-attention branch + ImageProjection (unet:1230-1287).  (The CLIP image encoder it
+        also loads upstream is out of scope: pass `image_embeds`.)"""
+        from .checkpoint import load_ip_adapter_file
+        self.unet._load_ip_adapter_weights(
+            load_ip_adapter_file(pretrained_model_name_or_path_or_dict, subfolder=subfolder, weight_name=weight_name))
+
     def load_motion_adapter(self, motion_adapter):
         self.unet.load_motion_modules(motion_adapter)
         self.motion_adapter = motion_adapter
@@ -90,8 +100,11 @@ class I2VAdapterPipeline:
                 f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
                 f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
         if latents is None:
-            latents = torch.randn(shape, generator=generator, dtype=torch.float32)
-        return latents.to(torch.float32) * self.scheduler.init_noise_sigma
+            if isinstance(generator, list):                                   # one generator per sample (pipe:287-290)
+                latents = torch.cat([_draw(torch.randn, (1,) + shape[1:], g, device) for g in generator], dim=0)
+            else:
+                latents = _draw(torch.randn, shape, generator, device)
+        return latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
 
     # ------------------------------------------------------------------------------------------ one step
     def _step(self, st):
@@ -132,7 +145,7 @@ class I2VAdapterPipeline:
                  callback=None, callback_steps: Optional[int] = 1, cross_attention_kwargs=None, clip_skip=None,
                  frame_similarity_sample_ratio: float = 1, frame_similarity_blurred_strength: float = 0.6,
                  condition_image_latents=None, image_embeds=None, negative_image_embeds=None,
-                 prior_mask_generator=None, prior_noise_generator=None, blur_sigma: float = 1.0,
+                 prior_mask_generator=None, prior_noise_generator=None, blur_sigma: Optional[float] = None,
                  use_graph: bool = True):
         if prompt is not None or condition_image is not None or ip_adapter_image is not None:
             raise NotImplementedError(
@@ -177,21 +190,23 @@ class I2VAdapterPipeline:
         self.scheduler.set_timesteps(num_inference_steps)                                       # pipe:630-631
         timesteps, _ = self.get_timesteps(num_inference_steps, frame_similarity_sample_ratio)
 
-        cond_cpu = condition_image_latents.detach().to("cpu", torch.float32)
+        cond_dev = condition_image_latents.detach().to(dev, torch.float32).contiguous()
         latents = self.prepare_latents(batch_size, self.unet.config.in_channels, num_frames, height, width,
                                        torch.float32, dev, generator, latents)                  # pipe:635-645
-        # first-frame-similarity prior (pipe:647-656), once per sample on the host with explicit generators
-        blurred = gaussian_blur3(cond_cpu, blur_sigma)
-        exp_blur = blurred.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)
-        exp_cond = cond_cpu.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)
-        mask = (torch.rand(exp_cond.shape, generator=prior_mask_generator)
-                < frame_similarity_blurred_strength).float()
-        prior = mask * exp_blur + (1 - mask) * exp_cond
-        noise = torch.randn(prior.shape, generator=prior_noise_generator, dtype=torch.float32)
-        latents = self.scheduler.add_noise(prior, noise, timesteps[0].repeat(batch_size))
+        # first-frame-similarity prior + add_noise (pipe:647-656) in ONE HIP kernel; the reference overwrites the
+        # latents drawn above (its `latents = self.scheduler.add_noise(...)`, pipe:656), and so does this.  The random
+        # draws (blur sigma, mask, noise) take explicit generators (the reference uses the unseeded global RNG).
+        if blur_sigma is None:
+            blur_sigma = draw_blur_sigma(prior_mask_generator)                                  # pipe:112
+        shape = (batch_size, num_frames) + tuple(cond_dev.shape[1:])
+        mask_u = _draw(torch.rand, shape, prior_mask_generator, dev)                            # pipe:652
+        noise = _draw(torch.randn, shape, prior_noise_generator, dev)                           # pipe:655
+        a_t = float(self.scheduler.alphas_cumprod[int(timesteps[0])])
+        latents = K.first_frame_prior(cond_dev, mask_u.contiguous(), noise.contiguous(), blur_sigma,
+                                      frame_similarity_blurred_strength, a_t ** 0.5, (1.0 - a_t) ** 0.5)
 
         st = dict(
-            latents=latents.to(dev).contiguous(), cond=cond_cpu.to(dev).contiguous(), copies=copies,
+            latents=latents, cond=cond_dev, copies=copies,
             num_frames=num_frames, guidance=float(guidance_scale),
             t_table=timesteps.to(torch.float32).to(dev), coef=self.scheduler.step_coefficients(timesteps).to(dev),
             step_idx=torch.zeros(1, dtype=torch.int32, device=dev),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 1
+#define I2V_ABI_VERSION 2
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -210,9 +210,10 @@ int i2v_nchw_to_tokens(const void* src, int32_t src_is_f32, void* dst, int32_t n
 int i2v_tokens_to_nchw(const void* src, int64_t ld, void* dst, int32_t dst_is_f32, int32_t n, int32_t c,
                        int32_t hw, i2v_stream_t stream);
 /* Timesteps(dim, flip_sin_to_cos=True, shift 0): out[b, :] = [cos(t*w) | sin(t*w)] fp16 (unet:763,1336).
- * t is fp32 [n]; if t_index != NULL the single value t[*t_index] is used for every row (graph replay). */
-int i2v_timestep_embedding(const float* t, const int32_t* t_index, void* out, int32_t n, int32_t dim,
-                           i2v_stream_t stream);
+ * t is fp32 [n]; if t_index != NULL, t is a table of t_rows entries and the single value
+ * t[clamp(*t_index, 0, t_rows - 1)] is used for every row (graph replay). */
+int i2v_timestep_embedding(const float* t, const int32_t* t_index, int32_t t_rows, void* out, int32_t n,
+                           int32_t dim, i2v_stream_t stream);
 /* y = silu(x), fp16, n elements (nonlinearity(temb), ResnetBlock2D). */
 int i2v_silu_f16(const void* x, void* y, int64_t n, i2v_stream_t stream);
 /* y[r, :] = x[r / repeat, :]  (repeat_interleave of temb / context rows, unet:1344,1355). */
@@ -227,14 +228,24 @@ int i2v_copy3d_f16(const void* src, int64_t src_batch_stride, int64_t ld_src, vo
  *   prep : latents[:, 0] = cond (pipe:669); model_in = tokens(cat([latents] * cfg_copies)) fp16, channels
  *          padded to c_pad (pipe:672-673; scale_model_input is the identity for DDIM).
  *   step : eps = u + g (c - u) (pipe:686-688); x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);
- *          x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps (pipe:691); then *step_index += 1.
+ *          x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps (pipe:691); then *step_index advances by one
+ *          and wraps to 0 after n_steps (the table row read is clamped to [0, n_steps - 1]).
  * latents fp32 [b, f, c, hw]; cond fp32 [b, c, hw]; noise_pred fp16 tokens [cfg_copies*b*f, hw, ld_np];
  * coef fp32 [n_steps][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}; step_index device int32. */
 int i2v_ddim_prep(float* latents, const float* cond, void* model_in, int32_t b, int32_t f, int32_t c,
                   int32_t hw, int32_t c_pad, int32_t cfg_copies, i2v_stream_t stream);
-int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, const float* coef,
+int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, const float* coef, int32_t n_steps,
                       int32_t* step_index, float guidance_scale, int32_t b, int32_t f, int32_t c, int32_t hw,
                       int32_t cfg_copies, i2v_stream_t stream);
+
+/* First-frame-similarity prior and the initial add_noise of the sampling loop, pipe:647-656:
+ *   prior   = mask * GaussianBlur3x3(cond) + (1 - mask) * cond, mask = (mask_uniform < strength), per frame (pipe:648-654)
+ *   latents = sqrt_alpha * prior + sqrt_one_minus_alpha * noise                          (scheduler.add_noise, pipe:656)
+ * cond fp32 [b, c, h, w]; mask_uniform, noise, latents fp32 [b, f, c, h, w].  The blur is torchvision's
+ * GaussianBlur(kernel_size=3) for one sigma (pipe:112): separable taps (k_edge, k_center, k_edge), reflect padding. */
+int i2v_first_frame_prior_f32(const float* cond, const float* mask_uniform, const float* noise, float* latents,
+                              int32_t b, int32_t f, int32_t c, int32_t h, int32_t w, float k_center, float k_edge,
+                              float strength, float sqrt_alpha, float sqrt_one_minus_alpha, i2v_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -175,7 +175,7 @@ def oracle_goldens():
         out["ddim_latents"] = I2VAdapterPipeline(ou)(
             pe, ne, cond, num_frames=4, num_inference_steps=10, guidance_scale=7.5, frame_similarity_sample_ratio=0.9,
             generator=torch.Generator().manual_seed(5), prior_mask_generator=torch.Generator().manual_seed(6),
-            prior_noise_generator=torch.Generator().manual_seed(7)).frames
+            prior_noise_generator=torch.Generator().manual_seed(7), blur_sigma=1.0).frames
         # add_noise KAT values (test/test_first_frame_pertubation.py): sqrt(alphas_cumprod) of DDPMScheduler(1000)
         sch = DDPMScheduler(1000)
         out["ddpm_sqrt_alphas_cumprod"] = sch.alphas_cumprod ** 0.5

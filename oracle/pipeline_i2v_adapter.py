@@ -48,7 +48,8 @@ class I2VAdapterPipeline:
                  guidance_scale: float = 7.5, eta: float = 0.0, generator=None, latents=None,
                  image_embeds=None, negative_image_embeds=None, frame_similarity_sample_ratio: float = 1,
                  frame_similarity_blurred_strength: float = 0.6, prior_mask_generator=None,
-                 prior_noise_generator=None, blur_sigma: float = 1.0, callback=None, output_type="latent"):
+                 prior_noise_generator=None, blur_sigma: Optional[float] = None, callback=None,
+                 output_type="latent"):
         if condition_image_latents is None:
             raise ValueError("`condition_image_latents` is required (the reference crashes at pipe:648 without "
                              "a condition image)")
@@ -73,7 +74,10 @@ class I2VAdapterPipeline:
         latents = self.prepare_latents(batch_size, self.unet.config.in_channels, num_frames, height, width,
                                        prompt_embeds.dtype, generator, latents)                   # pipe:635-645
 
-        # first-frame-similarity prior, pipe:647-656
+        # first-frame-similarity prior, pipe:647-656.  torchvision GaussianBlur(kernel_size=3) (pipe:112) draws
+        # sigma ~ U(0.1, 2.0) per call; here from the mask generator, before the mask
+        if blur_sigma is None:
+            blur_sigma = float(torch.empty(1).uniform_(0.1, 2.0, generator=prior_mask_generator).item())
         blurred = gaussian_blur3(condition_image_latents, blur_sigma)
         exp_blur = blurred.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)
         exp_cond = condition_image_latents.unsqueeze(1).repeat(1, num_frames, 1, 1, 1)

@@ -316,10 +316,22 @@ def test_temporal_attention(dev, npix, frames, heads, d):
     (2, 4, 4, 1280, 1280, 32, 1, True, False), (8, 5, 7, 40, 0, 4, 2, False, False),
     (2, 32, 32, 320, 0, 32, 2, False, True)])
 def test_groupnorm(dev, n, hh, ww, c1, c2, groups, fps, silu, perm):
+    _groupnorm_case(dev, n, hh, ww, c1, c2, groups, fps, silu, perm, mean=0.5, std=2.0)
+
+
+@pytest.mark.parametrize("mean,std", [(30.0, 0.5), (-200.0, 1.0), (1000.0, 4.0)])
+def test_groupnorm_large_mean(dev, mean, std):
+    """|mean| >> std (real SD activations have such channels): the statistics must not lose their digits to
+    E[x^2] - mean^2 cancellation (per-chunk shifted sums + Chan merge).  Spatial and clip-wide statistics."""
+    _groupnorm_case(dev, 4, 32, 32, 320, 0, 32, 1, True, False, mean=mean, std=std)
+    _groupnorm_case(dev, 4, 16, 16, 64, 64, 32, 2, False, True, mean=mean, std=std)
+
+
+def _groupnorm_case(dev, n, hh, ww, c1, c2, groups, fps, silu, perm, mean, std):
     k = K()
     g = torch.Generator().manual_seed(n + c1)
     c = c1 + c2
-    x = h(torch.randn(n, c, hh, ww, generator=g) * 2 + 0.5)
+    x = h(torch.randn(n, c, hh, ww, generator=g) * std + mean)
     ga, be = h(torch.randn(c, generator=g)), h(torch.randn(c, generator=g))
     if fps == 1:
         ref = F.group_norm(x, groups, ga, be, eps=1e-5)
@@ -386,6 +398,9 @@ def test_timestep_embedding(dev):
     idx = torch.tensor([3], dtype=torch.int32, device=dev)
     out = k.timestep_embedding(t.to(dev), 320, t_index=idx)
     close(out, ref[3:4], rel=2e-3, name="timestep embedding (indexed)")
+    # a step counter past the table (a graph replayed more often than the schedule is long) is clamped, never read past
+    idx.fill_(17)
+    close(k.timestep_embedding(t.to(dev), 320, t_index=idx), ref[4:5], rel=2e-3, name="timestep embedding (clamped)")
 
 
 def test_ddim_prep_and_step(dev):
@@ -422,6 +437,45 @@ def test_ddim_prep_and_step(dev):
     eps = (u + 7.5 * (cnd - u)).permute(0, 3, 1, 2).reshape(b, f, c, hh, ww)
     ref = sch.step(eps, ts[5], ref_lat)
     close(lat_d, ref, rel=1e-5, name="ddim step")
+    # the device-side counter wraps at the end of the coefficient table and a stale index is clamped
+    n = coef.shape[0]
+    step.fill_(n - 1)
+    lat2 = ref_lat.clone().to(dev)
+    k.ddim_cfg_step(lat2, npred.half().to(dev), coef.to(dev), step, 7.5, 2)
+    assert int(step.item()) == 0
+    close(lat2, sch.step(eps, ts[n - 1], ref_lat), rel=1e-5, name="ddim last step")
+    step.fill_(n + 40)
+    lat3 = ref_lat.clone().to(dev)
+    k.ddim_cfg_step(lat3, npred.half().to(dev), coef.to(dev), step, 7.5, 2)
+    assert int(step.item()) == 0 and torch.equal(lat3, lat2)
+
+
+@pytest.mark.parametrize("b,f,c,hh,ww,sigma", [(2, 3, 4, 8, 6, 1.0), (1, 16, 4, 64, 64, 0.37), (2, 2, 4, 1, 5, 1.9)])
+def test_first_frame_prior(dev, b, f, c, hh, ww, sigma):
+    """pipe:647-656 in one kernel vs the oracle's torch ops (torchvision-style 3x3 Gaussian, reflect padding)."""
+    from oracle.blocks import DDIMScheduler, gaussian_blur3
+    k = K()
+    g = torch.Generator().manual_seed(b + f + hh)
+    cond = torch.randn(b, c, hh, ww, generator=g)
+    u = torch.rand(b, f, c, hh, ww, generator=g)
+    noise = torch.randn(b, f, c, hh, ww, generator=g)
+    sch = DDIMScheduler()
+    sch.set_timesteps(25)
+    t = sch.timesteps[2]
+    if hh > 1:
+        blurred = gaussian_blur3(cond, sigma)
+    else:   # a 1-pixel axis cannot be reflect-padded by torch; the kernel degenerates to the centre row
+        xs = torch.linspace(-1.0, 1.0, 3)
+        k1 = torch.exp(-0.5 * (xs / sigma) ** 2)
+        k1 = k1 / k1.sum()
+        xp = F.pad(cond, (1, 1, 0, 0), mode="reflect")
+        blurred = (k1[0] * xp[..., :-2] + k1[1] * xp[..., 1:-1] + k1[2] * xp[..., 2:]) * (k1[1] + 2 * k1[0])
+    mask = (u < 0.6).float()
+    prior = mask * blurred.unsqueeze(1) + (1 - mask) * cond.unsqueeze(1)
+    ref = sch.add_noise(prior, noise, t.repeat(b))
+    a = float(sch.alphas_cumprod[int(t)])
+    out = k.first_frame_prior(cond.to(dev), u.to(dev), noise.to(dev), sigma, 0.6, a ** 0.5, (1 - a) ** 0.5)
+    close(out, ref, rel=2e-6, name="first-frame prior + add_noise")
 
 
 def test_bad_arguments_raise(dev):

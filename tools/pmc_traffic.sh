@@ -3,7 +3,9 @@
 # /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
 # (they do not fit one), no trace domains besides --kernel-trace, FETCH_SIZE doubled on gfx950.
 # Run on the GPU box from the repo root:  bash tools/pmc_traffic.sh   ->  gpurun_out/traffic.json
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+set -e
+cd "${GRAFT_REPO_ROOT:?}"
+export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- \
     python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph > gpurun_out/pmc_$c.log 2>&1
