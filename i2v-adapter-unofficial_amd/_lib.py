@@ -38,6 +38,7 @@ class GemmParams(C.Structure):
         ("out_scale", C.c_float),
         ("n_img", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("cin", C.c_int32),
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32),
+        ("asym_pad", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
@@ -101,6 +102,7 @@ SIGNATURES = {
     "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_groupnorm_f16": (C.c_int, [C.POINTER(GnParams), _P]),
     "i2v_layernorm_f16": (C.c_int, [C.POINTER(LnParams), _P]),
+    "i2v_softmax_rows_f16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "i2v_nchw_to_tokens": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_tokens_to_nchw": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_timestep_embedding": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
@@ -109,6 +111,7 @@ SIGNATURES = {
     "i2v_copy3d_f16": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_int64, _P]),
     "i2v_ddim_prep": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_gaussian_sample_f32": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_first_frame_prior_f32": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32, C.c_int32,

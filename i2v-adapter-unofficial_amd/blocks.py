@@ -181,13 +181,15 @@ class ResnetBlock2D(HipModule):
 
 
 class Downsample2D(HipModule):
-    """A3 (unet:250-259): conv 3x3, stride 2, padding 1."""
+    """A3 (unet:250-259): conv 3x3, stride 2, padding 1.  padding = 0 is the VAE encoder's form: one zero row / column
+    appended at the bottom / right, then the stride-2 conv without padding (the `asym_pad` gather of the conv kernel)."""
 
     def __init__(self, channels, use_conv=True, out_channels=None, padding=1, name="conv"):
         super().__init__()
-        if not use_conv or padding != 1:
-            raise NotImplementedError("hot path uses Downsample2D(use_conv=True, padding=1)")
+        if not use_conv or padding not in (0, 1):
+            raise NotImplementedError("Downsample2D(use_conv=True, padding in {0, 1}) only")
         out_channels = out_channels or channels
+        self.padding = padding
         self.conv = nn.Conv2d(channels, out_channels, 3, stride=2, padding=padding)
 
     def _pack(self):
@@ -195,7 +197,7 @@ class Downsample2D(HipModule):
 
     def _fwd(self, x):
         p = self.packed()
-        return K.conv3x3(x, p["w"], p["b"], stride=2)
+        return K.conv3x3(x, p["w"], p["b"], stride=2, asym_pad=self.padding == 0)
 
     def forward(self, hidden_states, scale: float = 1.0):
         return from_tokens(self._fwd(to_tokens(hidden_states)), hidden_states.dtype)

@@ -177,6 +177,19 @@ __global__ __launch_bounds__(256) void prior_kernel(const float* __restrict__ co
   }
 }
 
+// DiagonalGaussianDistribution.sample of the VAE encoder (pipe:627): moments [n, 2 c, hw] = (mean | logvar) ->
+// mean + exp(0.5 clamp(logvar, -30, 20)) eps
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __restrict__ moments, const float* __restrict__ eps,
+                                                              float* __restrict__ out, int n, int c, int hw) {
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t img = i / ((int64_t)c * hw), rem = i - img * c * hw;
+    const float mean = moments[img * 2 * c * hw + rem];
+    const float logvar = fminf(fmaxf(moments[img * 2 * c * hw + (int64_t)c * hw + rem], -30.f), 20.f);
+    out[i] = mean + expf(0.5f * logvar) * eps[i];
+  }
+}
+
 // the counter wraps at the end of the table: replay n_steps + k of a captured step restarts the schedule at entry k
 __global__ void bump_step_kernel(int32_t* step_index, int n_steps) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -288,4 +301,12 @@ extern "C" int i2v_first_frame_prior_f32(const float* cond, const float* mask_un
                      reinterpret_cast<hipStream_t>(stream), cond, mask_uniform, noise, latents, b, f, c, h, w, k_center,
                      k_edge, strength, sqrt_alpha, sqrt_one_minus_alpha);
   return i2v_check_launch("i2v_first_frame_prior_f32");
+}
+
+extern "C" int i2v_gaussian_sample_f32(const float* moments, const float* eps, float* out, int32_t n, int32_t c,
+                                       int32_t hw, i2v_stream_t stream) {
+  I2V_CHECK_ARG(moments && eps && out && n > 0 && c > 0 && hw > 0, "i2v_gaussian_sample_f32: bad arguments");
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3(ew_blocks((int64_t)n * c * hw)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), moments, eps, out, n, c, hw);
+  return i2v_check_launch("i2v_gaussian_sample_f32");
 }

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
             iy = uy >> 1;
             ix = ux >> 1;
           } else {
-            iy = crow[i].oy * p.stride - 1 + dy;
-            ix = crow[i].ox * p.stride - 1 + dx;
+            iy = crow[i].oy * p.stride - (p.asym_pad ? 0 : 1) + dy;
+            ix = crow[i].ox * p.stride - (p.asym_pad ? 0 : 1) + dx;
             ok = (iy >= 0) && (ix >= 0) && (iy < p.in_h) && (ix < p.in_w);
           }
           if (ok) v = ld_global_16B(A + (int64_t)(crow[i].pix_base + iy * p.in_w + ix) * p.lda + ci);
@@ -349,8 +349,10 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     I2V_CHECK_ARG(p.cin > 0 && p.cin % 8 == 0 && p.K == 9 * p.cin, "i2v_gemm_f16: conv needs cin %% 8 == 0, K == 9 cin");
     I2V_CHECK_ARG(p.stride == 1 || p.stride == 2, "i2v_gemm_f16: conv stride must be 1 or 2");
     I2V_CHECK_ARG(!(p.upsample && p.stride != 1), "i2v_gemm_f16: upsample conv must have stride 1");
-    const int eh = p.upsample ? 2 * p.in_h : (p.in_h + 2 - 3) / p.stride + 1;
-    const int ew = p.upsample ? 2 * p.in_w : (p.in_w + 2 - 3) / p.stride + 1;
+    I2V_CHECK_ARG(!p.asym_pad || (p.stride == 2 && !p.upsample), "i2v_gemm_f16: asym_pad needs stride 2, no upsample");
+    const int padsum = p.asym_pad ? 1 : 2;
+    const int eh = p.upsample ? 2 * p.in_h : (p.in_h + padsum - 3) / p.stride + 1;
+    const int ew = p.upsample ? 2 * p.in_w : (p.in_w + padsum - 3) / p.stride + 1;
     I2V_CHECK_ARG(p.out_h == eh && p.out_w == ew, "i2v_gemm_f16: conv output size mismatch (%d x %d vs %d x %d)",
                   p.out_h, p.out_w, eh, ew);
     I2V_CHECK_ARG((int64_t)p.n_img * p.out_h * p.out_w == p.M, "i2v_gemm_f16: conv M != n_img*out_h*out_w");

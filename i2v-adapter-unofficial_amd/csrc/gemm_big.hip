@@ -147,8 +147,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           iy = uy >> 1;
           ix = ux >> 1;
         } else {
-          iy = c_oy[i] * p.stride - 1 + dy;
-          ix = c_ox[i] * p.stride - 1 + dx;
+          iy = c_oy[i] * p.stride - (p.asym_pad ? 0 : 1) + dy;
+          ix = c_ox[i] * p.stride - (p.asym_pad ? 0 : 1) + dx;
           ok = (iy >= 0) && (ix >= 0) && (iy < p.in_h) && (ix < p.in_w);
         }
         const unsigned voff = ok ? (unsigned)(((c_pix[i] + iy * p.in_w + ix) * (int)p.lda + s_ci + lane_k) * 2) : OOB;

@@ -265,6 +265,48 @@ __global__ __launch_bounds__(256) void ln_kernel(const i2v_ln_params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- row softmax
+// y[r, :] = softmax(scale * x[r, :]) over `cols` columns, one wave per row, fp32 statistics; used by the VAE mid-block
+// attention (one head of dim 512 > the flash kernel's 160: QK^T and PV run as GEMMs around this kernel).  Three passes
+// over the row (max, sum, write): the second and third hit L2.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict__ x, int64_t ldx, f16* __restrict__ y,
+                                                           int64_t ldy, int rows, int cols, float scale_log2) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f16* xr = x + (int64_t)row * ldx;
+  f16* yr = y + (int64_t)row * ldy;
+  const int nvec = cols / 8;
+  float mx = -INFINITY;
+  for (int v = lane; v < nvec; v += 64) {
+    const f16x8 t = ld_global_16B(xr + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)t[e]);
+  }
+  for (int c = nvec * 8 + lane; c < cols; c += 64) mx = fmaxf(mx, (float)xr[c]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  // exp(scale (x - max)) = exp2(scale_log2 x - scale_log2 max)   (scale > 0)
+  const float mb = mx * scale_log2;
+  float sum = 0.f;
+  for (int v = lane; v < nvec; v += 64) {
+    const f16x8 t = ld_global_16B(xr + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f((float)t[e] * scale_log2 - mb);
+  }
+  for (int c = nvec * 8 + lane; c < cols; c += 64) sum += __builtin_amdgcn_exp2f((float)xr[c] * scale_log2 - mb);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int v = lane; v < nvec; v += 64) {
+    const f16x8 t = ld_global_16B(xr + v * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)(__builtin_amdgcn_exp2f((float)t[e] * scale_log2 - mb) * inv);
+    *reinterpret_cast<f16x8*>(yr + v * 8) = o;
+  }
+  for (int c = nvec * 8 + lane; c < cols; c += 64) yr[c] = (f16)(__builtin_amdgcn_exp2f((float)xr[c] * scale_log2 - mb) * inv);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -332,4 +374,15 @@ extern "C" int i2v_layernorm_f16(const i2v_ln_params* pp, i2v_stream_t stream) {
     default: hipLaunchKernelGGL((ln_kernel<8, 1>), dim3((unsigned)i2v_cdiv(p.rows, 4)), block, 0, s, p); break;
   }
   return i2v_check_launch("i2v_layernorm_f16");
+}
+
+extern "C" int i2v_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols,
+                                    float scale, i2v_stream_t stream) {
+  I2V_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= cols, "i2v_softmax_rows_f16: bad arguments");
+  I2V_CHECK_ARG(scale > 0.f, "i2v_softmax_rows_f16: scale must be positive");
+  I2V_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && al16(x) && al16(y), "i2v_softmax_rows_f16: rows must be 16-byte aligned");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)i2v_cdiv(rows, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(x), ldx,
+                     reinterpret_cast<f16*>(y), ldy, rows, cols, scale * 1.4426950408889634f);
+  return i2v_check_launch("i2v_softmax_rows_f16");
 }

@@ -125,9 +125,10 @@ def _attach_splitk_workspace(lib, p, device):
 
 
 def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
-            out_scale=1.0):
+            out_scale=1.0, asym_pad=False):
     """3x3 / pad 1 convolution of a token-major image x [N, H, W, Cin] with w_packed [Cout, 9 * Cin]
-    (k = (ky * 3 + kx) * Cin + ci); optional nearest-2x upsampling of the input first."""
+    (k = (ky * 3 + kx) * Cin + ci); optional nearest-2x upsampling of the input first.  asym_pad (stride 2): no
+    padding at the top / left, one zero row / column at the bottom / right (the VAE encoder's Downsample2D(padding=0))."""
     lib = _lib.load()
     _req(x, "x")
     if x.dim() != 4 or not x.is_contiguous():
@@ -137,12 +138,15 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     cout, K = w_packed.shape
     if K != 9 * cin:
         raise ValueError(f"w_packed is {tuple(w_packed.shape)} but x has {cin} channels")
+    if asym_pad and (stride != 2 or upsample):
+        raise ValueError("asym_pad needs stride 2 and no upsampling")
     if upsample:
         if stride != 1:
             raise ValueError("upsample conv must have stride 1")
         oh, ow = 2 * h, 2 * wd
     else:
-        oh, ow = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+        padsum = 1 if asym_pad else 2
+        oh, ow = (h + padsum - 3) // stride + 1, (wd + padsum - 3) // stride + 1
     M = n * oh * ow
     out = torch.empty((n, oh, ow, cout), dtype=f16, device=x.device)
     p = GemmParams()
@@ -170,6 +174,7 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     p.out_scale = out_scale
     p.n_img, p.in_h, p.in_w, p.cin = n, h, wd, cin
     p.out_h, p.out_w, p.stride, p.upsample = oh, ow, stride, 1 if upsample else 0
+    p.asym_pad = 1 if asym_pad else 0
     ws = _attach_splitk_workspace(lib, p, x.device)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16(conv3x3)")
     del ws
@@ -313,6 +318,20 @@ def layernorm(x, gamma, beta, eps, *, pe=None, pe_period=0):
     return y
 
 
+def softmax_rows(x, scale=1.0, out=None):
+    """row-wise softmax(scale * x) of a 2-D fp16 matrix (in place when out is x)."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    if out is None:                      # rows start on 16-byte boundaries: leading dimension rounded up to 8
+        out = torch.empty((x.shape[0], pad8(x.shape[1])), dtype=f16, device=x.device)[:, : x.shape[1]]
+    out, ldy = _mat(out, "out")
+    if out.shape != x.shape:
+        raise ValueError("softmax_rows: out must have x's shape")
+    _lib.check(lib.i2v_softmax_rows_f16(_p(x), ldx, _p(out), ldy, x.shape[0], x.shape[1], float(scale), _stream()),
+               "i2v_softmax_rows_f16")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- edges / misc
 def nchw_to_tokens(src, c_pad=None):
     """[N, C, H, W] (fp32 or fp16) -> token-major fp16 [N, H, W, c_pad]."""
@@ -411,6 +430,20 @@ def first_frame_prior(cond, mask_uniform, noise, sigma, strength, sqrt_alpha, sq
     _lib.check(lib.i2v_first_frame_prior_f32(_p(cond), _p(mask_uniform), _p(noise), _p(out), b, f, c, h, w, kc, ke,
                                              float(strength), float(sqrt_alpha), float(sqrt_one_minus_alpha),
                                              _stream()), "i2v_first_frame_prior_f32")
+    return out
+
+
+def gaussian_sample(moments, eps):
+    """mean + exp(0.5 clamp(logvar, -30, 20)) * eps for moments fp32 [N, 2C, H, W] = (mean | logvar), eps fp32 [N, C, H, W]."""
+    lib = _lib.load()
+    _req(moments, "moments", dtype=torch.float32)
+    _req(eps, "eps", dtype=torch.float32)
+    n, c2, h, w = moments.shape
+    if c2 % 2 != 0 or tuple(eps.shape) != (n, c2 // 2, h, w) or not moments.is_contiguous() or not eps.is_contiguous():
+        raise ValueError(f"moments {tuple(moments.shape)} / eps {tuple(eps.shape)} mismatch")
+    out = torch.empty_like(eps)
+    _lib.check(lib.i2v_gaussian_sample_f32(_p(moments), _p(eps), _p(out), n, c2 // 2, h * w, _stream()),
+               "i2v_gaussian_sample_f32")
     return out
 
 

@@ -9,8 +9,10 @@ scalars (t, sqrt(a_t), ...) are read on the device from small tables indexed by 
 there is no per-step host<->device traffic and no per-step sync (the reference syncs once per step on
 `alphas_cumprod[t]`).
 
-Out of scope here: CLIP text / image encoders, VAE encode / decode, PIL / GIF I/O.
-The loop takes `prompt_embeds`, `negative_prompt_embeds`, `condition_image_latents` and optional `image_embeds`.
+Either side of the loop: the condition image is encoded and the final latents are decoded by the HIP
+AutoencoderKL (vae.py: pipe:300-320, 626-627) when a `vae` is given; pre / post-processing, `tensor2vid` and GIF
+export are host-side plumbing (image_processor.py).  Out of scope: the CLIP text / image
+encoders -- pass `prompt_embeds`, `negative_prompt_embeds` and optional `image_embeds`.
 """
 from typing import Optional
 
@@ -19,6 +21,7 @@ import torch
 from . import kernels as K
 from ._lib import HipLibraryError
 from .blocks import DDIMScheduler
+from .image_processor import VaeImageProcessor, tensor2vid
 from .unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel
 
 f16 = torch.float16
@@ -64,8 +67,41 @@ class I2VAdapterPipeline:
         self.motion_adapter, self.i2v_adapter = motion_adapter, i2v_adapter
         self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
         self.feature_extractor, self.image_encoder = feature_extractor, image_encoder
+        if vae is not None:                                                                  # pipe:110-111
+            self.vae_scale_factor = 2 ** (len(vae.config["block_out_channels"]) - 1)
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
+        self._vae_slicing = False
         self._graph = None
         self._graph_key = None
+
+    def enable_vae_slicing(self):
+        """pipe:122-128: decode the frames one at a time (peak activation memory / num_frames)."""
+        self._vae_slicing = True
+
+    def disable_vae_slicing(self):
+        self._vae_slicing = False
+
+    def decode_latents(self, latents):
+        """pipe:300-320: latents (B, F, 4, h, w) -> video (B, F, 3, 8h, 8w) float32 through the HIP VAE decoder."""
+        if self.vae is None:
+            raise ValueError("decode_latents needs a `vae` (AutoencoderKL) -- or use output_type='latent'")
+        latents = 1 / self.vae.config["scaling_factor"] * latents
+        b, f, c, h, w = latents.shape
+        flat = latents.reshape(b * f, c, h, w)
+        if self._vae_slicing:
+            image = torch.cat([self.vae.decode(flat[i: i + 1]).sample for i in range(b * f)])
+        else:
+            image = self.vae.decode(flat).sample
+        return image[None, :].reshape((b, f, -1) + image.shape[2:]).float()
+
+    def encode_condition_image(self, condition_image, height, width, generator=None):
+        """pipe:626-627: preprocess -> vae.encode(...).latent_dist.sample() * scaling_factor."""
+        if self.vae is None:
+            raise ValueError("a `condition_image` needs a `vae` (AutoencoderKL) -- or pass `condition_image_latents`")
+        img = self.image_processor.preprocess(condition_image, height=height, width=width).to(self.vae.device)
+        if isinstance(generator, list):
+            generator = generator[0]
+        return self.vae.encode(img).latent_dist.sample(generator) * self.vae.config["scaling_factor"]
 
     def load_i2v_adapter(self, i2v_adapter):
         self.unet.load_i2v_adapter(i2v_adapter)
@@ -147,16 +183,23 @@ class I2VAdapterPipeline:
                  condition_image_latents=None, image_embeds=None, negative_image_embeds=None,
                  prior_mask_generator=None, prior_noise_generator=None, blur_sigma: Optional[float] = None,
                  use_graph: bool = True):
-        if prompt is not None or condition_image is not None or ip_adapter_image is not None:
+        if prompt is not None or ip_adapter_image is not None:
             raise NotImplementedError(
-                "text / image encoders and the VAE are out of scope of this build (SURVEY section 2 row 3b): pass "
-                "`prompt_embeds`, `negative_prompt_embeds`, `condition_image_latents` (and `image_embeds`)")
+                "the CLIP text / image encoders are out of scope of this build (SURVEY section 2 row 3b): pass "
+                "`prompt_embeds`, `negative_prompt_embeds` (and `image_embeds`)")
         if prompt_embeds is None:
             raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and "
                              "`prompt_embeds` undefined.")
+        if condition_image is not None and condition_image_latents is None:                     # pipe:624-627
+            if height is None or width is None:
+                height = height or self.unet.config.sample_size * self.vae_scale_factor         # pipe:568-569
+                width = width or self.unet.config.sample_size * self.vae_scale_factor
+            if height % 8 != 0 or width % 8 != 0:                                               # pipe:213-214
+                raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+            condition_image_latents = self.encode_condition_image(condition_image, height, width, generator)
         if condition_image_latents is None:
-            raise ValueError("`condition_image_latents` is required: the reference's prior (pipe:647-656) needs the "
-                             "condition image and crashes without it")
+            raise ValueError("`condition_image` (or `condition_image_latents`) is required: the reference's prior "
+                             "(pipe:647-656) needs the condition image and crashes without it")
         if eta != 0.0:
             raise NotImplementedError("eta = 0 on the hot path (pipe:550)")
         if callback is not None and use_graph:
@@ -169,6 +212,10 @@ class I2VAdapterPipeline:
         width = width or w_lat * self.vae_scale_factor
         if height % 8 != 0 or width % 8 != 0:                                                   # pipe:213-214
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        up = 2 ** self.unet.num_upsamplers
+        if h_lat % up != 0 or w_lat % up != 0:
+            raise ValueError(f"latent height / width ({h_lat} x {w_lat}) must be multiples of {up}: the reference's "
+                             "forward_upsample_size branch (unet:1304-1311) is not implemented")
         assert 0 < frame_similarity_sample_ratio <= 1, (
             f'"frame_similarity_sample_ratio" for img2vid must in (0, 1]. But receive {frame_similarity_sample_ratio}.')
         batch_size = prompt_embeds.shape[0]
@@ -222,8 +269,12 @@ class I2VAdapterPipeline:
                     callback(i, t, st["latents"])
         latents = st["latents"]
         latents[:, 0] = st["cond"]                                                              # pipe:699-700
-        if output_type != "latent":
-            raise NotImplementedError("VAE decode is out of scope: use output_type='latent'")
+        if output_type == "latent":                                                             # pipe:702-703
+            video = latents
+        else:
+            video_tensor = self.decode_latents(latents)                                         # pipe:706
+            video = video_tensor if output_type == "pt" else tensor2vid(video_tensor, self.image_processor,
+                                                                        output_type=output_type)  # pipe:708-711
         if not return_dict:
-            return (latents,)
-        return I2VAdapterPipelineOutput(frames=latents)
+            return (video,)
+        return I2VAdapterPipelineOutput(frames=video)

@@ -99,8 +99,10 @@ typedef struct i2v_gemm_params {
   float out_scale;
   /* I2V_A_CONV3X3 geometry: input image [n_img, in_h, in_w, cin] fp16 (pixel stride = lda elements),
      3x3 kernel, padding 1, `stride` 1 or 2; `upsample` = 1 applies nearest-2x to the input first
-     (Upsample2D).  M = n_img * out_h * out_w. */
-  int32_t n_img, in_h, in_w, cin, out_h, out_w, stride, upsample;
+     (Upsample2D).  `asym_pad` = 1 (stride 2 only): no padding at the top / left and one zero row / column at the
+     bottom / right = diffusers Downsample2D(padding=0) of the VAE encoder (F.pad(x, (0, 1, 0, 1)) + conv stride 2).
+     M = n_img * out_h * out_w. */
+  int32_t n_img, in_h, in_w, cin, out_h, out_w, stride, upsample, asym_pad;
   /* optional fp32 scratch for split-K (small M, long K: the 8 x 8 level's convolutions): when it holds at least
      i2v_gemm_workspace_bytes(p) bytes the K loop is split over several workgroups whose fp32 partial tiles are
      summed by a second kernel that applies the epilogue; NULL / too small => no split. */
@@ -199,6 +201,12 @@ typedef struct i2v_ln_params {
 
 int i2v_layernorm_f16(const i2v_ln_params* p, i2v_stream_t stream);
 
+/* y[r, :cols] = softmax(scale * x[r, :cols]) row-wise, fp16 in / out, fp32 statistics (in place allowed).  The VAE
+ * mid-block attention (diffusers Attention with ONE head of dim 512, AutoencoderKL decode / encode, pipe:305,627)
+ * exceeds the flash kernel's head_dim limit: its QK^T and PV products run as i2v_gemm_f16 calls around this kernel. */
+int i2v_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, float scale,
+                         i2v_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Layout edges, embeddings and the sampler step
  * ------------------------------------------------------------------------------------------------ */
@@ -246,6 +254,12 @@ int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, con
 int i2v_first_frame_prior_f32(const float* cond, const float* mask_uniform, const float* noise, float* latents,
                               int32_t b, int32_t f, int32_t c, int32_t h, int32_t w, float k_center, float k_edge,
                               float strength, float sqrt_alpha, float sqrt_one_minus_alpha, i2v_stream_t stream);
+
+/* DiagonalGaussianDistribution.sample() of the VAE encoder (vae.encode(image).latent_dist.sample(), pipe:627):
+ * moments fp32 [n, 2 c, hw] = (mean | logvar) along the channel axis; out = mean + exp(0.5 clamp(logvar, -30, 20)) eps,
+ * eps / out fp32 [n, c, hw]. */
+int i2v_gaussian_sample_f32(const float* moments, const float* eps, float* out, int32_t n, int32_t c, int32_t hw,
+                            i2v_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -80,14 +80,18 @@ class ResnetBlock2D(nn.Module):
 
 
 class Downsample2D(nn.Module):
-    """A3.  unet:250-259: Conv2d(C, C, 3, stride 2, padding=downsample_padding)."""
+    """A3.  unet:250-259: Conv2d(C, C, 3, stride 2, padding=downsample_padding).  padding = 0 (the VAE encoder's
+    DownEncoderBlock2D): the input is first padded by one zero row / column at the bottom / right."""
 
     def __init__(self, channels, use_conv=True, out_channels=None, padding=1, name="conv"):
         super().__init__()
         out_channels = out_channels or channels
+        self.padding = padding
         self.conv = nn.Conv2d(channels, out_channels, 3, stride=2, padding=padding)
 
     def forward(self, hidden_states, scale: float = 1.0):
+        if self.padding == 0:
+            hidden_states = F.pad(hidden_states, (0, 1, 0, 1), mode="constant", value=0)
         return self.conv(hidden_states)
 
 

@@ -155,3 +155,46 @@ def test_checkpoint_roundtrip_reference_file_layout(tmp_path):
     assert all(v.num_tokens == 0 for v in m.attn_processors.values())
     with pytest.raises(ValueError, match="number of processors"):
         m.set_attn_processor({"x": procs[next(iter(procs))]})
+
+
+def test_vae_container_layout_and_image_plumbing(tmp_path):
+    """AutoencoderKL mirrors diffusers' SD-1.5 VAE state-dict layout (248 tensors) and round-trips through the
+    reference's checkpoint files; VaeImageProcessor pre / post-processing and GIF export are host-side plumbing."""
+    import numpy as np
+    import PIL.Image
+    p = pkg()
+    with torch.device("meta"):
+        v = p.AutoencoderKL()
+    sd = {k: tuple(t.shape) for k, t in v.state_dict().items()}
+    assert len(sd) == 248
+    assert sd["encoder.conv_in.weight"] == (128, 3, 3, 3) and sd["encoder.conv_out.weight"] == (8, 512, 3, 3)
+    assert sd["encoder.down_blocks.1.resnets.0.conv_shortcut.weight"] == (256, 128, 1, 1)
+    assert sd["encoder.down_blocks.2.downsamplers.0.conv.weight"] == (512, 512, 3, 3)
+    assert "encoder.down_blocks.3.downsamplers.0.conv.weight" not in sd
+    assert sd["decoder.mid_block.attentions.0.to_q.weight"] == (512, 512) and sd["decoder.mid_block.attentions.0.to_q.bias"] == (512,)
+    assert sd["decoder.mid_block.attentions.0.group_norm.weight"] == (512,)
+    assert sd["decoder.up_blocks.2.resnets.0.conv_shortcut.weight"] == (256, 512, 1, 1)
+    assert sd["decoder.up_blocks.3.resnets.2.conv2.weight"] == (128, 128, 3, 3) and "decoder.up_blocks.3.upsamplers.0.conv.weight" not in sd
+    assert sd["decoder.conv_out.weight"] == (3, 128, 3, 3) and sd["quant_conv.weight"] == (8, 8, 1, 1)
+    assert sd["post_quant_conv.weight"] == (4, 4, 1, 1)
+    from oracle.vae import AutoencoderKL as O
+    with torch.device("meta"):
+        assert {k: tuple(t.shape) for k, t in O().state_dict().items()} == sd
+    small = p.AutoencoderKL(block_out_channels=(32, 64, 64, 64), norm_num_groups=8)
+    small.save_pretrained(str(tmp_path / "vae"))
+    back = p.AutoencoderKL.from_pretrained(str(tmp_path / "vae"))
+    assert back.config["scaling_factor"] == 0.18215 and tuple(back.config["block_out_channels"]) == (32, 64, 64, 64)
+    assert all(torch.equal(a, b) for a, b in zip(small.state_dict().values(), back.state_dict().values()))
+    with pytest.raises(p.HipLibraryError, match="no CPU fallback"):
+        small.decode(torch.zeros(1, 4, 4, 4))
+    proc = p.VaeImageProcessor(vae_scale_factor=8)
+    rgb = (np.random.RandomState(0).rand(37, 50, 3) * 255).astype("uint8")
+    t = proc.preprocess(PIL.Image.fromarray(rgb), height=32, width=48)
+    assert t.shape == (1, 3, 32, 48) and -1.0 <= t.min() and t.max() <= 1.0
+    t2 = proc.preprocess(PIL.Image.fromarray(rgb[:32, :48]))
+    assert torch.equal(t2, torch.from_numpy(rgb[:32, :48].astype("float32") / 255).permute(2, 0, 1)[None] * 2 - 1)
+    pil = proc.postprocess(t2, "pil")
+    assert np.array_equal(np.asarray(pil[0]), rgb[:32, :48])
+    vid = p.tensor2vid(t2[None].repeat(1, 3, 1, 1, 1), proc, "pil")
+    path = p.export_to_gif(vid[0], str(tmp_path / "x.gif"))
+    assert PIL.Image.open(path).n_frames >= 1

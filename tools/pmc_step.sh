@@ -12,3 +12,5 @@ CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_a -- $CMD > gpurun_out/${tag}_a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d gpurun_out/${tag}_b -- $CMD > gpurun_out/${tag}_b.log 2>&1
 python tools/summarize_pmc.py gpurun_out/${tag}_a gpurun_out/${tag}_b gpurun_out/${tag}_summary.txt
+# the raw per-dispatch CSVs are tens of MB (gpurun merges at most 64 MiB back): keep the summary only
+[ -n "$KEEP_RAW" ] || rm -rf gpurun_out/${tag}_a gpurun_out/${tag}_b

@@ -11,3 +11,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
     python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph > gpurun_out/pmc_$c.log 2>&1
 done
 python tools/summarize_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/traffic.json
+[ -n "$KEEP_RAW" ] || rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE

@@ -8,7 +8,7 @@ from i2v_adapter_unofficial_amd import kernels as K
 from i2v_adapter_unofficial_amd import profiling
 
 dev = torch.device("cuda:0")
-model = bench.build_hip_model(dev)
+model = bench.build_hip_model(dev, seed=1)
 with torch.no_grad():
     for p in model.parameters():
         p.normal_(0, 0.02)
