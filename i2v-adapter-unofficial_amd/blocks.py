@@ -645,7 +645,11 @@ class DDIMScheduler:
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
                  beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
-                 timestep_spacing="linspace", prediction_type="epsilon"):
+                 timestep_spacing="linspace", prediction_type="epsilon", **_unused):
+        self.config = dict(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                           beta_schedule=beta_schedule, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
+                           steps_offset=steps_offset, timestep_spacing=timestep_spacing,
+                           prediction_type=prediction_type)
         if beta_schedule == "scaled_linear":
             self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
                                         dtype=torch.float32) ** 2
@@ -662,6 +666,25 @@ class DDIMScheduler:
         self.timestep_spacing = timestep_spacing
         self.num_inference_steps = None
         self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.int64)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path: str, subfolder: Optional[str] = None, **overrides):
+        """pipe:755-757: `DDIMScheduler.from_pretrained(model_path, subfolder="scheduler", clip_sample=False,
+        timestep_spacing="linspace", steps_offset=1)`: scheduler_config.json + keyword overrides."""
+        import json
+        import os
+        path = os.path.join(pretrained_model_path, subfolder) if subfolder else pretrained_model_path
+        with open(os.path.join(path, "scheduler_config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        cfg.update(overrides)
+        return cls(**cfg)
+
+    def save_pretrained(self, save_directory: str):
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "scheduler_config.json"), "w") as f:
+            json.dump({"_class_name": "DDIMScheduler", **self.config}, f, indent=2, sort_keys=True)
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         import numpy as np

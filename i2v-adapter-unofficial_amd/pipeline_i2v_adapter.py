@@ -103,6 +103,14 @@ class I2VAdapterPipeline:
             generator = generator[0]
         return self.vae.encode(img).latent_dist.sample(generator) * self.vae.config["scaling_factor"]
 
+    def to(self, device=None, dtype=None):
+        """move the models the pipeline holds (pipe:784); fp16 is the storage dtype of the HIP path."""
+        for name in ("unet", "vae"):
+            m = getattr(self, name)
+            if m is not None:
+                setattr(self, name, m.to(device=device, dtype=dtype))
+        return self
+
     def load_i2v_adapter(self, i2v_adapter):
         self.unet.load_i2v_adapter(i2v_adapter)
         self.i2v_adapter = i2v_adapter
@@ -278,3 +286,106 @@ class I2VAdapterPipeline:
         if not return_dict:
             return (video,)
         return I2VAdapterPipelineOutput(frames=video)
+
+
+def main(argv=None):
+    """The reference's evaluation driver (pipe:721-809, the README command
+    `python src/pipelines/pipeline_i2v_adapter.py --task_name ... --checkpoint_epoch ...`): load MotionAdapter /
+    I2VAdapterModule / SD-1.5 UNet + VAE / IP-Adapter from the reference's directory layout, read the CSV of
+    (image_path, name) pairs, sample 16 frames per pair and write one GIF per prompt.
+
+    The CLIP text / image encoders are out of scope of this build, so the per-row `prompt_embeds`,
+    `negative_prompt_embeds` (and `image_embeds`) come from a safetensors file (--embeds) written by
+    `src/tools/encode_text.py`-style tooling; everything else follows the reference driver."""
+    import argparse
+    import logging
+    import os
+
+    import pandas as pd
+    import PIL.Image
+    from safetensors.torch import load_file
+
+    from .blocks import MotionAdapter
+    from .i2v_adapter import I2VAdapterModule
+    from .image_processor import export_to_gif
+    from .unet_motion_cross_frame_attn import UNet2DConditionModel
+    from .vae import AutoencoderKL
+
+    logger = logging.getLogger("i2v_adapter_pipeline")
+    logging.basicConfig(level=logging.INFO)
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--checkpoint_epoch", type=int, default=0)
+    parser.add_argument("--eval_data_path", type=str, default="./data/WebVid-10M/I2VAdapter-eval.csv")
+    parser.add_argument("--task_name", type=str)
+    parser.add_argument("--embeds", type=str, required=True,
+                        help="safetensors with prompt_embeds [N,77,768], negative_prompt_embeds [N or 1,77,768], "
+                             "optional image_embeds [N,1024] (row i = CSV row i)")
+    parser.add_argument("--model_path", type=str, default="./SG161222_Realistic_Vision_V5.1_noVAE/")
+    parser.add_argument("--motion_adapter_path", type=str, default="./animatediff-motion-adapter-v1-5-2")
+    parser.add_argument("--ip_adapter_path", type=str, default="./IP-Adapter/")
+    parser.add_argument("--checkpoint_root", type=str, default="./checkpoint")
+    parser.add_argument("--samples_root", type=str, default="./samples")
+    parser.add_argument("--num_frames", type=int, default=16)
+    parser.add_argument("--num_inference_steps", type=int, default=25)
+    parser.add_argument("--height", type=int, default=None)
+    parser.add_argument("--width", type=int, default=None)
+    parser.add_argument("--seed", type=int, default=0)
+    args = parser.parse_args(argv)
+    if args.task_name is None:
+        logger.error("Checkpoint `task_name` must be specified.")
+        return -1
+
+    i2v_adapter = None
+    motion_adapter = MotionAdapter.from_pretrained(args.motion_adapter_path)                     # pipe:734
+    checkpoint_path = os.path.join(args.checkpoint_root, args.task_name, f"epoch_{args.checkpoint_epoch}")
+    i2v_adapter_path = os.path.join(checkpoint_path, "i2v_adapter")
+    if not os.path.exists(i2v_adapter_path):
+        logger.warning(f"Fatal! Checkpoint path {i2v_adapter_path} for I2VAdapterModule doesnot exist!")
+    else:
+        i2v_adapter = I2VAdapterModule.from_pretrained(i2v_adapter_path)                         # pipe:741
+        logger.info(f"Successfully loaded I2VAdapterModule from {i2v_adapter_path}.")
+    motion_adapter_path = os.path.join(checkpoint_path, "motion_modules")
+    if os.path.exists(motion_adapter_path):
+        motion_adapter = MotionAdapter.from_pretrained(motion_adapter_path)                      # pipe:745
+        logger.info(f"Successfully loaded MotionModule from {motion_adapter_path}.")
+
+    device = torch.device("cuda")                                # there is no CPU path (the reference falls back to it)
+    unet2d = UNet2DConditionModel.from_pretrained(os.path.join(args.model_path, "unet"))         # pipe:751
+    vae = AutoencoderKL.from_pretrained(os.path.join(args.model_path, "vae"))                    # pipe:754
+    scheduler = DDIMScheduler.from_pretrained(args.model_path, subfolder="scheduler", clip_sample=False,
+                                              timestep_spacing="linspace", steps_offset=1)       # pipe:755-757
+
+    eval_data_dir = os.path.dirname(args.eval_data_path)                                         # pipe:759-768
+    eval_data_df = pd.read_csv(args.eval_data_path)
+    condition_images = [PIL.Image.open(os.path.join(eval_data_dir, p)) for p in eval_data_df["image_path"]]
+    eval_prompts = eval_data_df["name"].tolist()
+    emb = load_file(args.embeds)
+    n = len(eval_prompts)
+    if emb["prompt_embeds"].shape[0] != n:
+        raise ValueError(f"{args.embeds} holds {emb['prompt_embeds'].shape[0]} prompt embeddings for {n} CSV rows")
+
+    pipe = I2VAdapterPipeline(vae, None, None, unet2d.to(device).half(), motion_adapter, i2v_adapter, scheduler)
+    if "image_embeds" in emb:                                                                    # pipe:783
+        pipe.load_ip_adapter(args.ip_adapter_path, subfolder="models", weight_name="ip-adapter_sd15.bin")
+    pipe.to(device, torch.float16)
+    pipe.enable_vae_slicing()                                                                    # pipe:787
+
+    sample_save_dir = os.path.join(args.samples_root, args.task_name, f"epoch_{args.checkpoint_epoch}")
+    os.makedirs(sample_save_dir, exist_ok=True)
+    neg = emb["negative_prompt_embeds"]
+    for ind in range(n):                                         # one sample per call: every sample replays the graph
+        g = lambda k: torch.Generator().manual_seed(args.seed * 1000 + 10 * ind + k)
+        out = pipe(prompt_embeds=emb["prompt_embeds"][ind: ind + 1],
+                   negative_prompt_embeds=neg[ind: ind + 1] if neg.shape[0] == n else neg[:1],
+                   image_embeds=emb["image_embeds"][ind: ind + 1] if "image_embeds" in emb else None,
+                   condition_image=condition_images[ind], num_frames=args.num_frames, guidance_scale=7.5,
+                   num_inference_steps=args.num_inference_steps, frame_similarity_sample_ratio=0.9,
+                   height=args.height, width=args.width, output_type="pil", generator=g(0),
+                   prior_mask_generator=g(1), prior_noise_generator=g(2))                        # pipe:790-799
+        export_to_gif(out.frames[0], os.path.join(sample_save_dir, f"{eval_prompts[ind]}.gif"))  # pipe:806-807
+    logger.info(f"Finish sampling {n} instances, the results saved to {sample_save_dir}.")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
