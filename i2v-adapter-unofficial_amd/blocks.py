@@ -8,6 +8,7 @@ images are [N, H, W, C] tensors, token matrices are [rows, C]; the public `forwa
 reference's NCHW tensors and convert at the edge.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -67,6 +68,47 @@ def pack_geglu(weight, bias):
     w = torch.stack([weight[:inner], weight[inner:]], dim=1).reshape(2 * inner, weight.shape[1])
     b = torch.stack([bias[:inner], bias[inner:]], dim=1).reshape(2 * inner)
     return w16(w), w16(b)
+
+
+# LayerNorm folded into the consuming GEMMs (i2v_gemm_params.ln_stats); I2V_LN_FOLD=0 keeps the materialised LayerNorm
+# everywhere (same-box A/B)
+LN_FOLD = os.environ.get("I2V_LN_FOLD", "1") != "0"
+
+
+def fold_layernorm(weight, bias, gamma, beta):
+    """LayerNorm(gamma, beta) followed by Linear(weight, bias), as the operands of a LayerNorm-folded GEMM:
+        (LN(x) W^T + b)[m][n] = rstd_m (x W'^T - mean_m wsum)[m][n] + b'[n]
+    with W' = W o gamma (fp16), wsum = row sums of the fp16-ROUNDED W' (fp32: the mean term must cancel against what
+    the MFMA actually multiplies), b' = W beta + b (fp16)."""
+    wf = (weight.detach().float() * gamma.detach().float()[None, :]).to(f16).contiguous()
+    wsum = wf.float().sum(dim=1).contiguous()
+    b = weight.detach().float() @ beta.detach().float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    return wf, wsum, b.to(f16).contiguous()
+
+
+def fold_layernorm_geglu(proj_weight, proj_bias, gamma, beta):
+    """the same for a GEGLU projection, rows interleaved (value_i, gate_i) like pack_geglu."""
+    wf, wsum, b = fold_layernorm(proj_weight, proj_bias, gamma, beta)
+    inner = wf.shape[0] // 2
+    il = lambda t: torch.stack([t[:inner], t[inner:]], dim=1).reshape((2 * inner,) + tuple(t.shape[1:])).contiguous()
+    return il(wf), il(wsum), il(b)
+
+
+class LnFoldPlan:
+    """per-module cache of `does the library fold the LayerNorm for this problem?` answers (i2v_gemm_ln_supported),
+    keyed by the problem shape: the fold is used at a LayerNorm site only when EVERY consumer of that site supports it."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, key, probe):
+        if not LN_FOLD:
+            return False
+        if key not in self._cache:
+            self._cache[key] = bool(probe())
+        return self._cache[key]
 
 
 def to_tokens(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
@@ -358,6 +400,25 @@ class FeedForward(HipModule):
         h = K.gemm(n2d, p["w1"], p["b1"], epilogue=epi)
         return K.gemm(h, p["w2"], p["b2"], residual=residual2d, **store)
 
+    def fold_norm(self, norm):
+        """(W', wsum, b') of `norm` (LayerNorm) followed by the first projection, or None when the activation has no
+        LayerNorm-folded epilogue."""
+        if self.activation_fn != "geglu":
+            return None
+        proj = self.net[0].proj
+        return fold_layernorm_geglu(proj.weight, proj.bias, norm.weight, norm.bias)
+
+    def _fwd_folded(self, x2d, stats, folded, **store):
+        """x + FF(LayerNorm(x)) with the LayerNorm folded into the GEGLU projection (x2d is the UN-normalised input)."""
+        p = self.packed()
+        wf, wsum, bf = folded
+        h = K.gemm(x2d, wf, bf, epilogue=I2V_EPI_GEGLU, ln=(stats, wsum))
+        return K.gemm(h, p["w2"], p["b2"], residual=x2d, **store)
+
+    def folded_supported(self, x2d, stats, folded):
+        wf, wsum, bf = folded
+        return K.gemm(x2d, wf, bf, epilogue=I2V_EPI_GEGLU, ln=(stats, wsum), query_ln_support=True)
+
     def forward(self, hidden_states, scale: float = 1.0):
         x = _as_f16_matrix(hidden_states)
         shp = x.shape
@@ -412,6 +473,7 @@ class TemporalTransformerBlock(HipModule):
                                dropout=dropout, bias=attention_bias)
         self.norm3 = nn.LayerNorm(dim, elementwise_affine=norm_elementwise_affine, eps=norm_eps)
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
+        self._plan = LnFoldPlan()
 
     def _pack(self):
         p = dict(pe=w16(self.pos_embed.pe[0]))
@@ -421,7 +483,35 @@ class TemporalTransformerBlock(HipModule):
             p[f"wv{i}"] = w16(attn.to_v.weight)
             p[f"wo{i}"], p[f"bo{i}"] = w16(attn.to_out[0].weight), w16(attn.to_out[0].bias)
         p["g3"], p["b3"] = w16(self.norm3.weight), w16(self.norm3.bias)
+        # LayerNorm(+ positional table) folded into the q|k and V^T projections, LayerNorm 3 into the GEGLU projection:
+        # (LN(t) + pe[f]) W^T = rstd (t W'^T - mean wsum) + W beta + pe[f] W^T
+        pe = self.pos_embed.pe[0].detach().float()
+        for i, (norm, attn) in enumerate(((self.norm1, self.attn1), (self.norm2, self.attn2)), 1):
+            wqk = torch.cat([attn.to_q.weight, attn.to_k.weight], dim=0)
+            p[f"f_wqk{i}"], p[f"f_sqk{i}"], p[f"f_cqk{i}"] = fold_layernorm(wqk, None, norm.weight, norm.bias)
+            p[f"f_peqk{i}"] = (pe @ wqk.detach().float().T).to(f16).contiguous()                      # [max_len, 2C]
+            p[f"f_wv{i}"], p[f"f_sv{i}"], p[f"f_cv{i}"] = fold_layernorm(attn.to_v.weight, None, norm.weight, norm.bias)
+            p[f"f_pev{i}"] = (pe @ attn.to_v.weight.detach().float().T).T.to(f16).contiguous()       # [C, max_len]
+        p["f_ff"] = self.ff.fold_norm(self.norm3)
         return p
+
+    def _fold_ok(self, t, frames):
+        """(attention sites, feed-forward site): is the LayerNorm fold implemented for this problem's GEMMs?"""
+        def probe_attn():
+            p = self.packed()
+            st = torch.empty((t.shape[0], 2), dtype=torch.float32, device=t.device)
+            return (K.gemm(t, p["f_wqk1"], p["f_cqk1"], ln=(st, p["f_sqk1"]), rowvec=p["f_peqk1"], rowvec_period=frames,
+                           query_ln_support=True) and
+                    K.project_vt(t, p["f_wv1"], frames, bias=p["f_cv1"], ln=(st, p["f_sv1"]), pe_t=p["f_pev1"],
+                                 pe_period=frames, query_ln_support=True))
+
+        def probe_ff():
+            p = self.packed()
+            st = torch.empty((t.shape[0], 2), dtype=torch.float32, device=t.device)
+            return p["f_ff"] is not None and self.ff.folded_supported(t, st, p["f_ff"])
+
+        key = (t.shape[0], frames)
+        return self._plan.get(("attn",) + key, probe_attn), self._plan.get(("ff",) + key, probe_ff)
 
     def _fwd(self, t, n_pixels, frames, **final_store):
         """t [n_pixels * frames, C] in (b, pixel, frame) order.  `final_store` (ROWPERM + residual) is applied by
@@ -430,13 +520,23 @@ class TemporalTransformerBlock(HipModule):
             raise ValueError(f"num_frames {frames} exceeds the positional table ({self.max_len})")
         p = self.packed()
         c = self.dim
+        fold_attn, fold_ff = self._fold_ok(t, frames)
         for i in (1, 2):
-            n = K.layernorm(t, p[f"g{i}"], p[f"b{i}"], self.eps, pe=p["pe"], pe_period=frames)
-            qk = K.gemm(n, p[f"wqk{i}"])
-            vt = K.project_vt(n, p[f"wv{i}"], frames)
+            if fold_attn:
+                st = K.layernorm_stats(t, self.eps)
+                qk = K.gemm(t, p[f"f_wqk{i}"], p[f"f_cqk{i}"], ln=(st, p[f"f_sqk{i}"]), rowvec=p[f"f_peqk{i}"],
+                            rowvec_period=frames)
+                vt = K.project_vt(t, p[f"f_wv{i}"], frames, bias=p[f"f_cv{i}"], ln=(st, p[f"f_sv{i}"]),
+                                  pe_t=p[f"f_pev{i}"], pe_period=frames)
+            else:
+                n = K.layernorm(t, p[f"g{i}"], p[f"b{i}"], self.eps, pe=p["pe"], pe_period=frames)
+                qk = K.gemm(n, p[f"wqk{i}"])
+                vt = K.project_vt(n, p[f"wv{i}"], frames)
             o = K.temporal_attention(qk[:, :c], qk[:, c:], vt, n_pixels=n_pixels, frames=frames, heads=self.heads,
                                      head_dim=self.dim_head, scale=self.dim_head ** -0.5)
             t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)
+        if fold_ff:
+            return self.ff._fwd_folded(t, K.layernorm_stats(t, self.eps), p["f_ff"])
         n = K.layernorm(t, p["g3"], p["b3"], self.eps)
         return self.ff._fwd(n, t)
 

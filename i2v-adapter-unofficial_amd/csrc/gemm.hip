@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
       const int pix = rem / p.frames, f = rem - pix * p.frames;
       m_out = (int64_t)(b * p.frames + f) * p.hw + pix;
     }
-    const f16* rv = rowvec ? rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
+    const f16* rv = rowvec ? rowvec + (int64_t)(p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : m / p.rows_per_vec) * p.ld_rowvec
+                           : nullptr;
     const f16* rs = resid ? resid + m_out * p.ldr : nullptr;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -333,6 +334,11 @@ extern "C" int64_t i2v_gemm_workspace_bytes(const i2v_gemm_params* pp) {
   return i2v_gemm_big_workspace_bytes(*pp, vector_epilogue_ok(*pp));
 }
 
+extern "C" int i2v_gemm_ln_supported(const i2v_gemm_params* pp) {
+  if (pp == nullptr || pp->M <= 0 || pp->N <= 0 || pp->K <= 0) return 0;
+  return i2v_gemm_big_ln_ok(*pp, vector_epilogue_ok(*pp));
+}
+
 extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(pp != nullptr, "i2v_gemm_f16: null params");
   const i2v_gemm_params& p = *pp;
@@ -376,9 +382,11 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   if (p.store_mode == I2V_STORE_VT_T) {
     I2V_CHECK_ARG(p.vt_len > 0 && p.vt_ld >= p.vt_len && p.M % p.vt_len == 0,
                   "i2v_gemm_f16: VT_T store needs M %% vt_len == 0 and vt_ld >= vt_len");
-    I2V_CHECK_ARG(p.residual == nullptr && p.rowvec == nullptr, "i2v_gemm_f16: VT_T store takes no residual/rowvec");
+    I2V_CHECK_ARG(p.residual == nullptr && (p.rowvec == nullptr || (p.rowvec_period > 0 && p.ln_stats)),
+                  "i2v_gemm_f16: VT_T store takes no residual, and a rowvec only as the transposed positional table of a "
+                  "LayerNorm-folded projection");
   }
-  if (p.rowvec) I2V_CHECK_ARG(p.rows_per_vec > 0, "i2v_gemm_f16: rows_per_vec must be positive");
+  if (p.rowvec) I2V_CHECK_ARG(p.rows_per_vec > 0 || p.rowvec_period > 0, "i2v_gemm_f16: rows_per_vec must be positive");
   if (p.store_mode == I2V_STORE_ROWPERM) {
     I2V_CHECK_ARG(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0,
                   "i2v_gemm_f16: ROWPERM needs M %% (frames*hw) == 0");
@@ -391,6 +399,19 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   }
 
   int vec4 = vector_epilogue_ok(p);
+  if (p.rowvec && p.rowvec_period > 0)
+    I2V_CHECK_ARG(p.store_mode != I2V_STORE_ROWPERM && p.store_mode != I2V_STORE_VT &&
+                      (p.rowvec_period & (p.rowvec_period - 1)) == 0,
+                  "i2v_gemm_f16: a periodic rowvec (positional table) needs a power-of-two period (the epilogue masks the "
+                  "row index: an integer modulo there cost the 256-row kernels 40 %%) and a row-major / VT_T store");
+  if (p.ln_stats || p.ln_wsum) {
+    I2V_CHECK_ARG(p.ln_stats && p.ln_wsum && aligned_to(p.ln_stats, 8) && aligned_to(p.ln_wsum, 16),
+                  "i2v_gemm_f16: ln_stats / ln_wsum must both be set (8 / 16-byte aligned)");
+    if (!i2v_gemm_big_ln_ok(p, vec4))
+      I2V_FAIL(I2V_ERR_INVALID_ARG, "i2v_gemm_f16: LayerNorm-folded GEMM is not implemented for this problem "
+               "(M %d N %d K %d, epilogue %d, store %d): ask i2v_gemm_ln_supported() first", p.M, p.N, p.K, p.epilogue,
+               p.store_mode);
+  }
 
   // large problems whose N is a multiple of 320 go to the 8-wave LDS-DMA kernel (gemm_big.hip)
   {

@@ -30,6 +30,16 @@ __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wa
                                            0);
 }
 
+// m / d for 0 <= m < 2^24 (row indices): one multiply by the precomputed reciprocal and a +-1 fix-up instead of the
+// ~35-instruction integer division (the epilogue runs it once per 8-column task)
+__device__ __forceinline__ int fast_div(int m, int d, float inv_d) {
+  int q = (int)((float)m * inv_d);
+  const int r = m - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -58,7 +68,9 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
   return u * 128 + ((c8 ^ ((u >> 1) & 7)) << 4);
 }
 
-template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true>
+// LNF: LayerNorm folded into the epilogue (a template parameter: as a runtime branch the 160 accumulators of the two
+// paths met in PHI nodes and the 256-row kernels spilled 170-290 registers).
+template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) {
   constexpr int BN = BIG_BN;
   constexpr int WM = BM / 2, MI = WM / 16, NI = 5;
@@ -69,7 +81,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   constexpr int KSTEPS = BK / 32;
   constexpr int LEAD = NS - 1;              // tiles in flight
   // + 1 KiB that swallows the DMA of W groups past the tile (every wave issues the same count: one vmcnt for all)
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 1024];
+  // LNF: + 4 KiB holding this tile's LayerNorm row statistics (BM x (mean, rstd)) and the 320 weight row sums; they are
+  // fetched before the first K tile's DMA and parked here, so the epilogue reads them from LDS instead of paying a
+  // global-load round trip per tile (measured: +2.2 ms per step with the loads in the epilogue)
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 1024 + (LNF ? 4096 : 0)];
+  float2* const lds_st = reinterpret_cast<float2*>(smem + NS * STAGE + 1024);
+  float* const lds_ws = reinterpret_cast<float*>(smem + NS * STAGE + 1024 + 2048 + 512);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,9 +204,22 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const int nkt_all = (K + BK - 1) / BK;
   const int kt0 = SPLIT ? (int)blockIdx.y * kps : 0;
   const int nkt = SPLIT ? min(nkt_all, kt0 + kps) : nkt_all;
+  float2 ln_row = float2{0.f, 1.f};
+  float ln_col = 0.f;
+  if (LNF) {   // issued ahead of the first tile's DMA: landed by the time that tile's vmcnt(0) returns
+    const float2* lnst_g = reinterpret_cast<const float2*>(p.ln_stats);
+    const float* lnws_g = reinterpret_cast<const float*>(p.ln_wsum);
+    if (tid < BM && m0 + tid < M) ln_row = lnst_g[m0 + tid];
+    if (tid < BN) ln_col = lnws_g[n0 + tid];
+  }
 #pragma unroll
   for (int s = 0; s < LEAD; ++s)
     if (kt0 + s < nkt) issue(kt0 + s, s);
+  if (LNF) {
+    wait_vmcnt<0>();   // the wait the first sync_tile would do anyway (LEAD - 1 tiles stay in flight only for NS > 2)
+    if (tid < BM) lds_st[tid] = ln_row;
+    if (tid < BN) lds_ws[tid] = ln_col;
+  }
   auto sync_tile = [&](int kt) {
     // tile kt has landed once at most the LEAD - 1 tiles issued after it are outstanding (in the tail fewer exist)
     if (kt + LEAD - 1 < nkt)
@@ -269,6 +299,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(p.rowvec);
   f16* __restrict__ C = reinterpret_cast<f16*>(p.c);
   const float oscale = p.out_scale;
+  const float inv_rpv = 1.0f / (float)(p.rows_per_vec > 0 ? p.rows_per_vec : 1);
   if (SPLIT) {
     float* __restrict__ ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.y * M * N;
     static_for<MI>([&](auto jc) {
@@ -293,6 +324,26 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     constexpr int TPR = WM / 8, NT = 16 * TPR;
     __builtin_amdgcn_s_barrier();    // every wave has left the K loop: the stages are free
     float* stg = reinterpret_cast<float*>(smem) + wave * (16 * LDS_LD);
+    if (LNF) {
+      // LayerNorm fold: accumulator rows are tokens m = .. + 4 g + r, the column is channel n (l15)
+      static_for<MI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int m = m0 + wm * WM + j * 16 + 4 * g;
+        float mu[4], rs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float2 st = lds_st[m - m0 + r];
+          mu[r] = st.x;
+          rs[r] = st.y;
+        }
+        static_for<NI>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          const float ws = lds_ws[wn * 80 + i * 16 + l15];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = rs[r] * (acc[i][j][r] - mu[r] * ws);
+        });
+      });
+    }
     static_for<NI>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       static_for<MI>([&](auto jc) {
@@ -310,11 +361,17 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
           const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
           const int bt = m / p.vt_len, kk = m - bt * p.vt_len;
+          float pe[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (rowvec) {   // transposed positional table [N][period]: the 8 keys are 8 consecutive positions
+            const f16x8 t8 = ld_global_16B(rowvec + (int64_t)n * p.ld_rowvec + (m & (p.rowvec_period - 1)));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pe[e] = (float)t8[e];
+          }
           f16x8 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[e] = (f16)((lo[e] + bn) * oscale);
-            o[4 + e] = (f16)((hi[e] + bn) * oscale);
+            o[e] = (f16)((lo[e] + bn + pe[e]) * oscale);
+            o[4 + e] = (f16)((hi[e] + bn + pe[4 + e]) * oscale);
           }
           *reinterpret_cast<f16x8*>(C + ((int64_t)bt * N + n) * p.vt_ld + kk) = o;
         }
@@ -362,6 +419,24 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     const int out_col0 = EPI == I2V_EPI_GEGLU ? (n0 >> 1) + wn * 40 : n0 + wn * 80;
     // bias (and the GEGLU gate, in place: registers 0 / 1 of each accumulator become the two outputs) first, as a
     // pure register pass: fused with the staging below, the GELU temporaries pushed accumulators into scratch
+    if (LNF) {
+      // LayerNorm fold: v = rstd_m (acc - mean_m wsum_n); the bias added below is W beta + b
+      f32x4 ws4[NI];
+      static_for<NI>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        ws4[i] = *reinterpret_cast<const f32x4*>(lds_ws + wn * 80 + g * 4 + i * 16);
+      });
+      static_for<MI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int m = m0 + wm * WM + j * 16 + l15;
+        const float2 st = lds_st[m - m0];
+        static_for<NI>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = st.y * (acc[i][j][r] - st.x * ws4[i][r]);
+        });
+      });
+    }
     static_for<MI>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       static_for<NI>([&](auto ic) {
@@ -402,7 +477,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           const int n = out_col0 + c * 8;
           if (EPI != I2V_EPI_GEGLU) {
             if (rowvec) {
-              const f16x8 t8 = ld_global_16B(rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec + n);
+              const int vrow = p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : fast_div(m, p.rows_per_vec, inv_rpv);
+              const f16x8 t8 = ld_global_16B(rowvec + (int64_t)vrow * p.ld_rowvec + n);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += (float)t8[e];
             }
@@ -434,7 +510,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         const int pix = rem / p.frames, f = rem - pix * p.frames;
         m_out = (int64_t)(b * p.frames + f) * p.hw + pix;
       }
-      const f16* rv = rowvec ? rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
+      const f16* rv = rowvec ? rowvec + (int64_t)(p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : fast_div(m, p.rows_per_vec, inv_rpv)) * p.ld_rowvec
+                             : nullptr;
       const f16* rs = resid ? resid + m_out * p.ldr : nullptr;
       static_for<NI>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -473,6 +550,24 @@ template <int BM, int BK, int NS, int AMODE>
 int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BIG_BN;
   const dim3 grid(tiles_m * tiles_n), block(512);
+  if (p.ln_stats != nullptr) {   // LayerNorm-folded epilogues (i2v_gemm_big_ln_ok has vetted the combination)
+    if constexpr (AMODE == I2V_A_PLAIN) {
+      if (p.epilogue == I2V_EPI_GEGLU)
+        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, false, true, true>), grid,
+                           block, 0, s, p, tiles_n, 0);
+      else if (p.store_mode == I2V_STORE_VT_T)
+        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_VT_T, false, true, true>), grid, block,
+                           0, s, p, tiles_n, 0);
+      else if (p.store_mode == I2V_STORE_ROWPERM)
+        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWPERM, false, true, true>), grid,
+                           block, 0, s, p, tiles_n, 0);
+      else
+        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false, true, true>), grid,
+                           block, 0, s, p, tiles_n, 0);
+    }
+    const int rc = i2v_check_launch("i2v_gemm_f16(big, LayerNorm fold)");
+    return rc < 0 ? rc : 1;
+  }
   if (p.epilogue == I2V_EPI_GEGLU) {
     if constexpr (AMODE == I2V_A_PLAIN)
       hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p,
@@ -564,7 +659,9 @@ int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4) {
   return splits ? (int64_t)splits * p.M * p.N * (int64_t)sizeof(float) : 0;
 }
 
-int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
+namespace {
+// dispatch decision for one problem: 0 = not for this kernel, 256 / 128 = tile height, -1 = split-K (*splits, *kps set)
+int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) {
   static const int mode = getenv("I2V_GEMM_BIG") ? atoi(getenv("I2V_GEMM_BIG")) : -1;  // 0 off, 256 / 128 force
   if (mode == 0) return 0;
   if (p.N % BIG_BN != 0) return 0;
@@ -588,10 +685,10 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
     if (p.residual && (p.ldr % 8 != 0 || !a16(p.residual))) return 0;
     if (p.rowvec && (p.ld_rowvec % 8 != 0 || !a16(p.rowvec))) return 0;
   }
+  if (p.rowvec && p.M >= (1 << 24)) return 0;   // the epilogue's reciprocal division of the row index is exact below 2^24
   const int64_t tn = p.N / BIG_BN;
   const int64_t t256 = i2v_cdiv(p.M, 256) * tn, t128 = i2v_cdiv(p.M, 128) * tn;
-  if (mode == 256) return launch_big<256>(p, vec4, s);
-  if (mode == 128) return launch_big<128>(p, vec4, s);
+  if (mode == 256 || mode == 128) return mode;
   static const int min_k = getenv("I2V_GEMM_BIG_MINK") ? atoi(getenv("I2V_GEMM_BIG_MINK")) : 128;
   if (p.a_mode != I2V_A_CONV3X3 && p.K < min_k) return 0;   // a single K tile cannot hide its own DMA latency
   // one 8-wave block per CU: a tile count just above a multiple of 256 wastes most of the last round.  Pick the
@@ -599,13 +696,42 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   // profiles/r1_tile_sweep.txt); below 40 % the 3-blocks-per-CU kernel of gemm.hip is faster.
   const double e256 = (double)t256 / (double)(i2v_cdiv(t256, 256) * 256);
   const double e128 = 0.82 * (double)t128 / (double)(i2v_cdiv(t128, 256) * 256);
-  if (e256 >= e128 && e256 >= 0.40) return launch_big<256>(p, vec4, s);
-  if (e128 >= 0.40) return launch_big<128>(p, vec4, s);
+  if (e256 >= e128 && e256 >= 0.40) return 256;
+  if (e128 >= 0.40) return 128;
   // too few output tiles for the chip: split K when the caller supplied the fp32 scratch
   int kps = 0;
   const int splits = splitk_plan(p, vec4, &kps);
   if (splits && p.workspace && p.workspace_bytes >= (int64_t)splits * p.M * p.N * (int64_t)sizeof(float) &&
-      (reinterpret_cast<uintptr_t>(p.workspace) % 16) == 0)
-    return launch_split(p, vec4, splits, kps, s);
+      (reinterpret_cast<uintptr_t>(p.workspace) % 16) == 0) {
+    if (splits_out) *splits_out = splits;
+    if (kps_out) *kps_out = kps;
+    return -1;
+  }
+  return 0;
+}
+}  // namespace
+
+// LayerNorm-folded problems (ln_stats set) run only on the un-split 8-wave kernel, through the epilogues that
+// implement the fold: the row-contiguous staged stores (row-major / row-permuted, plain or GEGLU) and the fast V^T form.
+int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4) {
+  const int plan = big_plan(p, vec4, nullptr, nullptr);
+  if (plan != 256 && plan != 128) return 0;
+  if (p.a_mode != I2V_A_PLAIN) return 0;
+  if (p.rowvec && p.rowvec_period > 0 && (p.rowvec_period & (p.rowvec_period - 1)) != 0) return 0;
+  if (p.store_mode == I2V_STORE_ROWMAJOR || p.store_mode == I2V_STORE_ROWPERM)
+    return (p.epilogue == I2V_EPI_NONE || (p.epilogue == I2V_EPI_GEGLU && !p.rowvec && !p.residual)) ? 1 : 0;
+  if (p.store_mode == I2V_STORE_VT_T)
+    return (p.vt_len % 8 == 0 && p.M % 8 == 0 && p.vt_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15) == 0 &&
+            (!p.rowvec || (p.rowvec_period >= 8 && (p.rowvec_period & (p.rowvec_period - 1)) == 0 && p.ld_rowvec % 8 == 0)))
+               ? 1 : 0;
+  return 0;
+}
+
+int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
+  int splits = 0, kps = 0;
+  const int plan = big_plan(p, vec4, &splits, &kps);
+  if (plan == 256) return launch_big<256>(p, vec4, s);
+  if (plan == 128) return launch_big<128>(p, vec4, s);
+  if (plan == -1) return launch_split(p, vec4, splits, kps, s);
   return 0;
 }

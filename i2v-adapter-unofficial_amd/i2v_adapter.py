@@ -16,7 +16,8 @@ import torch
 from torch import nn
 
 from . import kernels as K
-from .blocks import (Attention, FeedForward, HipModule, _as_f16_matrix, from_tokens, to_tokens, w16)
+from .blocks import (Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
+                     to_tokens, w16)
 from .checkpoint import PretrainedMixin
 
 f16 = torch.float16
@@ -102,6 +103,7 @@ class I2VAdapterTransformerBlock(HipModule):
         self.i2v_adapter = Attention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim,
                                      dropout=dropout, bias=attention_bias, cross_attention_dim=dim,
                                      out_bias=attention_out_bias)                           # i2v:409-418
+        self._plan = LnFoldPlan()
 
     def _pack(self):
         a1, ad = self.attn1, self.i2v_adapter
@@ -119,28 +121,71 @@ class I2VAdapterTransformerBlock(HipModule):
             p["g2"], p["b2"] = w16(self.norm2.weight), w16(self.norm2.bias)
             p["w_q2"] = w16(self.attn2.to_q.weight)
             p["w_o2"], p["b_o2"] = w16(self.attn2.to_out[0].weight), w16(self.attn2.to_out[0].bias)
+            p["f_q2"] = fold_layernorm(self.attn2.to_q.weight, None, self.norm2.weight, self.norm2.bias)
+        # LayerNorm folded into the consuming projections (i2v:444-445 -> q | k | q_adapter and V^T; i2v:510 -> attn2.to_q;
+        # i2v:539 -> GEGLU): operands (W o gamma, row sums, W beta + b) of the LayerNorm-folded GEMM
+        p["f_qkq"] = fold_layernorm(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), None,
+                                    self.norm1.weight, self.norm1.bias)
+        p["f_v1"] = fold_layernorm(a1.to_v.weight, None, self.norm1.weight, self.norm1.bias)
+        p["f_ff"] = self.ff.fold_norm(self.norm3)
         return p
+
+    def _fold_ok(self, x, L, rows_qkq):
+        """(LayerNorm 1, 2, 3 sites): is the fold implemented for the GEMMs that consume each of them?"""
+        M = x.shape[0]
+        st = lambda: torch.empty((M, 2), dtype=torch.float32, device=x.device)
+
+        def probe1():
+            p = self.packed()
+            wf, ws, cb = p["f_qkq"]
+            wv, sv, cv = p["f_v1"]
+            return (K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(st(), ws[:rows_qkq]), query_ln_support=True) and
+                    K.project_vt(x, wv, L, bias=cv, ln=(st(), sv), query_ln_support=True))
+
+        def probe2():
+            wf, ws, cb = self.packed()["f_q2"]
+            return K.gemm(x, wf, cb, ln=(st(), ws), query_ln_support=True)
+
+        def probe3():
+            p = self.packed()
+            return p["f_ff"] is not None and self.ff.folded_supported(x, st(), p["f_ff"])
+
+        return (self._plan.get((1, M, L, rows_qkq), probe1),
+                self.attn2 is not None and self._plan.get((2, M), probe2), self._plan.get((3, M), probe3))
 
     def _fwd(self, x, n_img, L, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip):
         """x [n_img * L, C] tokens; ctx_text [Bc, Lt, Dc] (+ ctx_ip [Bc, Li, Dc]) with n_img % Bc == 0."""
         p = self.packed()
         c = self.dim
-        n = K.layernorm(x, p["g1"], p["b1"], self.eps)                                       # i2v:444-445
         if enable_cross_frame_attn:
             if num_frames is None:
                 raise ValueError('`num_frames` must be provided when `enable_cross_frame_attn` is True.')
             if n_img % num_frames != 0:
                 raise ValueError(f'Batch size {n_img} must be divisible by the number of frames {num_frames}.')
-            proj = K.gemm(n, p["w_qkq"])                                                     # q1 | k1 | q_adapter
+        rows_qkq = 3 * c if enable_cross_frame_attn else 2 * c                               # q1 | k1 [| q_adapter]
+        fold1, fold2, fold3 = self._fold_ok(x, L, rows_qkq)
+        if fold1:
+            # LayerNorm 1 (i2v:444-445) is never materialised: its statistics feed the folded q|k|q_ad and V^T GEMMs
+            st1 = K.layernorm_stats(x, self.eps)
+            wf, ws, cb = p["f_qkq"]
+            proj = K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(st1, ws[:rows_qkq]))
+            wv, sv, cv = p["f_v1"]
+            vt1 = K.project_vt(x, wv, L, bias=cv, ln=(st1, sv))
+            n = None
         else:
-            proj = K.gemm(n, p["w_qkq"][: 2 * c])
-        vt1 = K.project_vt(n, p["w_v1"], L)
+            n = K.layernorm(x, p["g1"], p["b1"], self.eps)                                   # i2v:444-445
+            proj = K.gemm(n, p["w_qkq"][:rows_qkq])
+            vt1 = K.project_vt(n, p["w_v1"], L)
         o1 = K.attention(proj[:, :c], proj[:, c:2 * c], vt1, batch_q=n_img, lq=L, lk=L, heads=self.heads,
                          head_dim=self.dim_head, scale=self.dim_head ** -0.5)                # i2v:468-473
         if enable_cross_frame_attn:
             clips = n_img // num_frames
             first = torch.empty((clips, L, c), dtype=f16, device=x.device)
-            K.copy3d(n.view(clips, num_frames * L, c)[:, :L], first)                         # i2v:484 (no repeat)
+            if n is None:   # frame-0 rows only: gather the raw rows, normalise just those (1 / num_frames of the work)
+                K.copy3d(x.view(clips, num_frames * L, c)[:, :L], first)
+                first = K.layernorm(first.view(-1, c), p["g1"], p["b1"], self.eps).view(clips, L, c)
+            else:
+                K.copy3d(n.view(clips, num_frames * L, c)[:, :L], first)                     # i2v:484 (no repeat)
             f2d = first.view(-1, c)
             k0 = K.gemm(f2d, p["w_k_ad"])
             v0t = K.project_vt(f2d, p["w_v_ad"], L)
@@ -150,14 +195,20 @@ class I2VAdapterTransformerBlock(HipModule):
         else:
             x = K.gemm(o1, p["w_o1"], p["b_o1"], residual=x)                                 # i2v:501
         if self.attn2 is not None:                                                           # i2v:510-533
-            n = K.layernorm(x, p["g2"], p["b2"], self.eps)
-            q = K.gemm(n, p["w_q2"])
+            if fold2:
+                wf, ws, cb = p["f_q2"]
+                q = K.gemm(x, wf, cb, ln=(K.layernorm_stats(x, self.eps), ws))
+            else:
+                n = K.layernorm(x, p["g2"], p["b2"], self.eps)
+                q = K.gemm(n, p["w_q2"])
             if ctx_text is None:
                 raise ValueError("encoder_hidden_states is required by the cross-attention layer")
             if n_img % ctx_text.shape[0] != 0:
                 raise ValueError(f"context batch {ctx_text.shape[0]} does not divide batch {n_img}")
             o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, n_img // ctx_text.shape[0])
             x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
+        if fold3:
+            return self.ff._fwd_folded(x, K.layernorm_stats(x, self.eps), p["f_ff"])         # i2v:539,554,561
         n = K.layernorm(x, p["g3"], p["b3"], self.eps)                                       # i2v:539
         return self.ff._fwd(n, x)                                                            # i2v:554,561
 

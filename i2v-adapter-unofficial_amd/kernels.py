@@ -54,8 +54,14 @@ def pad8(n: int) -> int:
 
 # ---------------------------------------------------------------------------------------------- GEMM / conv
 def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0, epilogue=I2V_EPI_NONE,
-         out=None, store=I2V_STORE_ROWMAJOR, frames=0, hw=0, vt_len=0, vt_ld=0, out_scale=1.0):
-    """C = epi(A W^T + bias + rowvec + residual) * out_scale   (see i2v_gemm_f16)."""
+         out=None, store=I2V_STORE_ROWMAJOR, frames=0, hw=0, vt_len=0, vt_ld=0, out_scale=1.0, ln=None,
+         rowvec_period=0, query_ln_support=False):
+    """C = epi(A W^T + bias + rowvec + residual) * out_scale   (see i2v_gemm_f16).
+
+    ln = (stats fp32 [M, 2], wsum fp32 [N]): LayerNorm of A's rows folded into the epilogue (w = W o gamma,
+    bias = W beta + b; see i2v_gemm_params.ln_stats).  rowvec_period > 0: rowvec row = m % period (with a VT_T store the
+    table is passed transposed, [N, >= period]).  query_ln_support=True launches nothing and returns whether the library
+    implements the fold for exactly this problem."""
     lib = _lib.load()
     a, lda = _mat(a, "a")
     w, ldw = _mat(w, "w")
@@ -101,13 +107,28 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
         p.residual, p.ldr = _p(residual), ldr
     if rowvec is not None:
         rowvec, ldv = _mat(rowvec, "rowvec")
-        if rows_per_vec <= 0 or M % rows_per_vec != 0 or rowvec.shape != (M // rows_per_vec, N):
-            raise ValueError(f"rowvec must be [M / rows_per_vec, N], got {tuple(rowvec.shape)}")
-        p.rowvec, p.ld_rowvec, p.rows_per_vec = _p(rowvec), ldv, rows_per_vec
+        if rowvec_period > 0:
+            want = (N, rowvec_period) if store == I2V_STORE_VT_T else (rowvec_period, N)
+            if rowvec.shape[0] < want[0] or rowvec.shape[1] < want[1] or (store != I2V_STORE_VT_T and rowvec.shape[1] != N):
+                raise ValueError(f"periodic rowvec must cover {want}, got {tuple(rowvec.shape)}")
+            p.rowvec, p.ld_rowvec, p.rowvec_period = _p(rowvec), ldv, rowvec_period
+        else:
+            if rows_per_vec <= 0 or M % rows_per_vec != 0 or rowvec.shape != (M // rows_per_vec, N):
+                raise ValueError(f"rowvec must be [M / rows_per_vec, N], got {tuple(rowvec.shape)}")
+            p.rowvec, p.ld_rowvec, p.rows_per_vec = _p(rowvec), ldv, rows_per_vec
+    if ln is not None:
+        stats, wsum = ln
+        _req(stats, "ln stats", dtype=torch.float32)
+        _req(wsum, "ln wsum", dtype=torch.float32)
+        if tuple(stats.shape) != (M, 2) or not stats.is_contiguous() or wsum.numel() != N or not wsum.is_contiguous():
+            raise ValueError(f"ln = (stats [M, 2], wsum [N]) expected, got {tuple(stats.shape)} / {tuple(wsum.shape)}")
+        p.ln_stats, p.ln_wsum = _p(stats), _p(wsum)
     p.M, p.N, p.K = M, N, K
     p.epilogue, p.store_mode = epilogue, store
     p.frames, p.hw = frames, hw
     p.out_scale = out_scale
+    if query_ln_support:
+        return bool(lib.i2v_gemm_ln_supported(C.byref(p)))
     ws = _attach_splitk_workspace(lib, p, a.device)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16")
     del ws
@@ -181,24 +202,34 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     return out
 
 
-def project_vt(tokens, w_v, batch_len, out=None):
+def project_vt(tokens, w_v, batch_len, out=None, bias=None, ln=None, pe_t=None, pe_period=0, query_ln_support=False):
     """V^T[batch][channel][key] = (tokens W_v^T)^T, emitted directly by the GEMM epilogue (I2V_STORE_VT).
-    tokens [batches * batch_len, K]; w_v [C, K]; returns [batches, C, pad8(batch_len)] (tail keys unwritten)."""
+    tokens [batches * batch_len, K]; w_v [C, K]; returns [batches, C, pad8(batch_len)] (tail keys unwritten).
+    ln / bias / pe_t: LayerNorm(+positional table, transposed [C, >= pe_period]) folded into the projection (see gemm)."""
     tokens, _ = _mat(tokens, "tokens")
     T = tokens.shape[0]
     if T % batch_len != 0:
         raise ValueError(f"{T} tokens are not a multiple of batch_len {batch_len}")
     ld = pad8(batch_len)
     Cc = w_v.shape[0]
+    natural = Cc % 320 == 0 and batch_len % 4 == 0 and T >= 8192
     if out is None:
         out = torch.empty((T // batch_len, Cc, ld), dtype=f16, device=tokens.device)
-    if Cc % 320 == 0 and batch_len % 4 == 0 and T >= 8192:
+    if query_ln_support:
+        return natural and gemm(tokens, w_v, bias, store=I2V_STORE_VT_T, vt_len=batch_len, vt_ld=ld, ln=ln, rowvec=pe_t,
+                                rowvec_period=pe_period, out=out, query_ln_support=True)
+    if natural:
         # natural operand order (A = tokens): eligible for the 256-row LDS-DMA tile kernel, which transposes in its
         # MFMA operand order (I2V_STORE_VT_T)
-        gemm(tokens, w_v, store=I2V_STORE_VT_T, vt_len=batch_len, vt_ld=ld, out=out)
+        gemm(tokens, w_v, bias, store=I2V_STORE_VT_T, vt_len=batch_len, vt_ld=ld, out=out, ln=ln, rowvec=pe_t,
+             rowvec_period=pe_period)
     else:
+        if ln is not None or pe_t is not None or bias is not None:
+            raise ValueError("the LayerNorm-folded V^T projection needs the natural operand order "
+                             "(C % 320 == 0, batch_len % 4 == 0, >= 8192 tokens)")
         gemm(w_v, tokens, store=I2V_STORE_VT, vt_len=batch_len, vt_ld=ld, out=out)
     return out
+
 
 
 # ---------------------------------------------------------------------------------------------- attention
@@ -294,6 +325,16 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_st
     p.workspace = _p(ws)
     _lib.check(lib.i2v_groupnorm_f16(C.byref(p), _stream()), "i2v_groupnorm_f16")
     return y
+
+
+def layernorm_stats(x, eps):
+    """per-row (mean, rstd) fp32 [rows, 2] of a 2-D fp16 token matrix: the input of the LayerNorm-folded GEMMs."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    rows, Cc = x.shape
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.i2v_layernorm_stats_f16(_p(x), ldx, rows, Cc, eps, _p(stats), _stream()), "i2v_layernorm_stats_f16")
+    return stats
 
 
 def layernorm(x, gamma, beta, eps, *, pe=None, pe_period=0):
