@@ -30,7 +30,7 @@ class GemmParams(C.Structure):
         ("bias", C.c_void_p),
         ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int64), ("rows_per_vec", C.c_int32), ("rowvec_period", C.c_int32),
-        ("ln_stats", C.c_void_p), ("ln_wsum", C.c_void_p),
+        ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float),
         ("c", C.c_void_p), ("ldc", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("epilogue", C.c_int32), ("store_mode", C.c_int32),
@@ -98,7 +98,6 @@ SIGNATURES = {
     "i2v_last_error": (C.c_char_p, []),
     "i2v_gemm_f16": (C.c_int, [C.POINTER(GemmParams), _P]),
     "i2v_gemm_ln_supported": (C.c_int, [C.POINTER(GemmParams)]),
-    "i2v_layernorm_stats_f16": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P, _P]),
     "i2v_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmParams)]),
     "i2v_attention_f16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "i2v_temporal_attention_f16": (C.c_int, [C.POINTER(TAttnParams), _P]),

@@ -70,7 +70,7 @@ def pack_geglu(weight, bias):
     return w16(w), w16(b)
 
 
-# LayerNorm folded into the consuming GEMMs (i2v_gemm_params.ln_stats); I2V_LN_FOLD=0 keeps the materialised LayerNorm
+# LayerNorm folded into the consuming GEMMs (i2v_gemm_params.ln_wsum); I2V_LN_FOLD=0 keeps the materialised LayerNorm
 # everywhere (same-box A/B)
 LN_FOLD = os.environ.get("I2V_LN_FOLD", "1") != "0"
 
@@ -408,16 +408,16 @@ class FeedForward(HipModule):
         proj = self.net[0].proj
         return fold_layernorm_geglu(proj.weight, proj.bias, norm.weight, norm.bias)
 
-    def _fwd_folded(self, x2d, stats, folded, **store):
+    def _fwd_folded(self, x2d, eps, folded, **store):
         """x + FF(LayerNorm(x)) with the LayerNorm folded into the GEGLU projection (x2d is the UN-normalised input)."""
         p = self.packed()
         wf, wsum, bf = folded
-        h = K.gemm(x2d, wf, bf, epilogue=I2V_EPI_GEGLU, ln=(stats, wsum))
+        h = K.gemm(x2d, wf, bf, epilogue=I2V_EPI_GEGLU, ln=(wsum, eps))
         return K.gemm(h, p["w2"], p["b2"], residual=x2d, **store)
 
-    def folded_supported(self, x2d, stats, folded):
+    def folded_supported(self, x2d, eps, folded):
         wf, wsum, bf = folded
-        return K.gemm(x2d, wf, bf, epilogue=I2V_EPI_GEGLU, ln=(stats, wsum), query_ln_support=True)
+        return K.gemm(x2d, wf, bf, epilogue=I2V_EPI_GEGLU, ln=(wsum, eps), query_ln_support=True)
 
     def forward(self, hidden_states, scale: float = 1.0):
         x = _as_f16_matrix(hidden_states)
@@ -499,16 +499,16 @@ class TemporalTransformerBlock(HipModule):
         """(attention sites, feed-forward site): is the LayerNorm fold implemented for this problem's GEMMs?"""
         def probe_attn():
             p = self.packed()
-            st = torch.empty((t.shape[0], 2), dtype=torch.float32, device=t.device)
-            return (K.gemm(t, p["f_wqk1"], p["f_cqk1"], ln=(st, p["f_sqk1"]), rowvec=p["f_peqk1"], rowvec_period=frames,
-                           query_ln_support=True) and
-                    K.project_vt(t, p["f_wv1"], frames, bias=p["f_cv1"], ln=(st, p["f_sv1"]), pe_t=p["f_pev1"],
+            if frames & (frames - 1):
+                return False                                     # the positional table is indexed by a mask
+            return (K.gemm(t, p["f_wqk1"], p["f_cqk1"], ln=(p["f_sqk1"], self.eps), rowvec=p["f_peqk1"],
+                           rowvec_period=frames, query_ln_support=True) and
+                    K.project_vt(t, p["f_wv1"], frames, bias=p["f_cv1"], ln=(p["f_sv1"], self.eps), pe_t=p["f_pev1"],
                                  pe_period=frames, query_ln_support=True))
 
         def probe_ff():
             p = self.packed()
-            st = torch.empty((t.shape[0], 2), dtype=torch.float32, device=t.device)
-            return p["f_ff"] is not None and self.ff.folded_supported(t, st, p["f_ff"])
+            return p["f_ff"] is not None and self.ff.folded_supported(t, self.eps, p["f_ff"])
 
         key = (t.shape[0], frames)
         return self._plan.get(("attn",) + key, probe_attn), self._plan.get(("ff",) + key, probe_ff)
@@ -523,10 +523,9 @@ class TemporalTransformerBlock(HipModule):
         fold_attn, fold_ff = self._fold_ok(t, frames)
         for i in (1, 2):
             if fold_attn:
-                st = K.layernorm_stats(t, self.eps)
-                qk = K.gemm(t, p[f"f_wqk{i}"], p[f"f_cqk{i}"], ln=(st, p[f"f_sqk{i}"]), rowvec=p[f"f_peqk{i}"],
+                qk = K.gemm(t, p[f"f_wqk{i}"], p[f"f_cqk{i}"], ln=(p[f"f_sqk{i}"], self.eps), rowvec=p[f"f_peqk{i}"],
                             rowvec_period=frames)
-                vt = K.project_vt(t, p[f"f_wv{i}"], frames, bias=p[f"f_cv{i}"], ln=(st, p[f"f_sv{i}"]),
+                vt = K.project_vt(t, p[f"f_wv{i}"], frames, bias=p[f"f_cv{i}"], ln=(p[f"f_sv{i}"], self.eps),
                                   pe_t=p[f"f_pev{i}"], pe_period=frames)
             else:
                 n = K.layernorm(t, p[f"g{i}"], p[f"b{i}"], self.eps, pe=p["pe"], pe_period=frames)
@@ -536,7 +535,7 @@ class TemporalTransformerBlock(HipModule):
                                      head_dim=self.dim_head, scale=self.dim_head ** -0.5)
             t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)
         if fold_ff:
-            return self.ff._fwd_folded(t, K.layernorm_stats(t, self.eps), p["f_ff"])
+            return self.ff._fwd_folded(t, self.eps, p["f_ff"])
         n = K.layernorm(t, p["g3"], p["b3"], self.eps)
         return self.ff._fwd(n, t)
 

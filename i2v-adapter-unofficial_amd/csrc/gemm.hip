@@ -382,7 +382,7 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   if (p.store_mode == I2V_STORE_VT_T) {
     I2V_CHECK_ARG(p.vt_len > 0 && p.vt_ld >= p.vt_len && p.M % p.vt_len == 0,
                   "i2v_gemm_f16: VT_T store needs M %% vt_len == 0 and vt_ld >= vt_len");
-    I2V_CHECK_ARG(p.residual == nullptr && (p.rowvec == nullptr || (p.rowvec_period > 0 && p.ln_stats)),
+    I2V_CHECK_ARG(p.residual == nullptr && (p.rowvec == nullptr || (p.rowvec_period > 0 && p.ln_wsum)),
                   "i2v_gemm_f16: VT_T store takes no residual, and a rowvec only as the transposed positional table of a "
                   "LayerNorm-folded projection");
   }
@@ -404,9 +404,8 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
                       (p.rowvec_period & (p.rowvec_period - 1)) == 0,
                   "i2v_gemm_f16: a periodic rowvec (positional table) needs a power-of-two period (the epilogue masks the "
                   "row index: an integer modulo there cost the 256-row kernels 40 %%) and a row-major / VT_T store");
-  if (p.ln_stats || p.ln_wsum) {
-    I2V_CHECK_ARG(p.ln_stats && p.ln_wsum && aligned_to(p.ln_stats, 8) && aligned_to(p.ln_wsum, 16),
-                  "i2v_gemm_f16: ln_stats / ln_wsum must both be set (8 / 16-byte aligned)");
+  if (p.ln_wsum) {
+    I2V_CHECK_ARG(aligned_to(p.ln_wsum, 16) && p.ln_eps > 0.f, "i2v_gemm_f16: ln_wsum must be 16-byte aligned, ln_eps > 0");
     if (!i2v_gemm_big_ln_ok(p, vec4))
       I2V_FAIL(I2V_ERR_INVALID_ARG, "i2v_gemm_f16: LayerNorm-folded GEMM is not implemented for this problem "
                "(M %d N %d K %d, epilogue %d, store %d): ask i2v_gemm_ln_supported() first", p.M, p.N, p.K, p.epilogue,

@@ -81,9 +81,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   constexpr int KSTEPS = BK / 32;
   constexpr int LEAD = NS - 1;              // tiles in flight
   // + 1 KiB that swallows the DMA of W groups past the tile (every wave issues the same count: one vmcnt for all)
-  // LNF: + 4 KiB holding this tile's LayerNorm row statistics (BM x (mean, rstd)) and the 320 weight row sums; they are
-  // fetched before the first K tile's DMA and parked here, so the epilogue reads them from LDS instead of paying a
-  // global-load round trip per tile (measured: +2.2 ms per step with the loads in the epilogue)
+  // LNF: + 4 KiB holding this tile's LayerNorm row statistics (BM x (mean, rstd)) and the 320 weight row sums.  The
+  // statistics are computed IN the K loop from the A fragments every wave reads anyway (the loop streams whole rows of A
+  // through the workgroup: K = the normalised width), so there is no statistics kernel and no extra pass over A; the row
+  // sums are fetched before the first K tile's DMA, so the epilogue reads both from LDS instead of paying a global-load
+  // round trip per tile (measured: +2.2 ms per step with the loads in the epilogue).
   __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 1024 + (LNF ? 4096 : 0)];
   float2* const lds_st = reinterpret_cast<float2*>(smem + NS * STAGE + 1024);
   float* const lds_ws = reinterpret_cast<float*>(smem + NS * STAGE + 1024 + 2048 + 512);
@@ -204,12 +206,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const int nkt_all = (K + BK - 1) / BK;
   const int kt0 = SPLIT ? (int)blockIdx.y * kps : 0;
   const int nkt = SPLIT ? min(nkt_all, kt0 + kps) : nkt_all;
-  float2 ln_row = float2{0.f, 1.f};
   float ln_col = 0.f;
   if (LNF) {   // issued ahead of the first tile's DMA: landed by the time that tile's vmcnt(0) returns
-    const float2* lnst_g = reinterpret_cast<const float2*>(p.ln_stats);
     const float* lnws_g = reinterpret_cast<const float*>(p.ln_wsum);
-    if (tid < BM && m0 + tid < M) ln_row = lnst_g[m0 + tid];
     if (tid < BN) ln_col = lnws_g[n0 + tid];
   }
 #pragma unroll
@@ -217,7 +216,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     if (kt0 + s < nkt) issue(kt0 + s, s);
   if (LNF) {
     wait_vmcnt<0>();   // the wait the first sync_tile would do anyway (LEAD - 1 tiles stay in flight only for NS > 2)
-    if (tid < BM) lds_st[tid] = ln_row;
     if (tid < BN) lds_ws[tid] = ln_col;
   }
   auto sync_tile = [&](int kt) {
@@ -254,6 +252,30 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
                                               : mfma16x16x32(wf[i], af[j], acc[i][j]);
   };
 
+  // LNF: row sums of x and x^2 from the A fragments.  A wave's MI row blocks are shared by the four N-waves that read
+  // the same rows: wave wn accumulates blocks wn * RB .. wn * RB + RB - 1 (a wave-uniform select: a runtime index into
+  // the fragment array would send it to scratch).  v_dot2_f32_f16: exact fp16 products, fp32 sums; 8 VALU per fragment.
+  // Raw moments in fp32 are accurate to ~(mean / std)^2 x 1e-7, far below the quantisation of the fp16 rows themselves
+  // (mean / std x 5e-4), so no shift is needed here (unlike GroupNorm's million-element sums).
+  constexpr int RB = MI / 4 > 0 ? MI / 4 : 1;
+  float ln_s[RB], ln_q[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) ln_s[b] = ln_q[b] = 0.f;
+  auto ln_accum = [&](const f16x8 (&af)[MI]) {
+    static_for<MI>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (wn == (j / RB) % 4) {
+        const f16x2 one2 = {(f16)1.f, (f16)1.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f16x2 a2 = {af[j][2 * e], af[j][2 * e + 1]};
+          ln_s[j % RB] = __builtin_amdgcn_fdot2(a2, one2, ln_s[j % RB], false);
+          ln_q[j % RB] = __builtin_amdgcn_fdot2(a2, a2, ln_q[j % RB], false);
+        }
+      }
+    });
+  };
+
   // The two waves of a SIMD (wave w and w + 4: wm = 0 and wm = 1) run half a K tile out of phase: the wm = 1 group
   // reads the fragments of a tile's last k-step BEFORE the tile barrier but issues their MFMAs AFTER it, i.e. while the
   // wm = 0 group is reading the next tile's first fragments; from there on one wave's LDS reads coincide with the
@@ -267,6 +289,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       for (int ks = 0; ks < KSTEPS; ++ks) {
         f16x8 wf[NI], af[MI];
         read_frags(cur, ks, wf, af);
+        if (LNF) ln_accum(af);
         mma(wf, af);
       }
     }
@@ -281,13 +304,32 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       for (int ks = 0; ks + 1 < KSTEPS; ++ks) {
         f16x8 wf[NI], af[MI];
         read_frags(cur, ks, wf, af);
+        if (LNF) ln_accum(af);
         mma(wf, af);
       }
       __builtin_amdgcn_sched_barrier(0);   // strict read / MFMA phases: the overlap comes from the partner wave
       read_frags(cur, KSTEPS - 1, pwf, paf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads have left LDS before the stage can be refilled
+      if (LNF) ln_accum(paf);
     }
     if (nkt > kt0) mma(pwf, paf);
+  }
+  if (LNF) {
+    // a row's 32 k of one step sit on the 4 lane groups: fold them, then lane group 0 publishes (mean, rstd) of the
+    // rows of this wave's blocks; the epilogue's barrier (with the LDS write retired) makes them visible to every wave
+    const float inv_k = 1.0f / (float)K;
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      float sv = ln_s[b], qv = ln_q[b];
+      sv += __shfl_xor(sv, 16, 64);
+      qv += __shfl_xor(qv, 16, 64);
+      sv += __shfl_xor(sv, 32, 64);
+      qv += __shfl_xor(qv, 32, 64);
+      const float mean = sv * inv_k;
+      const float var = fmaxf(qv * inv_k - mean * mean, 0.f);
+      if (g == 0) lds_st[wm * WM + ((MI >= 4 ? wn * RB : 0) + b) * 16 + l15] = float2{mean, rsqrtf(var + p.ln_eps)};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
   // ---------------------------------------------------------------- epilogue (lane: row m, 4 consecutive n)
@@ -550,7 +592,7 @@ template <int BM, int BK, int NS, int AMODE>
 int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BIG_BN;
   const dim3 grid(tiles_m * tiles_n), block(512);
-  if (p.ln_stats != nullptr) {   // LayerNorm-folded epilogues (i2v_gemm_big_ln_ok has vetted the combination)
+  if (p.ln_wsum != nullptr) {   // LayerNorm-folded epilogues (i2v_gemm_big_ln_ok has vetted the combination)
     if constexpr (AMODE == I2V_A_PLAIN) {
       if (p.epilogue == I2V_EPI_GEGLU)
         hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, false, true, true>), grid,
@@ -711,12 +753,12 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
 }
 }  // namespace
 
-// LayerNorm-folded problems (ln_stats set) run only on the un-split 8-wave kernel, through the epilogues that
+// LayerNorm-folded problems (ln_wsum set) run only on the un-split 8-wave kernel, through the epilogues that
 // implement the fold: the row-contiguous staged stores (row-major / row-permuted, plain or GEGLU) and the fast V^T form.
 int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4) {
   const int plan = big_plan(p, vec4, nullptr, nullptr);
   if (plan != 256 && plan != 128) return 0;
-  if (p.a_mode != I2V_A_PLAIN) return 0;
+  if (p.a_mode != I2V_A_PLAIN || p.a2 != nullptr) return 0;   // the K loop must stream whole rows of ONE source
   if (p.rowvec && p.rowvec_period > 0 && (p.rowvec_period & (p.rowvec_period - 1)) != 0) return 0;
   if (p.store_mode == I2V_STORE_ROWMAJOR || p.store_mode == I2V_STORE_ROWPERM)
     return (p.epilogue == I2V_EPI_NONE || (p.epilogue == I2V_EPI_GEGLU && !p.rowvec && !p.residual)) ? 1 : 0;

@@ -116,7 +116,7 @@ __device__ __forceinline__ void gemm_store4(const i2v_gemm_params& p, const int 
 // implemented in gemm_big.hip: 256-thread-pair (8-wave) LDS-DMA kernel for N % 320 == 0; returns 1 if it took the
 // problem, 0 if the caller should use the generic kernel, < 0 on error.
 int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s);
-// 1 if gemm_big.hip takes this problem AND implements the LayerNorm fold (ln_stats / ln_wsum) for its epilogue
+// 1 if gemm_big.hip takes this problem AND implements the LayerNorm fold (ln_wsum) for its epilogue
 int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4);
 // fp32 scratch bytes with which gemm_big.hip would split K for this problem (0: no split)
 int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4);

@@ -307,53 +307,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
   for (int c = nvec * 8 + lane; c < cols; c += 64) yr[c] = (f16)(__builtin_amdgcn_exp2f((float)xr[c] * scale_log2 - mb) * inv);
 }
 
-// LayerNorm statistics only: (mean, rstd) per row for the GEMMs that fold the normalisation into their epilogue
-// (i2v_gemm_params.ln_stats): one read of x, 8 bytes written per row.  Same register-resident two-pass variance as
-// ln_kernel, so the folded and the materialised LayerNorm agree.
-template <int NV, int R>
-__global__ __launch_bounds__(256) void ln_stats_kernel(const f16* __restrict__ x, int64_t ldx, int rows, int C, float eps,
-                                                       float2* __restrict__ stats) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * R;
-  if (row0 >= rows) return;
-  const int nvec = C / 8;
-  float v[R][NV][8];
-  float s[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    s[r] = 0.f;
-    const bool live = row0 + r < rows;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int vi = lane + 64 * i;
-      f16x8 t = zero8();
-      if (live && vi < nvec) t = ld_global_16B(x + (int64_t)(row0 + r) * ldx + vi * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[r][i][e] = (float)t[e];
-        s[r] += v[r][i][e];
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float mean = wave_sum(s[r]) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      if (lane + 64 * i < nvec) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = v[r][i][e] - mean;
-          q += d * d;
-        }
-      }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    if (lane == 0 && row0 + r < rows) stats[row0 + r] = float2{mean, rstd};
-  }
-}
-
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -432,28 +385,4 @@ extern "C" int i2v_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(x), ldx,
                      reinterpret_cast<f16*>(y), ldy, rows, cols, scale * 1.4426950408889634f);
   return i2v_check_launch("i2v_softmax_rows_f16");
-}
-
-extern "C" int i2v_layernorm_stats_f16(const void* x, int64_t ldx, int32_t rows, int32_t C, float eps, void* stats,
-                                       i2v_stream_t stream) {
-  I2V_CHECK_ARG(x && stats && rows > 0 && C > 0 && C % 8 == 0 && C <= 4096,
-                "i2v_layernorm_stats_f16: C (%d) must be a multiple of 8 and <= 4096", C);
-  I2V_CHECK_ARG(ldx % 8 == 0 && ldx >= C && al16(x) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
-                "i2v_layernorm_stats_f16: bad ldx / alignment");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const f16* xp = reinterpret_cast<const f16*>(x);
-  float2* st = reinterpret_cast<float2*>(stats);
-  const dim3 block(256);
-  const int nv = (int)i2v_cdiv(C / 8, 64);
-  switch (nv) {
-    case 1: hipLaunchKernelGGL((ln_stats_kernel<1, 4>), dim3((unsigned)i2v_cdiv(rows, 16)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-    case 2: hipLaunchKernelGGL((ln_stats_kernel<2, 2>), dim3((unsigned)i2v_cdiv(rows, 8)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-    case 3: hipLaunchKernelGGL((ln_stats_kernel<3, 2>), dim3((unsigned)i2v_cdiv(rows, 8)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-    case 4: hipLaunchKernelGGL((ln_stats_kernel<4, 1>), dim3((unsigned)i2v_cdiv(rows, 4)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-    case 5: hipLaunchKernelGGL((ln_stats_kernel<5, 1>), dim3((unsigned)i2v_cdiv(rows, 4)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-    case 6: hipLaunchKernelGGL((ln_stats_kernel<6, 1>), dim3((unsigned)i2v_cdiv(rows, 4)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-    case 7: hipLaunchKernelGGL((ln_stats_kernel<7, 1>), dim3((unsigned)i2v_cdiv(rows, 4)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-    default: hipLaunchKernelGGL((ln_stats_kernel<8, 1>), dim3((unsigned)i2v_cdiv(rows, 4)), block, 0, s, xp, ldx, rows, C, eps, st); break;
-  }
-  return i2v_check_launch("i2v_layernorm_stats_f16");
 }

@@ -133,22 +133,21 @@ class I2VAdapterTransformerBlock(HipModule):
     def _fold_ok(self, x, L, rows_qkq):
         """(LayerNorm 1, 2, 3 sites): is the fold implemented for the GEMMs that consume each of them?"""
         M = x.shape[0]
-        st = lambda: torch.empty((M, 2), dtype=torch.float32, device=x.device)
 
         def probe1():
             p = self.packed()
             wf, ws, cb = p["f_qkq"]
             wv, sv, cv = p["f_v1"]
-            return (K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(st(), ws[:rows_qkq]), query_ln_support=True) and
-                    K.project_vt(x, wv, L, bias=cv, ln=(st(), sv), query_ln_support=True))
+            return (K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(ws[:rows_qkq], self.eps), query_ln_support=True) and
+                    K.project_vt(x, wv, L, bias=cv, ln=(sv, self.eps), query_ln_support=True))
 
         def probe2():
             wf, ws, cb = self.packed()["f_q2"]
-            return K.gemm(x, wf, cb, ln=(st(), ws), query_ln_support=True)
+            return K.gemm(x, wf, cb, ln=(ws, self.eps), query_ln_support=True)
 
         def probe3():
             p = self.packed()
-            return p["f_ff"] is not None and self.ff.folded_supported(x, st(), p["f_ff"])
+            return p["f_ff"] is not None and self.ff.folded_supported(x, self.eps, p["f_ff"])
 
         return (self._plan.get((1, M, L, rows_qkq), probe1),
                 self.attn2 is not None and self._plan.get((2, M), probe2), self._plan.get((3, M), probe3))
@@ -165,12 +164,11 @@ class I2VAdapterTransformerBlock(HipModule):
         rows_qkq = 3 * c if enable_cross_frame_attn else 2 * c                               # q1 | k1 [| q_adapter]
         fold1, fold2, fold3 = self._fold_ok(x, L, rows_qkq)
         if fold1:
-            # LayerNorm 1 (i2v:444-445) is never materialised: its statistics feed the folded q|k|q_ad and V^T GEMMs
-            st1 = K.layernorm_stats(x, self.eps)
+            # LayerNorm 1 (i2v:444-445) is never materialised: the q|k|q_ad and V^T GEMMs normalise inside their K loops
             wf, ws, cb = p["f_qkq"]
-            proj = K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(st1, ws[:rows_qkq]))
+            proj = K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(ws[:rows_qkq], self.eps))
             wv, sv, cv = p["f_v1"]
-            vt1 = K.project_vt(x, wv, L, bias=cv, ln=(st1, sv))
+            vt1 = K.project_vt(x, wv, L, bias=cv, ln=(sv, self.eps))
             n = None
         else:
             n = K.layernorm(x, p["g1"], p["b1"], self.eps)                                   # i2v:444-445
@@ -197,7 +195,7 @@ class I2VAdapterTransformerBlock(HipModule):
         if self.attn2 is not None:                                                           # i2v:510-533
             if fold2:
                 wf, ws, cb = p["f_q2"]
-                q = K.gemm(x, wf, cb, ln=(K.layernorm_stats(x, self.eps), ws))
+                q = K.gemm(x, wf, cb, ln=(ws, self.eps))
             else:
                 n = K.layernorm(x, p["g2"], p["b2"], self.eps)
                 q = K.gemm(n, p["w_q2"])
@@ -208,7 +206,7 @@ class I2VAdapterTransformerBlock(HipModule):
             o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, n_img // ctx_text.shape[0])
             x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
         if fold3:
-            return self.ff._fwd_folded(x, K.layernorm_stats(x, self.eps), p["f_ff"])         # i2v:539,554,561
+            return self.ff._fwd_folded(x, self.eps, p["f_ff"])                               # i2v:539,554,561
         n = K.layernorm(x, p["g3"], p["b3"], self.eps)                                       # i2v:539
         return self.ff._fwd(n, x)                                                            # i2v:554,561
 

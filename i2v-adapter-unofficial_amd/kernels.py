@@ -58,8 +58,8 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
          rowvec_period=0, query_ln_support=False):
     """C = epi(A W^T + bias + rowvec + residual) * out_scale   (see i2v_gemm_f16).
 
-    ln = (stats fp32 [M, 2], wsum fp32 [N]): LayerNorm of A's rows folded into the epilogue (w = W o gamma,
-    bias = W beta + b; see i2v_gemm_params.ln_stats).  rowvec_period > 0: rowvec row = m % period (with a VT_T store the
+    ln = (wsum fp32 [N], eps): LayerNorm of A's rows folded into the GEMM (w = W o gamma, bias = W beta + b; the row
+    statistics are computed inside the kernel; see i2v_gemm_params.ln_wsum).  rowvec_period > 0: rowvec row = m % period (with a VT_T store the
     table is passed transposed, [N, >= period]).  query_ln_support=True launches nothing and returns whether the library
     implements the fold for exactly this problem."""
     lib = _lib.load()
@@ -117,12 +117,11 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
                 raise ValueError(f"rowvec must be [M / rows_per_vec, N], got {tuple(rowvec.shape)}")
             p.rowvec, p.ld_rowvec, p.rows_per_vec = _p(rowvec), ldv, rows_per_vec
     if ln is not None:
-        stats, wsum = ln
-        _req(stats, "ln stats", dtype=torch.float32)
+        wsum, eps = ln
         _req(wsum, "ln wsum", dtype=torch.float32)
-        if tuple(stats.shape) != (M, 2) or not stats.is_contiguous() or wsum.numel() != N or not wsum.is_contiguous():
-            raise ValueError(f"ln = (stats [M, 2], wsum [N]) expected, got {tuple(stats.shape)} / {tuple(wsum.shape)}")
-        p.ln_stats, p.ln_wsum = _p(stats), _p(wsum)
+        if wsum.numel() != N or not wsum.is_contiguous() or a2 is not None:
+            raise ValueError(f"ln = (wsum fp32 [N], eps) with a single-source A expected, got {tuple(wsum.shape)}")
+        p.ln_wsum, p.ln_eps = _p(wsum), float(eps)
     p.M, p.N, p.K = M, N, K
     p.epilogue, p.store_mode = epilogue, store
     p.frames, p.hw = frames, hw
@@ -325,16 +324,6 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_st
     p.workspace = _p(ws)
     _lib.check(lib.i2v_groupnorm_f16(C.byref(p), _stream()), "i2v_groupnorm_f16")
     return y
-
-
-def layernorm_stats(x, eps):
-    """per-row (mean, rstd) fp32 [rows, 2] of a 2-D fp16 token matrix: the input of the LayerNorm-folded GEMMs."""
-    lib = _lib.load()
-    x, ldx = _mat(x, "x")
-    rows, Cc = x.shape
-    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
-    _lib.check(lib.i2v_layernorm_stats_f16(_p(x), ldx, rows, Cc, eps, _p(stats), _stream()), "i2v_layernorm_stats_f16")
-    return stats
 
 
 def layernorm(x, gamma, beta, eps, *, pe=None, pe_period=0):

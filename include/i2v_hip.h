@@ -92,14 +92,15 @@ typedef struct i2v_gemm_params {
   int32_t rowvec_period; /* > 0 (a power of two): the vector of row m is rowvec[m % rowvec_period] (positional-embedding
                             table of the motion modules: tokens are in (b, pixel, frame) order, period = frames);
                             with I2V_STORE_VT_T the table is passed TRANSPOSED, [N, ld_rowvec >= period]          */
-  /* LayerNorm folded into the GEMM (i2v:444-445, 510, 539 and the motion modules' norm1/2/3): with per-row
-     statistics ln_stats fp32 [M][2] = (mean_m, rstd_m) of A's rows (i2v_layernorm_stats_f16), W' = W o gamma (the w
-     passed here), ln_wsum fp32 [N] = sum_k W'[n][k] (summed from the fp16-ROUNDED W') and bias = W beta + b:
+  /* LayerNorm folded into the GEMM (i2v:444-445, 510, 539 and the motion modules' norm1/2/3).  With W' = W o gamma
+     (the w passed here), ln_wsum fp32 [N] = sum_k W'[n][k] (summed from the fp16-ROUNDED W') and bias = W beta + b:
         C[m][n] = rstd_m (sum_k A[m][k] W'[n][k] - mean_m ln_wsum[n]) + bias[n]   = (LayerNorm(A) W^T + b)[m][n]
-     so the normalised activations are never written to / read back from HBM.  NULL = plain GEMM.  Only the 8-wave
-     LDS-DMA kernel implements it: i2v_gemm_ln_supported() tells whether a problem qualifies. */
-  const void* ln_stats;
+     where mean_m / rstd_m = 1 / sqrt(var_m + ln_eps) are the statistics of row m of A over its K columns, computed
+     INSIDE the kernel from the A tiles its K loop streams anyway: the normalised activations are never written to /
+     read back from HBM and there is no statistics pass.  NULL = plain GEMM.  Only the 8-wave LDS-DMA kernel
+     implements it (single-source A): i2v_gemm_ln_supported() tells whether a problem qualifies. */
   const void* ln_wsum;
+  float ln_eps;
   void* c;              /* fp16                                                                      */
   int64_t ldc;
   int32_t M, N, K;
@@ -122,12 +123,8 @@ typedef struct i2v_gemm_params {
 } i2v_gemm_params;
 
 int i2v_gemm_f16(const i2v_gemm_params* p, i2v_stream_t stream);
-/* 1 if i2v_gemm_f16 accepts this problem with ln_stats / ln_wsum set (pointers are not dereferenced), else 0. */
+/* 1 if i2v_gemm_f16 accepts this problem with ln_wsum set (pointers are not dereferenced), else 0. */
 int i2v_gemm_ln_supported(const i2v_gemm_params* p);
-/* per-row LayerNorm statistics of x fp16 [rows, C] (ld = ldx): stats fp32 [rows][2] = (mean, 1 / sqrt(var + eps)),
-   exact two-pass variance in registers.  C % 8 == 0, C <= 4096. */
-int i2v_layernorm_stats_f16(const void* x, int64_t ldx, int32_t rows, int32_t C, float eps, void* stats,
-                            i2v_stream_t stream);
 /* bytes of `workspace` with which i2v_gemm_f16 would split K for this problem (0: it would not split). */
 int64_t i2v_gemm_workspace_bytes(const i2v_gemm_params* p);
 
