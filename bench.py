@@ -201,6 +201,9 @@ def main():
         if ip:
             ie = torch.cat([torch.zeros_like(s["ie"]) for s in grp] + [s["ie"] for s in grp])      # pipe:343, 621-622
             st["ctx_ip"].copy_(model._project_image_embeds({"image_embeds": ie.to(dev)}))
+        # per-sample work outside the step: K / V^T of the context for the 16 cross-attention layers, written into the
+        # buffers the captured graph reads
+        st["ctx_proj"] = model.project_context(st["ctx_text"], st["ctx_ip"], out=st.get("ctx_proj"))
         st["step_idx"].zero_()
 
     with torch.no_grad():

@@ -111,6 +111,36 @@ class LnFoldPlan:
         return self._cache[key]
 
 
+class ProjectedContext:
+    """Text (+ IP-Adapter image) context with its per-layer K / V^T projections already computed.
+
+    `to_k(ctx)` / `to_v(ctx)` of the 16 cross-attention layers (i2v:527-532, unet:1263-1279) depend only on the prompt
+    (and image) embeddings and the weights, not on the latents or the timestep: the reference recomputes them in every
+    UNet call of every denoising step; here they are computed once per sample (`UNetMotionCrossFrameAttnModel.
+    project_context`) and the captured step only reads them (-32 ... -64 small GEMM launches per step).  Passed down the
+    blocks in place of the raw context tensor."""
+
+    def __init__(self, text, ip):
+        self.text, self.ip = text, ip
+        self.kv = {}                       # Attention module -> (k, vt, k_ip, vt_ip)
+
+    @property
+    def shape(self):
+        return self.text.shape
+
+
+class ProjectedTemb:
+    """`time_emb_proj(silu(temb))` of every ResnetBlock2D as column slices of ONE GEMM over the concatenated
+    weights: 22 launches of an M = 2 GEMM per step become one."""
+
+    def __init__(self, all_proj, slices):
+        self.all_proj, self.slices = all_proj, slices      # [B, sum Cout] fp16; {resnet: (offset, Cout)}
+
+    def view_for(self, resnet):
+        off, n = self.slices[resnet]
+        return self.all_proj[:, off: off + n]
+
+
 def to_tokens(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
     """reference NCHW tensor -> token-major fp16 [N, H, W, C]."""
     return K.nchw_to_tokens(x, c_pad)
@@ -203,8 +233,9 @@ class ResnetBlock2D(HipModule):
         h = K.groupnorm(x, p["g1"], p["b1"], self.groups, self.eps, x2=x2, silu=True)
         rowvec, rpv = None, 0
         if self.time_emb_proj is not None and temb_act is not None:
-            rowvec = K.gemm(temb_act, p["wt"], p["bt"])
-            rpv = (n // temb_act.shape[0]) * hh * ww
+            rowvec = (temb_act.view_for(self) if isinstance(temb_act, ProjectedTemb)
+                      else K.gemm(temb_act, p["wt"], p["bt"]))
+            rpv = (n // rowvec.shape[0]) * hh * ww
         h = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv)
         h = K.groupnorm(h, p["g2"], p["b2"], self.groups, self.eps, silu=True)
         if self.conv_shortcut is not None:
@@ -313,18 +344,33 @@ class Attention(HipModule):
             p["wk_ip"], p["wv_ip"] = w16(self.to_k_ip.weight), w16(self.to_v_ip.weight)
         return p
 
-    def _cross(self, q, ctx_text, ctx_ip, batch_q, lq, kv_group):
-        """softmax(q Kt^T) Vt (+ ip_scale * softmax(q Kip^T) Vip) for context tensors [Bc, L, D]."""
+    def project_kv(self, ctx_text, ctx_ip, out=None):
+        """(k, vt, k_ip, vt_ip) of context tensors [Bc, L, D]; `out` = a previous result to overwrite in place."""
         p = self.packed()
         bc, lt, dc = ctx_text.shape
-        k = K.gemm(ctx_text.view(-1, dc), p["wk"])
-        vt = K.project_vt(ctx_text.view(-1, dc), p["wv"], lt)
+        o = out if out is not None else (None, None, None, None)
+        k = K.gemm(ctx_text.view(-1, dc), p["wk"], out=o[0])
+        vt = K.project_vt(ctx_text.view(-1, dc), p["wv"], lt, out=o[1])
+        kip = vtip = None
+        if ctx_ip is not None and self.ip_num_tokens:
+            kip = K.gemm(ctx_ip.view(-1, dc), p["wk_ip"], out=o[2])
+            vtip = K.project_vt(ctx_ip.view(-1, dc), p["wv_ip"], ctx_ip.shape[1], out=o[3])
+        return k, vt, kip, vtip
+
+    def _cross(self, q, ctx_text, ctx_ip, batch_q, lq, kv_group):
+        """softmax(q Kt^T) Vt (+ ip_scale * softmax(q Kip^T) Vip) for context tensors [Bc, L, D] (or a
+        ProjectedContext holding this layer's K / V^T)."""
+        if isinstance(ctx_text, ProjectedContext):
+            k, vt, kip, vtip = ctx_text.kv[self]
+            lt = ctx_text.text.shape[1]
+            li = ctx_text.ip.shape[1] if ctx_text.ip is not None else 0
+        else:
+            k, vt, kip, vtip = self.project_kv(ctx_text, ctx_ip)
+            lt = ctx_text.shape[1]
+            li = ctx_ip.shape[1] if ctx_ip is not None else 0
         o = K.attention(q, k, vt, batch_q=batch_q, lq=lq, lk=lt, heads=self.heads, head_dim=self.dim_head,
                         kv_group=kv_group, scale=self.scale)
-        if ctx_ip is not None and self.ip_num_tokens:
-            li = ctx_ip.shape[1]
-            kip = K.gemm(ctx_ip.view(-1, dc), p["wk_ip"])
-            vtip = K.project_vt(ctx_ip.view(-1, dc), p["wv_ip"], li)
+        if kip is not None and self.ip_num_tokens:
             K.attention(q, kip, vtip, batch_q=batch_q, lq=lq, lk=li, heads=self.heads, head_dim=self.dim_head,
                         kv_group=kv_group, scale=self.scale, out=o, accumulate=True, acc_scale=self.ip_scale)
         return o

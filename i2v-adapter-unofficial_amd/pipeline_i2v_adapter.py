@@ -156,7 +156,8 @@ class I2VAdapterPipeline:
         unet = self.unet
         x = K.ddim_prep(st["latents"], st["cond"], unet.packed()["cin_pad"], st["copies"])    # pipe:668-673
         temb = unet._embed_time(st["t_table"], t_index=st["step_idx"])
-        y = unet._fwd_tokens(x, temb, True, st["ctx_text"], st["ctx_ip"], st["num_frames"])   # pipe:676-683
+        y = unet._fwd_tokens(x, temb, True, st.get("ctx_proj") or st["ctx_text"], st["ctx_ip"],
+                             st["num_frames"])                                          # pipe:676-683
         K.ddim_cfg_step(st["latents"], y, st["coef"], st["step_idx"], st["guidance"], st["copies"])  # pipe:686-691
 
     def _run_steps(self, st, n_steps, use_graph):
@@ -268,6 +269,8 @@ class I2VAdapterPipeline:
             ctx_text=prompt_embeds.to(dev, f16).contiguous(),
             ctx_ip=self.unet._project_image_embeds(
                 {"image_embeds": image_embeds.to(dev)} if image_embeds is not None else None))
+        # K / V^T of the prompt (+ image) context for all 16 cross-attention layers: once per sample, not once per step
+        st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
         if callback is None:
             self._run_steps(st, len(timesteps), use_graph)
         else:

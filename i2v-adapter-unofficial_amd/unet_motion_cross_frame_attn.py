@@ -17,8 +17,8 @@ from torch import nn
 from . import kernels as K
 from ._lib import HipLibraryError
 from .blocks import (Attention, DownBlockMotion, Downsample2D, HipModule, ImageProjection, MotionAdapter,
-                     ResnetBlock2D, TimestepEmbedding, Timesteps, UpBlockMotion, Upsample2D, _as_f16_matrix,
-                     _motion, from_tokens, pack_conv3x3, to_tokens, w16)
+                     ProjectedContext, ProjectedTemb, ResnetBlock2D, TimestepEmbedding, Timesteps, UpBlockMotion,
+                     Upsample2D, _as_f16_matrix, _motion, from_tokens, pack_conv3x3, to_tokens, w16)
 from .checkpoint import PretrainedMixin
 from .i2v_adapter import I2VAdapterModule, I2VAdapterTransformer2DModel
 
@@ -602,11 +602,46 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
             self._packed_key = key
         return self._packed
 
+    def _cross_attention_layers(self):
+        """the spatial blocks' attn2 modules, in attn_processors order."""
+        modules = dict(self.named_modules())
+        return [modules[n[: -len(".processor")]] for n in self.attn_processor_names()
+                if n.endswith("attn2.processor") and "motion_modules" not in n]
+
+    def project_context(self, ctx_text, ctx_ip=None, out: Optional[ProjectedContext] = None) -> ProjectedContext:
+        """K / V^T of the text (+ image) context for every cross-attention layer, computed ONCE per sample instead of in
+        every UNet call (they do not depend on the latents or the timestep).  `out`: a previous result whose buffers
+        are overwritten in place (a captured hipGraph keeps reading the same memory for the next sample)."""
+        pc = out if out is not None else ProjectedContext(ctx_text, ctx_ip)
+        if out is not None:
+            pc.text, pc.ip = ctx_text, ctx_ip
+        for attn in self._cross_attention_layers():
+            pc.kv[attn] = attn.project_kv(ctx_text, ctx_ip, out=pc.kv.get(attn))
+        return pc
+
+    def _temb_pack(self):
+        """time_emb_proj weights of all resnets concatenated ([sum Cout, 4 C0]) + the column slice of each resnet."""
+        resnets = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+        key = tuple((r.time_emb_proj.weight.data_ptr(), r.time_emb_proj.weight._version, r.time_emb_proj.bias._version)
+                    for r in resnets)
+        if getattr(self, "_temb_packed_key", None) != key:
+            with torch.no_grad():
+                w = w16(torch.cat([r.time_emb_proj.weight for r in resnets], dim=0))
+                b = w16(torch.cat([r.time_emb_proj.bias for r in resnets], dim=0))
+            slices, off = {}, 0
+            for r in resnets:
+                slices[r] = (off, r.out_channels)
+                off += r.out_channels
+            self._temb_packed, self._temb_packed_key = (w, b, slices), key
+        return self._temb_packed
+
     def _fwd_tokens(self, x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames):
         """x: model-input tokens [B*F, H, W, cin_pad] fp16; temb [B, 4*C0] fp16 (pre-SiLU); ctx_text [B, Lt, D]
-        (+ ctx_ip [B, 4, D]); returns noise-prediction tokens [B*F, H, W, out_channels]."""
+        (+ ctx_ip [B, 4, D]) or a ProjectedContext; returns noise-prediction tokens [B*F, H, W, out_channels]."""
         p = self.packed()
-        temb_act = K.silu(temb)                                                         # ResnetBlock2D nonlinearity(temb)
+        wt, bt, slices = self._temb_pack()
+        # ResnetBlock2D: time_emb_proj(nonlinearity(temb)) of all 22 resnets in one GEMM
+        temb_act = ProjectedTemb(K.gemm(K.silu(temb), wt, bt), slices)
         x = K.conv3x3(x, p["w_in"], p["b_in"])                                          # unet:1359
         res = (x,)
         for blk in self.down_blocks:                                                    # unet:1362-1377
@@ -667,8 +702,13 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
             timesteps = timesteps[None]
         timesteps = timesteps.to(device=sample.device, dtype=torch.float32).expand(b).contiguous()
         temb = self._embed_time(timesteps)
-        ctx_text = _as_f16_matrix(encoder_hidden_states)
-        ctx_ip = self._project_image_embeds(added_cond_kwargs)
+        if isinstance(encoder_hidden_states, ProjectedContext):     # K / V^T already projected (project_context)
+            ctx_text, ctx_ip = encoder_hidden_states, encoder_hidden_states.ip
+            if self.encoder_hid_proj is not None and ctx_ip is None:
+                self._project_image_embeds(None)                                          # raises like unet:1347-1350
+        else:
+            ctx_text = _as_f16_matrix(encoder_hidden_states)
+            ctx_ip = self._project_image_embeds(added_cond_kwargs)
         p = self.packed()
         x = K.nchw_to_tokens(sample.reshape(b * num_frames, c, hh, ww), p["cin_pad"])     # unet:1358
         y = self._fwd_tokens(x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames)

@@ -148,6 +148,34 @@ def test_small_unet_forward(dev, cross_frame, ip):
             hu(inp["sample"].to(dev), inp["timestep"].to(dev), cross_frame, inp["ctx"].to(dev))
 
 
+def test_projected_context_is_bit_exact(dev):
+    """the per-sample K / V^T cache (project_context) gives the bits of the per-call projection, with and without the
+    IP branch, and refreshing it in place for the next sample rewrites the same buffers."""
+    ou = oracle_small_unet(ip=False)
+    ipsd = small_ip_state_dict(ou)
+    hu = hip_unet_from_oracle(ou, dev, ip_state_dict=ipsd)
+    inp = small_unet_inputs()
+    ctx = inp["ctx"].to(dev).half()
+    ctx_ip = hu._project_image_embeds({"image_embeds": inp["image_embeds"].to(dev)})
+    with torch.no_grad():
+        direct = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, ctx,
+                    added_cond_kwargs={"image_embeds": inp["image_embeds"].to(dev)}).sample
+        pc = hu.project_context(ctx, ctx_ip)
+        assert len(pc.kv) == 16 and all(v[2] is not None for v in pc.kv.values())
+        cached = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, pc,
+                    added_cond_kwargs={"image_embeds": inp["image_embeds"].to(dev)}).sample
+        assert torch.equal(direct, cached)
+        ptrs = {a: tuple(t.data_ptr() for t in v) for a, v in pc.kv.items()}
+        ctx2 = (ctx.float() * 0.5).half()
+        hu.project_context(ctx2, ctx_ip, out=pc)
+        assert ptrs == {a: tuple(t.data_ptr() for t in v) for a, v in pc.kv.items()}
+        direct2 = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, ctx2,
+                     added_cond_kwargs={"image_embeds": inp["image_embeds"].to(dev)}).sample
+        cached2 = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, pc,
+                     added_cond_kwargs={"image_embeds": inp["image_embeds"].to(dev)}).sample
+        assert torch.equal(direct2, cached2) and not torch.equal(direct, direct2)
+
+
 def test_adapter_contributes(dev):
     """with a non-zero adapter to_out the cross-frame branch must change the output (K1 is exercised)."""
     ou = oracle_small_unet()
