@@ -129,6 +129,19 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev):
     return base, parity
 
 
+def write_shape_table(prof, path, what):
+    """where the step's time sits per (kernel wrapper, problem shape, fused extras); algorithmic TFLOP/s and GB/s."""
+    rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1]["ms"])
+    total = sum(d["ms"] for _, d in rows)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        f.write(f"# one instrumented eager step ({what}): {total:.2f} ms in {sum(d['calls'] for _, d in rows)} launches\n")
+        f.write(f"{'launch':58s} {'n':>4s} {'ms':>8s} {'%':>6s} {'us/launch':>10s} {'TFLOP/s':>8s} {'GB/s':>7s}\n")
+        for name, d in rows:
+            f.write(f"{name:58s} {d['calls']:4d} {d['ms']:8.3f} {100 * d['ms'] / total:6.2f} "
+                    f"{1e3 * d['ms'] / d['calls']:10.1f} {d['tflops']:8.1f} {d['gbps']:7.0f}\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +153,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="total (image, prompt) pairs sharded over the ranks (configs[3])")
     ap.add_argument("--batch", type=int, default=1, help="samples per graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shapes", default="", help="write the per-shape time table of the instrumented step here")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
@@ -261,6 +275,8 @@ def main():
             with KernelProfile() as prof:
                 pipe._step(st)
             classes = prof.summary()
+            if args.shapes:
+                write_shape_table(prof, args.shapes, f"frames {F}, {args.size}x{args.size}, ip {ip}, batch {B}")
             dom = max(classes, key=lambda c: classes[c]["ms"])
             d = classes[dom]
             if d["flops"] > 0:

@@ -90,6 +90,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   float2* const lds_st = reinterpret_cast<float2*>(smem + NS * STAGE + 1024);
   float* const lds_ws = reinterpret_cast<float*>(smem + NS * STAGE + 1024 + 2048 + 512);
 
+#if defined(I2V_PROBE) && I2V_PROBE == 5
+  long long stamp[6], cstamp[6];
+  stamp[0] = __builtin_amdgcn_s_memrealtime();
+  cstamp[0] = __builtin_amdgcn_s_memtime();
+#define I2V_STAMP(i) stamp[i] = __builtin_amdgcn_s_memrealtime(); cstamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define I2V_STAMP(i)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -179,6 +187,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         s_tap += 1;
       }
     } else if (kb < ksp) {
+#if defined(I2V_PROBE) && (I2V_PROBE == 3 || I2V_PROBE == 6)
+      if (p.out_scale == 123.f)
+#endif
 #pragma unroll
       for (int i = 0; i < AG; ++i) bdma16(rs_a, sa + (wave + 8 * i) * 1024, a_voff[i], kb * 2);
     } else {   // second source of a channel-concatenated A (skip connections)
@@ -189,6 +200,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         bdma16(rs_a2, sa + (wave + 8 * i) * 1024, voff, (kb - ksp) * 2);
       }
     }
+#if defined(I2V_PROBE) && (I2V_PROBE == 4 || I2V_PROBE == 6)
+    if (p.out_scale == 123.f)
+#endif
 #pragma unroll
     for (int i = 0; i < WG; ++i) {
       const bool in_tile = (WGT % 8 == 0) || (wave + 8 * i < WGT);   // wave-uniform
@@ -283,6 +297,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   if (!STAGGER || wm == 0) {
     for (int kt = kt0; kt < nkt; ++kt) {
       sync_tile(kt);
+      if (kt == kt0) { I2V_STAMP(1); }
       prefetch(kt);
       const int cur = (kt - kt0) % NS;
 #pragma unroll
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     }
     if (nkt > kt0) mma(pwf, paf);
   }
+  I2V_STAMP(2);
   if (LNF) {
     // a row's 32 k of one step sit on the 4 lane groups: fold them, then lane group 0 publishes (mean, rstd) of the
     // rows of this wave's blocks; the epilogue's barrier (with the LDS write retired) makes them visible to every wave
@@ -332,6 +348,16 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
+#if defined(I2V_PROBE) && (I2V_PROBE == 1 || I2V_PROBE == 3 || I2V_PROBE == 4 || I2V_PROBE == 6)
+  if (p.M >= 0) {
+    if (p.out_scale == 123.f) {
+      float t = 0.f;
+      static_for<NI>([&](auto ic) { static_for<MI>([&](auto jc) { t += acc[decltype(ic)::value][decltype(jc)::value][0] + acc[decltype(ic)::value][decltype(jc)::value][1] + acc[decltype(ic)::value][decltype(jc)::value][2] + acc[decltype(ic)::value][decltype(jc)::value][3]; }); });
+      reinterpret_cast<float*>(p.c)[tid] = t;
+    }
+    return;
+  }
+#endif
   // ---------------------------------------------------------------- epilogue (lane: row m, 4 consecutive n)
   // The (epilogue, store mode) pair is a template parameter and the accumulator indices are compile-time constants
   // (static_for): with the generic runtime-switched store the 8 x 5 loop was not unrolled, the 160 accumulators went
@@ -491,6 +517,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         }
       });
     });
+    I2V_STAMP(3);
     static_for<MI>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       static_for<NI>([&](auto ic) {
@@ -535,10 +562,23 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           f16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+#if defined(I2V_PROBE) && I2V_PROBE == 2
+          if (p.out_scale == 123.f)
+#endif
           *reinterpret_cast<f16x8*>(C + m_out * p.ldc + n) = o;
         }
       }
     });
+#if defined(I2V_PROBE) && I2V_PROBE == 5
+    I2V_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    I2V_STAMP(5);
+    if (tid == 0) {
+      long long* dst = reinterpret_cast<long long*>(C + (int64_t)m0 * p.ldc + out_col0);
+      for (int q = 0; q < 6; ++q) dst[q] = stamp[q];
+      for (int q = 0; q < 6; ++q) dst[6 + q] = cstamp[q];
+    }
+#endif
     return;
   }
   static_for<MI>([&](auto jc) {

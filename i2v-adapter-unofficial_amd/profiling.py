@@ -18,37 +18,47 @@ def _numel_bytes(*ts):
 def _work_gemm(args, kw, out):
     a, w = args[0], args[1]
     M, N, Kd = a.shape[0], w.shape[0], w.shape[1]
-    return "gemm", 2.0 * M * N * Kd, _numel_bytes(a, kw.get("a2"), w, kw.get("residual"), out)
+    if kw.get("a2") is not None:
+        Kd = w.shape[1]
+    tag = "".join(t for t, on in ((" geglu", kw.get("epilogue") == K.I2V_EPI_GEGLU), (" gelu", kw.get("epilogue") == K.I2V_EPI_GELU),
+                                  (" +res", kw.get("residual") is not None), (" +ln", kw.get("ln") is not None),
+                                  (" st%d" % kw.get("store", 0), bool(kw.get("store")))) if on)
+    return ("gemm", 2.0 * M * N * Kd, _numel_bytes(a, kw.get("a2"), w, kw.get("residual"), out),
+            f"{M}x{N}x{Kd}{tag}")
 
 
 def _work_conv(args, kw, out):
     x, w = args[0], args[1]
     M = out.shape[0] * out.shape[1] * out.shape[2]
-    return "conv3x3", 2.0 * M * w.shape[0] * w.shape[1], _numel_bytes(x, w, kw.get("residual"), out)
+    return ("conv3x3", 2.0 * M * w.shape[0] * w.shape[1], _numel_bytes(x, w, kw.get("residual"), out),
+            f"{M}x{w.shape[0]}x{w.shape[1]}" + (" s2" if kw.get("stride", 1) == 2 else "")
+            + (" up" if kw.get("upsample") else "") + (" +res" if kw.get("residual") is not None else ""))
 
 
 def _work_attn(args, kw, out):
     c = kw["heads"] * kw["head_dim"]
-    return "attention", 4.0 * kw["batch_q"] * kw["lq"] * kw["lk"] * c, _numel_bytes(args[0], args[1], args[2], out)
+    return ("attention", 4.0 * kw["batch_q"] * kw["lq"] * kw["lk"] * c, _numel_bytes(args[0], args[1], args[2], out),
+            f"B{kw['batch_q']} Lq{kw['lq']} Lk{kw['lk']} h{kw['heads']} d{kw['head_dim']}")
 
 
 def _work_tattn(args, kw, out):
     c = kw["heads"] * kw["head_dim"]
     return ("temporal_attention", 4.0 * kw["n_pixels"] * kw["frames"] * kw["frames"] * c,
-            _numel_bytes(args[0], args[1], out) + kw["n_pixels"] * c * kw["frames"] * 2)
+            _numel_bytes(args[0], args[1], out) + kw["n_pixels"] * c * kw["frames"] * 2,
+            f"px{kw['n_pixels']} F{kw['frames']} h{kw['heads']} d{kw['head_dim']}")
 
 
 def _work_gn(args, kw, out):
-    return "groupnorm", 0.0, 3 * _numel_bytes(out)
+    return "groupnorm", 0.0, 3 * _numel_bytes(out), "x".join(map(str, out.shape))
 
 
 def _work_ln(args, kw, out):
-    return "layernorm", 0.0, 2 * _numel_bytes(out)
+    return "layernorm", 0.0, 2 * _numel_bytes(out), "x".join(map(str, out.shape))
 
 
 def _work_misc(name):
     def f(args, kw, out):
-        return name, 0.0, 2 * _numel_bytes(out)
+        return name, 0.0, 2 * _numel_bytes(out), ""
     return f
 
 
@@ -69,8 +79,8 @@ class KernelProfile:
 
     def _wrap(self, name, fn, work):
         def wrapped(*args, **kw):
-            if self._depth:                      # nested wrapper (project_vt -> gemm): time the outer call only
-                return fn(*args, **kw)
+            if self._depth or kw.get("query_ln_support"):   # nested wrapper: time the outer call only; a support
+                return fn(*args, **kw)                      # query launches nothing
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self._depth += 1
             s.record()
@@ -79,8 +89,8 @@ class KernelProfile:
             finally:
                 self._depth -= 1
             e.record()
-            cls, flops, nbytes = work(args, kw, out)
-            self.records.append((cls, flops, nbytes, s, e))
+            cls, flops, nbytes, detail = work(args, kw, out)
+            self.records.append((cls, flops, nbytes, s, e, f"{name} {detail}".strip()))
             return out
         return wrapped
 
@@ -97,10 +107,18 @@ class KernelProfile:
 
     def summary(self):
         """{class: dict(calls, ms, flops, bytes, tflops, gbps)} after a device synchronise."""
+        return self._aggregate(lambda rec: rec[0])
+
+    def by_shape(self):
+        """the same totals per (wrapper, problem shape, fused extras): which shapes the step's time sits in."""
+        return self._aggregate(lambda rec: rec[5])
+
+    def _aggregate(self, key):
         torch.cuda.synchronize()
         agg = {}
-        for cls, flops, nbytes, s, e in self.records:
-            d = agg.setdefault(cls, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+        for rec in self.records:
+            cls, flops, nbytes, s, e = rec[:5]
+            d = agg.setdefault(key(rec), dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += flops
