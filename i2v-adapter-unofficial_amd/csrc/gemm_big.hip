@@ -40,6 +40,17 @@ __device__ __forceinline__ int fast_div(int m, int d, float inv_d) {
   return q;
 }
 
+// x(l) + x(l ^ mask) through ds_bpermute with the partner's address passed in (derived by the caller from an opaque
+// copy of the lane id at the point of use: __shfl_xor's own lane-id registers get hoisted in front of the tile loop and
+// stay live through the accumulator-bound K loop)
+__device__ __forceinline__ float xor_sum(float x, int partner_addr) {
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner_addr, __builtin_bit_cast(int, x)));
+}
+// a wave-uniform float held in a scalar register (the compiler otherwise keeps such loop invariants in VGPRs)
+__device__ __forceinline__ float uniform_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -70,8 +81,14 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
 
 // LNF: LayerNorm folded into the epilogue (a template parameter: as a runtime branch the 160 accumulators of the two
 // paths met in PHI nodes and the 256-row kernels spilled 170-290 registers).
-template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true, bool LNF = false>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps) {
+// FAST: plain A from one source with M % BM == 0 -- no ragged rows, no second source, so a K tile's DMA is a fixed list of
+// instructions with scalar offsets; these problems (every transformer GEMM of the step) run the persistent tile loop.
+// Everything else (conv, split-K, ragged M, channel-concatenated A) runs one tile per workgroup.
+template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true, bool LNF = false,
+          bool FAST = false>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps,
+                                                       const int ntiles) {
+  static_assert(NS == 2, "the cross-tile prefetch of the persistent tile loop is written for two stages");
   constexpr int BN = BIG_BN;
   constexpr int WM = BM / 2, MI = WM / 16, NI = 5;
   constexpr int AG = BM * BK / 4096;        // 1 KiB (8-unit) A groups per wave: BM * BK * 2 / 1024 groups over 8 waves
@@ -79,21 +96,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   constexpr int WG = (WGT + 7) / 8;         // per wave; for BK = 32 the third one exists for waves 0-3 only
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int KSTEPS = BK / 32;
-  constexpr int LEAD = NS - 1;              // tiles in flight
   // + 1 KiB that swallows the DMA of W groups past the tile (every wave issues the same count: one vmcnt for all)
   // LNF: + 4 KiB holding this tile's LayerNorm row statistics (BM x (mean, rstd)) and the 320 weight row sums.  The
   // statistics are computed IN the K loop from the A fragments every wave reads anyway (the loop streams whole rows of A
   // through the workgroup: K = the normalised width), so there is no statistics kernel and no extra pass over A; the row
   // sums are fetched before the first K tile's DMA, so the epilogue reads both from LDS instead of paying a global-load
   // round trip per tile (measured: +2.2 ms per step with the loads in the epilogue).
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 1024 + (LNF ? 4096 : 0)];
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 1024 + (LNF ? 2048 + 512 + 2 * 1280 : 0)];
   float2* const lds_st = reinterpret_cast<float2*>(smem + NS * STAGE + 1024);
-  float* const lds_ws = reinterpret_cast<float*>(smem + NS * STAGE + 1024 + 2048 + 512);
+  float* const lds_ws2 = reinterpret_cast<float*>(smem + NS * STAGE + 1024 + 2048 + 512);   // two buffers of BN sums
 
 #if defined(I2V_PROBE) && I2V_PROBE == 5
   long long stamp[6], cstamp[6];
-  stamp[0] = __builtin_amdgcn_s_memrealtime();
-  cstamp[0] = __builtin_amdgcn_s_memtime();
 #define I2V_STAMP(i) stamp[i] = __builtin_amdgcn_s_memrealtime(); cstamp[i] = __builtin_amdgcn_s_memtime()
 #else
 #define I2V_STAMP(i)
@@ -102,8 +116,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int g = lane >> 4, l15 = lane & 15;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int M = p.M, N = p.N, K = p.K;
 
   const f16* __restrict__ A = reinterpret_cast<const f16*>(p.a);
@@ -125,90 +137,142 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const int lane_k = (BK == 64 ? c8 : (c8 & 3)) * 8;   // k offset (halfs) of the chunk inside a K tile
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W), 0,
                                                       (int)(((int64_t)(N - 1) * p.ldw + K) * 2), 0x00020000);
-  const unsigned w_voff = (unsigned)(((n0 + r0) * (int)p.ldw + lane_k) * 2);
   const int64_t a_extent = AMODE == I2V_A_CONV3X3 ? ((int64_t)p.n_img * p.in_h * p.in_w - 1) * p.lda + p.cin
                                                   : (int64_t)(M - 1) * p.lda + ksp;
   const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(A), 0, (int)(a_extent * 2), 0x00020000);
   const auto rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<f16*>(A2 ? A2 : A), 0, A2 ? (int)(((int64_t)(M - 1) * p.lda2 + (K - ksp)) * 2) : 0, 0x00020000);
-  unsigned a_voff[AG];                         // plain: byte offset of (row, lane_k) in A, or OOB
-  int c_pix[AG], c_oy[AG], c_ox[AG];           // conv: first pixel of the row's image, output pixel coordinates
+  // Plain A and W: the per-lane part of a DMA offset (row r0 of a 1 KiB group, chunk lane_k) does not depend on the
+  // output tile; the tile's first row / column, the group's row step and the K tile all go into the instruction's SCALAR
+  // offset.  So the K loop carries two address registers per lane whatever the tile, and the next tile's first K tile
+  // can be issued with scalar arithmetic only.
+  const unsigned a_lane = (unsigned)((r0 * (int)p.lda + lane_k) * 2);
+  const unsigned w_lane = (unsigned)((r0 * (int)p.ldw + lane_k) * 2);
+  // conv: output pixel of each of the lane's AG rows (first pixel of its image, oy, ox)
+  auto conv_rows = [&](int tm0, int (&cp)[AG], int (&cy)[AG], int (&cx)[AG]) {
 #pragma unroll
-  for (int i = 0; i < AG; ++i) {
-    const int m = m0 + r0 + RSTEP * i;
-    const bool ok = m < M;
-    if (AMODE == I2V_A_CONV3X3) {
+    for (int i = 0; i < AG; ++i) {
+      const int m = tm0 + r0 + RSTEP * i;
+      const bool ok = m < M;
       const int ohw = p.out_h * p.out_w;
       const int mm = ok ? m : 0;
       const int img = mm / ohw, rem = mm - img * ohw;
-      c_pix[i] = img * p.in_h * p.in_w;
-      c_oy[i] = ok ? rem / p.out_w : -4;       // row >= M: every tap falls outside the image
-      c_ox[i] = rem - (rem / p.out_w) * p.out_w;
-      a_voff[i] = 0;
-    } else {
-      a_voff[i] = ok ? (unsigned)((m * (int)p.lda + lane_k) * 2) : OOB;
-      c_pix[i] = c_oy[i] = c_ox[i] = 0;
+      cp[i] = img * p.in_h * p.in_w;
+      cy[i] = ok ? rem / p.out_w : -4;       // row >= M: every tap falls outside the image
+      cx[i] = rem - (rem / p.out_w) * p.out_w;
     }
-  }
-  // conv: (tap, first channel) of the K tile being issued; cin % BK == 0, so a tile never straddles two taps
-  int s_tap = 0, s_ci = 0;
-  if (AMODE == I2V_A_CONV3X3 && SPLIT) {
-    const int k_first = (int)blockIdx.y * kps * BK;
-    s_tap = k_first / p.cin;
-    s_ci = k_first - s_tap * p.cin;
-  }
+  };
 
-  auto issue = [&](int kt, int stage) {
+  // DMA of K tile kt of the output tile at (tm0, tn0) into LDS stage `stage`.  conv: (cp, cy, cx) = conv_rows(tm0) and
+  // (tap, ci) = the (tap, first channel) of that K tile, advanced here; cin % BK == 0, so a K tile never straddles taps.
+  auto issue_at = [&](int kt, int stage, int tm0, int tn0, const int (&cp)[AG], const int (&cy)[AG], const int (&cx)[AG],
+                      int& tap, int& ci) {
     char* sa = smem + stage * STAGE;
     char* sw = sa + BM * BK * 2;
     const int kb = kt * BK;
     if (AMODE == I2V_A_CONV3X3) {
-      const int dy = s_tap / 3, dx = s_tap - dy * 3;
+      const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
         int iy, ix;
         bool ok;
         if (p.upsample) {
-          const int uy = c_oy[i] - 1 + dy, ux = c_ox[i] - 1 + dx;
+          const int uy = cy[i] - 1 + dy, ux = cx[i] - 1 + dx;
           ok = (uy >= 0) && (ux >= 0) && (uy < 2 * p.in_h) && (ux < 2 * p.in_w);
           iy = uy >> 1;
           ix = ux >> 1;
         } else {
-          iy = c_oy[i] * p.stride - (p.asym_pad ? 0 : 1) + dy;
-          ix = c_ox[i] * p.stride - (p.asym_pad ? 0 : 1) + dx;
+          iy = cy[i] * p.stride - (p.asym_pad ? 0 : 1) + dy;
+          ix = cx[i] * p.stride - (p.asym_pad ? 0 : 1) + dx;
           ok = (iy >= 0) && (ix >= 0) && (iy < p.in_h) && (ix < p.in_w);
         }
-        const unsigned voff = ok ? (unsigned)(((c_pix[i] + iy * p.in_w + ix) * (int)p.lda + s_ci + lane_k) * 2) : OOB;
+        const unsigned voff = ok ? (unsigned)(((cp[i] + iy * p.in_w + ix) * (int)p.lda + ci + lane_k) * 2) : OOB;
         bdma16(rs_a, sa + (wave + 8 * i) * 1024, voff, 0);
       }
-      s_ci += BK;
-      if (s_ci >= p.cin) {
-        s_ci -= p.cin;
-        s_tap += 1;
+      ci += BK;
+      if (ci >= p.cin) {
+        ci -= p.cin;
+        tap += 1;
       }
-    } else if (kb < ksp) {
-#if defined(I2V_PROBE) && (I2V_PROBE == 3 || I2V_PROBE == 6)
-      if (p.out_scale == 123.f)
-#endif
-#pragma unroll
-      for (int i = 0; i < AG; ++i) bdma16(rs_a, sa + (wave + 8 * i) * 1024, a_voff[i], kb * 2);
-    } else {   // second source of a channel-concatenated A (skip connections)
+    } else if (FAST || (kb < ksp && tm0 + BM <= M)) {
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
-        const int m = m0 + r0 + RSTEP * i;
-        const unsigned voff = m < M ? (unsigned)((m * (int)p.lda2 + lane_k) * 2) : OOB;
-        bdma16(rs_a2, sa + (wave + 8 * i) * 1024, voff, (kb - ksp) * 2);
+        // (opaque scalar: otherwise the compiler folds the group's row step into AG per-lane offsets kept in registers
+        // through the whole loop, which the accumulator-bound 256-row LayerNorm kernels cannot afford)
+        int soff = ((tm0 + RSTEP * i) * (int)p.lda + kb) * 2;
+        asm volatile("" : "+s"(soff));
+        bdma16(rs_a, sa + (wave + 8 * i) * 1024, a_lane, soff);
+      }
+    } else {
+      // last row tile of a ragged M (rows >= M carry the out-of-range offset: zero fill), or the second source of a
+      // channel-concatenated A (skip connections).  The lane's row and chunk are re-derived here from an opaque copy of
+      // the lane id, so that these rare forms keep no registers alive in the common loop.
+      int ol = lane;
+      asm volatile("" : "+v"(ol));
+      const int ou0 = 8 * wave + (ol >> 3);
+      const int oc8 = (ol & 7) ^ ((ou0 >> 1) & 7);
+      const int orow = BK == 64 ? ou0 : 2 * ou0 + (oc8 >> 2);
+      const int ok8 = (BK == 64 ? oc8 : (oc8 & 3)) * 8;
+      const bool first = kb < ksp;
+#pragma unroll
+      for (int i = 0; i < AG; ++i) {
+        const int m = tm0 + orow + RSTEP * i;
+        const unsigned voff = m < M ? (unsigned)((m * (int)(first ? p.lda : p.lda2) + ok8) * 2) : OOB;
+        if (first)
+          bdma16(rs_a, sa + (wave + 8 * i) * 1024, voff, kb * 2);
+        else
+          bdma16(rs_a2, sa + (wave + 8 * i) * 1024, voff, (kb - ksp) * 2);
       }
     }
-#if defined(I2V_PROBE) && (I2V_PROBE == 4 || I2V_PROBE == 6)
-    if (p.out_scale == 123.f)
-#endif
 #pragma unroll
     for (int i = 0; i < WG; ++i) {
       const bool in_tile = (WGT % 8 == 0) || (wave + 8 * i < WGT);   // wave-uniform
-      bdma16(rs_w, in_tile ? sw + (wave + 8 * i) * 1024 : smem + NS * STAGE, in_tile ? w_voff : OOB,
-             (RSTEP * i * (int)p.ldw + kb) * 2);
+      bdma16(rs_w, in_tile ? sw + (wave + 8 * i) * 1024 : smem + NS * STAGE, in_tile ? w_lane : OOB,
+             ((tn0 + RSTEP * i) * (int)p.ldw + kb) * 2);
     }
+  };
+
+  // ---- tile loop.  One workgroup per tile by default (a single trip).  In the persistent form (FAST kernels launched
+  //      with min(tiles, CUs) workgroups, see persistent_grid) workgroup b takes tile b of every round of gridDim.x
+  //      tiles (the XCD remap applied inside a round, so a round's tiles are laid out over the XCDs as a
+  //      one-tile-per-workgroup launch would), and the DMA of a tile's FIRST K tile is issued from the previous tile's
+  //      loop (behind its last barrier), landing under that tile's last MFMAs and its epilogue.
+  const int nkt_all = (K + BK - 1) / BK;
+  const int kt0 = SPLIT ? (int)blockIdx.y * kps : 0;
+  const int nkt = SPLIT ? min(nkt_all, kt0 + kps) : nkt_all;
+  static_assert(!FAST || (!SPLIT && AMODE == I2V_A_PLAIN), "FAST is a plain, un-split GEMM");
+  constexpr bool PERSIST = FAST;
+  int sbase = 0;             // LDS stage of the current tile's first K tile
+  bool have_first = false;   // ... which the previous tile's loop has already issued
+  int ws_buf = 0;            // LNF: which of the two weight-row-sum buffers this tile uses
+  for (int round0 = 0; round0 < ntiles; round0 += (int)gridDim.x) {
+  const int in_round = min((int)gridDim.x, ntiles - round0);
+  if ((int)blockIdx.x >= in_round) break;
+  const int tile = round0 + xcd_remap(blockIdx.x, in_round);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int next0 = round0 + (int)gridDim.x;
+  const bool has_next = PERSIST && next0 < ntiles && (int)blockIdx.x < min((int)gridDim.x, ntiles - next0);
+#if defined(I2V_PROBE) && I2V_PROBE == 5
+  I2V_STAMP(0);
+#endif
+  int c_pix[AG], c_oy[AG], c_ox[AG];           // conv: first pixel of the row's image, output pixel coordinates
+  int s_tap = 0, s_ci = 0;                     // conv: (tap, first channel) of the K tile being issued next
+  if (AMODE == I2V_A_CONV3X3) {
+    conv_rows(m0, c_pix, c_oy, c_ox);
+    if (SPLIT) {
+      const int k_first = (int)blockIdx.y * kps * BK;
+      s_tap = k_first / p.cin;
+      s_ci = k_first - s_tap * p.cin;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < AG; ++i) c_pix[i] = c_oy[i] = c_ox[i] = 0;
+  }
+  auto issue = [&](int kt, int stage) { issue_at(kt, stage, m0, n0, c_pix, c_oy, c_ox, s_tap, s_ci); };
+  auto issue_next_first = [&](int stage) {   // K tile 0 of this workgroup's next output tile (plain A only)
+    const int nt = next0 + xcd_remap(blockIdx.x, min((int)gridDim.x, ntiles - next0));
+    int ntap = 0, nci = 0;
+    issue_at(0, stage, (nt / tiles_n) * BM, (nt % tiles_n) * BN, c_pix, c_oy, c_ox, ntap, nci);
   };
 
   f32x4 acc[NI][MI];
@@ -217,43 +281,62 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt_all = (K + BK - 1) / BK;
-  const int kt0 = SPLIT ? (int)blockIdx.y * kps : 0;
-  const int nkt = SPLIT ? min(nkt_all, kt0 + kps) : nkt_all;
-  float ln_col = 0.f;
-  if (LNF) {   // issued ahead of the first tile's DMA: landed by the time that tile's vmcnt(0) returns
-    const float* lnws_g = reinterpret_cast<const float*>(p.ln_wsum);
-    if (tid < BN) ln_col = lnws_g[n0 + tid];
-  }
-#pragma unroll
-  for (int s = 0; s < LEAD; ++s)
-    if (kt0 + s < nkt) issue(kt0 + s, s);
+  // LNF: this column tile's 320 weight row sums into LDS.  Two buffers, alternating per output tile: a slow wave may still
+  // be reading the previous tile's sums in its epilogue.  The wait is the one the first K tile's barrier would do anyway
+  // (everything older -- the previous epilogue's stores, the first K tile's DMA -- is waited for there too); done here,
+  // the value is not carried into the K loop.
+  float* const lds_ws = lds_ws2 + ws_buf * BN;
+  if (!have_first && kt0 < nkt) issue(kt0, sbase);
   if (LNF) {
-    wait_vmcnt<0>();   // the wait the first sync_tile would do anyway (LEAD - 1 tiles stay in flight only for NS > 2)
-    if (tid < BN) lds_ws[tid] = ln_col;
+    const float* lnws_g = reinterpret_cast<const float*>(p.ln_wsum);
+    if (tid < BN) {
+      const float ln_col = lnws_g[n0 + tid];
+      wait_vmcnt<0>();
+      lds_ws[tid] = ln_col;
+    }
+    ws_buf ^= 1;
   }
   auto sync_tile = [&](int kt) {
-    // tile kt has landed once at most the LEAD - 1 tiles issued after it are outstanding (in the tail fewer exist)
-    if (kt + LEAD - 1 < nkt)
-      wait_vmcnt<(LEAD - 1) * (AG + WG)>();
-    else
-      wait_vmcnt<0>();
+    wait_vmcnt<0>();   // K tile kt has landed (one tile in flight)
     // one barrier per K tile: every wave's share of tile kt is in LDS, and every wave has finished reading tile
-    // kt - 1, whose stage is the one refilled next
+    // kt - 1 (or the previous output tile's epilogue slabs), whose stage is the one refilled next
     __builtin_amdgcn_s_barrier();
   };
   auto prefetch = [&](int kt) {
-    if (kt + LEAD < nkt) issue(kt + LEAD, (kt - kt0 + LEAD) % NS);
+    const int stage = (sbase + kt - kt0 + 1) & 1;
+    if (kt + 1 < nkt)
+      issue(kt + 1, stage);
+    else if (has_next)
+      issue_next_first(stage);
   };
+  // Fragment reads.  BK = 64: a row is 128 B and the 16-row steps of a wave's blocks leave the swizzle term
+  // ((row >> 1) & 7) unchanged, so every fragment address is (one per-lane offset per operand) ^ (k-step << 6)
+  // + (block * 2 KiB as the instruction's immediate) + the stage base.  The stage base enters as an opaque scalar: one
+  // v_add per operand and k-step, instead of an address register per (stage, k-step, operand) held through the loop --
+  // the nine registers the accumulator-bound LayerNorm kernels spilled to scratch INSIDE the K loop (a scratch reload
+  // there waits on vmcnt, i.e. on the DMA it should overlap).
+  const int fa_lane = big_lds_addr<BK>(wm * WM + l15, g);
+  const int fw_lane = BM * BK * 2 + big_lds_addr<BK>(wn * 80 + l15, g);
   auto read_frags = [&](int cur, int ks, f16x8 (&wf)[NI], f16x8 (&af)[MI]) {
-    const char* sa = smem + cur * STAGE;
-    const char* sw = sa + BM * BK * 2;
+    if constexpr (BK == 64) {
+      int so = cur * STAGE;
+      asm volatile("" : "+s"(so));
+      const char* pw = smem + ((fw_lane ^ (ks << 6)) + so);
+      const char* pa = smem + ((fa_lane ^ (ks << 6)) + so);
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      wf[i] = *reinterpret_cast<const f16x8*>(sw + big_lds_addr<BK>(wn * 80 + i * 16 + l15, ks * 4 + g));
+      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const f16x8*>(pw + i * 2048);
 #pragma unroll
-    for (int j = 0; j < MI; ++j)
-      af[j] = *reinterpret_cast<const f16x8*>(sa + big_lds_addr<BK>(wm * WM + j * 16 + l15, ks * 4 + g));
+      for (int j = 0; j < MI; ++j) af[j] = *reinterpret_cast<const f16x8*>(pa + j * 2048);
+    } else {
+      const char* sa = smem + cur * STAGE;
+      const char* sw = sa + BM * BK * 2;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        wf[i] = *reinterpret_cast<const f16x8*>(sw + big_lds_addr<BK>(wn * 80 + i * 16 + l15, ks * 4 + g));
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+        af[j] = *reinterpret_cast<const f16x8*>(sa + big_lds_addr<BK>(wm * WM + j * 16 + l15, ks * 4 + g));
+    }
   };
   // D = W_frag * A_frag: lane owns 4 consecutive n of one row m.  For the transposed V^T store the operands are
   // swapped (D = A_frag * W_frag): lane owns 4 consecutive m (keys) of one channel n = an 8-byte run of a V^T row.
@@ -299,7 +382,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       sync_tile(kt);
       if (kt == kt0) { I2V_STAMP(1); }
       prefetch(kt);
-      const int cur = (kt - kt0) % NS;
+      const int cur = (sbase + kt - kt0) & 1;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         f16x8 wf[NI], af[MI];
@@ -309,10 +392,16 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       }
     }
   } else {
+    // (initialised: left undefined on the zero-trip path they become values carried around the whole TILE loop, 52
+    // registers live through the other branch and the epilogue)
     f16x8 pwf[NI], paf[MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) pwf[i] = zero8();
+#pragma unroll
+    for (int j = 0; j < MI; ++j) paf[j] = zero8();
     for (int kt = kt0; kt < nkt; ++kt) {
       sync_tile(kt);
-      const int cur = (kt - kt0) % NS;
+      const int cur = (sbase + kt - kt0) & 1;
       if (kt > kt0) mma(pwf, paf);   // before the DMA address arithmetic: the pending fragments die here
       prefetch(kt);
 #pragma unroll
@@ -333,14 +422,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   if (LNF) {
     // a row's 32 k of one step sit on the 4 lane groups: fold them, then lane group 0 publishes (mean, rstd) of the
     // rows of this wave's blocks; the epilogue's barrier (with the LDS write retired) makes them visible to every wave
-    const float inv_k = 1.0f / (float)K;
+    const float inv_k = uniform_f(1.0f / (float)K);
+    int pl = lane;
+    asm volatile("" : "+v"(pl));
+    const int a16 = (pl ^ 16) << 2, a32 = (pl ^ 32) << 2;
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-      float sv = ln_s[b], qv = ln_q[b];
-      sv += __shfl_xor(sv, 16, 64);
-      qv += __shfl_xor(qv, 16, 64);
-      sv += __shfl_xor(sv, 32, 64);
-      qv += __shfl_xor(qv, 32, 64);
+      const float sv = xor_sum(xor_sum(ln_s[b], a16), a32), qv = xor_sum(xor_sum(ln_q[b], a16), a32);
       const float mean = sv * inv_k;
       const float var = fmaxf(qv * inv_k - mean * mean, 0.f);
       if (g == 0) lds_st[wm * WM + ((MI >= 4 ? wn * RB : 0) + b) * 16 + l15] = float2{mean, rsqrtf(var + p.ln_eps)};
@@ -348,26 +436,26 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
-#if defined(I2V_PROBE) && (I2V_PROBE == 1 || I2V_PROBE == 3 || I2V_PROBE == 4 || I2V_PROBE == 6)
-  if (p.M >= 0) {
-    if (p.out_scale == 123.f) {
-      float t = 0.f;
-      static_for<NI>([&](auto ic) { static_for<MI>([&](auto jc) { t += acc[decltype(ic)::value][decltype(jc)::value][0] + acc[decltype(ic)::value][decltype(jc)::value][1] + acc[decltype(ic)::value][decltype(jc)::value][2] + acc[decltype(ic)::value][decltype(jc)::value][3]; }); });
-      reinterpret_cast<float*>(p.c)[tid] = t;
-    }
-    return;
-  }
-#endif
+  // the next output tile's first K tile is in flight into stage `sbase`; the stage the loop read last is free for the
+  // epilogue's transpose slabs once every wave has left the loop (the epilogues' own barrier)
+  sbase = (sbase + (nkt - kt0)) & 1;
+  have_first = has_next;
+  char* const slab_stage = smem + (sbase ^ 1) * STAGE;
+
   // ---------------------------------------------------------------- epilogue (lane: row m, 4 consecutive n)
   // The (epilogue, store mode) pair is a template parameter and the accumulator indices are compile-time constants
   // (static_for): with the generic runtime-switched store the 8 x 5 loop was not unrolled, the 160 accumulators went
   // through scratch memory and every tile paid ~50 us for it.
+  // (lane and what derives from it enter as arguments made opaque per tile: otherwise the compiler hoists the epilogue's
+  // lane arithmetic -- slab and row addresses, a few dozen registers -- in front of the tile loop, where it stays live
+  // across the accumulator-bound K loop: 70-290 spilled registers in the 256-row kernels)
+  auto epilogue = [&](const int lane, const int g, const int l15, const int tid) {
   const f16* __restrict__ bias = reinterpret_cast<const f16*>(p.bias);
   const f16* __restrict__ resid = reinterpret_cast<const f16*>(p.residual);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(p.rowvec);
   f16* __restrict__ C = reinterpret_cast<f16*>(p.c);
   const float oscale = p.out_scale;
-  const float inv_rpv = 1.0f / (float)(p.rows_per_vec > 0 ? p.rows_per_vec : 1);
+  const float inv_rpv = uniform_f(1.0f / (float)(p.rows_per_vec > 0 ? p.rows_per_vec : 1));
   if (SPLIT) {
     float* __restrict__ ws = reinterpret_cast<float*>(p.workspace) + (int64_t)blockIdx.y * M * N;
     static_for<MI>([&](auto jc) {
@@ -391,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     constexpr int LDS_LD = WM + 4;   // floats: 16 rows start on 16 distinct bank groups
     constexpr int TPR = WM / 8, NT = 16 * TPR;
     __builtin_amdgcn_s_barrier();    // every wave has left the K loop: the stages are free
-    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * LDS_LD);
+    float* stg = reinterpret_cast<float*>(slab_stage) + wave * (16 * LDS_LD);
     if (LNF) {
       // LayerNorm fold: accumulator rows are tokens m = .. + 4 g + r, the column is channel n (l15)
       static_for<MI>([&](auto jc) {
@@ -482,9 +570,50 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     constexpr int OC = EPI == I2V_EPI_GEGLU ? 40 : 80;   // output columns per wave
     constexpr int LDS_LD = OC + 4;                        // floats; 84 / 44: 16 rows start on 16 distinct bank groups
     constexpr int TPR = OC / 8, NT = 16 * TPR;            // 8-column tasks per row / per 16-row block
-    __builtin_amdgcn_s_barrier();                         // every wave has left the K loop: the stages are free
-    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * LDS_LD);
     const int out_col0 = EPI == I2V_EPI_GEGLU ? (n0 >> 1) + wn * 40 : n0 + wn * 80;
+    // One 8-column task of the 16-row block j: (valid, row m, destination row, first column)
+    constexpr int QN = (NT + 63) / 64;
+    auto task = [&](int j, int q, int& row, int& c, int& m, int64_t& m_out, int& n) {
+      const int t = lane + 64 * q;
+      row = t / TPR;
+      c = t - row * TPR;
+      m = m0 + wm * WM + j * 16 + row;
+      m_out = m;
+      if (STORE == I2V_STORE_ROWPERM) {
+        const int per = p.hw * p.frames;
+        const int b = m / per, rem = m - b * per;
+        const int pix = rem / p.frames, f = rem - pix * p.frames;
+        m_out = (int64_t)(b * p.frames + f) * p.hw + pix;
+      }
+      n = out_col0 + c * 8;
+      return t < NT && m < M;
+    };
+    // Residual rows are fetched RES_AHEAD blocks ahead of the block being written (the first ones before the barrier
+    // and the bias pass).  Fetched where they are added, each
+    // block paid a full memory round trip before its stores could go out: eight dependent round trips per tile,
+    // 22 us of a 131072 x 320 x 320 tile's 40 (tools/tile_timeline.py) against 4.6 us without a residual.
+#ifndef I2V_RES_AHEAD
+#define I2V_RES_AHEAD 3
+#endif
+    constexpr int RES_AHEAD = I2V_RES_AHEAD;
+    f16x8 rpre[MI][QN];
+    auto fetch_resid = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        int row, c, m, n;
+        int64_t m_out;
+        rpre[j][q] = zero8();
+        if (task(j, q, row, c, m, m_out, n)) rpre[j][q] = ld_global_16B(resid + m_out * p.ldr + n);
+      }
+    };
+    // (no residual behind a folded LayerNorm: those GEMMs feed q / k / v / the feed-forward; i2v_gemm_big_ln_ok refuses it)
+    const bool use_res = !LNF && EPI != I2V_EPI_GEGLU && resid != nullptr;
+    if (use_res) {
+      static_for<(RES_AHEAD < MI ? RES_AHEAD : MI)>([&](auto jc) { fetch_resid(jc); });
+    }
+    __builtin_amdgcn_s_barrier();                         // every wave has left the K loop: the stages are free
+    float* stg = reinterpret_cast<float*>(slab_stage) + wave * (16 * LDS_LD);
     // bias (and the GEGLU gate, in place: registers 0 / 1 of each accumulator become the two outputs) first, as a
     // pure register pass: fused with the staging below, the GELU temporaries pushed accumulators into scratch
     if (LNF) {
@@ -520,6 +649,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     I2V_STAMP(3);
     static_for<MI>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
+      if constexpr (j + RES_AHEAD < MI) {
+        if (use_res) fetch_resid(std::integral_constant<int, j + RES_AHEAD>{});
+      }
       static_for<NI>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if (EPI == I2V_EPI_GEGLU)
@@ -528,22 +660,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           *reinterpret_cast<f32x4*>(stg + l15 * LDS_LD + i * 16 + 4 * g) = acc[i][j];
       });
 #pragma unroll
-      for (int q = 0; q < (NT + 63) / 64; ++q) {
-        const int t = lane + 64 * q;
-        const int row = t / TPR, c = t - row * TPR;
-        const int m = m0 + wm * WM + j * 16 + row;
-        if (t < NT && m < M) {
+      for (int q = 0; q < QN; ++q) {
+        int row, c, m, n;
+        int64_t m_out;
+        if (task(j, q, row, c, m, m_out, n)) {
           const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
           const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          int64_t m_out = m;
-          if (STORE == I2V_STORE_ROWPERM) {
-            const int per = p.hw * p.frames;
-            const int b = m / per, rem = m - b * per;
-            const int pix = rem / p.frames, f = rem - pix * p.frames;
-            m_out = (int64_t)(b * p.frames + f) * p.hw + pix;
-          }
-          const int n = out_col0 + c * 8;
           if (EPI != I2V_EPI_GEGLU) {
             if (rowvec) {
               const int vrow = p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : fast_div(m, p.rows_per_vec, inv_rpv);
@@ -551,10 +674,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += (float)t8[e];
             }
-            if (resid) {
-              const f16x8 r8 = ld_global_16B(resid + m_out * p.ldr + n);
+            if (use_res) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+              for (int e = 0; e < 8; ++e) v[e] += (float)rpre[j][q][e];
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= oscale;
@@ -562,9 +684,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           f16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-#if defined(I2V_PROBE) && I2V_PROBE == 2
-          if (p.out_scale == 123.f)
-#endif
           *reinterpret_cast<f16x8*>(C + m_out * p.ldc + n) = o;
         }
       }
@@ -626,50 +745,65 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       });
     }
   });
+  };
+  int e_lane = lane;
+  asm volatile("" : "+v"(e_lane));
+  epilogue(e_lane, e_lane >> 4, e_lane & 15, wave * 64 + e_lane);
+  if (!PERSIST) break;
+  }   // persistent tile loop
 }
 
-template <int BM, int BK, int NS, int AMODE>
+// Persistent launch (I2V_GEMM_PERSIST=1; OFF by default): one workgroup per CU walks the tiles, the next tile's first K
+// tile already in flight under the current epilogue.  Measured on the step's shapes (round 2, same box): the in-kernel
+// timeline loses its 2.4-2.8 us first-tile wait, but a cache-warm 131072 x 2560 x 320 GEGLU gains only 2 %, the K = 640
+// GEGLU loses 2.5 %, N = K = 320 gains 7 %, the whole step: 59.3 vs 59.3 ms.  The hardware's own workgroup turnover
+// already hides what the loop hides; what bounds these kernels is the K loop itself (2.3-2.8 us per 64-deep K tile
+// against 1.3 at the clock the chip holds under this load: one 72 KiB stage in flight does not cover the DMA's tail
+// latency, and LDS has no room for a third stage).  Kept as an A/B switch.
+int persistent_grid(int ntiles) {
+  static const int cus = [] {
+    if (!getenv("I2V_GEMM_PERSIST") || atoi(getenv("I2V_GEMM_PERSIST")) == 0) return 0;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return 0;
+    return n;
+  }();
+  return (cus > 0 && ntiles > cus) ? cus : ntiles;
+}
+
+template <int BM, int BK, int NS, int AMODE, bool FAST>
 int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BIG_BN;
-  const dim3 grid(tiles_m * tiles_n), block(512);
+  const int ntiles = tiles_m * tiles_n;
+  const dim3 grid(FAST ? persistent_grid(ntiles) : ntiles), block(512);
+#define I2V_BIG_LAUNCH(EPI, STORE, LNF) \
+  hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, EPI, STORE, false, true, LNF, FAST>), grid, block, 0, s, p, tiles_n, 0, ntiles)
   if (p.ln_wsum != nullptr) {   // LayerNorm-folded epilogues (i2v_gemm_big_ln_ok has vetted the combination)
     if constexpr (AMODE == I2V_A_PLAIN) {
       if (p.epilogue == I2V_EPI_GEGLU)
-        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, false, true, true>), grid,
-                           block, 0, s, p, tiles_n, 0);
+        I2V_BIG_LAUNCH(I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, true);
       else if (p.store_mode == I2V_STORE_VT_T)
-        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_VT_T, false, true, true>), grid, block,
-                           0, s, p, tiles_n, 0);
+        I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT_T, true);
       else if (p.store_mode == I2V_STORE_ROWPERM)
-        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWPERM, false, true, true>), grid,
-                           block, 0, s, p, tiles_n, 0);
+        I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWPERM, true);
       else
-        hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false, true, true>), grid,
-                           block, 0, s, p, tiles_n, 0);
+        I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true);
     }
     const int rc = i2v_check_launch("i2v_gemm_f16(big, LayerNorm fold)");
     return rc < 0 ? rc : 1;
   }
   if (p.epilogue == I2V_EPI_GEGLU) {
-    if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p,
-                         tiles_n, 0);
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, false);
   } else if (p.store_mode == I2V_STORE_ROWPERM) {
-    if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWPERM>), grid, block, 0, s, p,
-                         tiles_n, 0);
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWPERM, false);
   } else if (p.store_mode == I2V_STORE_VT) {
-    if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_VT>), grid, block, 0, s, p, tiles_n,
-                         0);
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT, false);
   } else if (p.store_mode == I2V_STORE_VT_T) {
-    if constexpr (AMODE == I2V_A_PLAIN)
-      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_VT_T>), grid, block, 0, s, p,
-                         tiles_n, 0);
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT_T, false);
   } else {
-    hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWMAJOR>), grid, block, 0, s, p,
-                       tiles_n, 0);
+    I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false);
   }
+#undef I2V_BIG_LAUNCH
   const int rc = i2v_check_launch("i2v_gemm_f16(big)");
   return rc < 0 ? rc : 1;
 }
@@ -679,8 +813,10 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
 template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   (void)vec4;
-  if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, 64, 2, I2V_A_CONV3X3>(p, s);
-  return launch_big_mode<BM, 64, 2, I2V_A_PLAIN>(p, s);
+  if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, 64, 2, I2V_A_CONV3X3, false>(p, s);
+  if (p.a2 == nullptr && p.M % BM == 0 && persistent_grid(1 << 20) != (1 << 20))
+    return launch_big_mode<BM, 64, 2, I2V_A_PLAIN, true>(p, s);
+  return launch_big_mode<BM, 64, 2, I2V_A_PLAIN, false>(p, s);
 }
 
 // ---- split-K: sum the fp32 partial tiles and apply the fused epilogue (bias / time-embedding vector / residual)
@@ -721,10 +857,10 @@ int launch_split(const i2v_gemm_params& p, int vec4, int splits, int kps, hipStr
   const dim3 grid(tiles_m * tiles_n, splits), block(512);
   if (p.a_mode == I2V_A_CONV3X3)
     hipLaunchKernelGGL((gemm_big_kernel<128, 64, 2, I2V_A_CONV3X3, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
-                       tiles_n, kps);
+                       tiles_n, kps, tiles_m * tiles_n);
   else
     hipLaunchKernelGGL((gemm_big_kernel<128, 64, 2, I2V_A_PLAIN, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
-                       tiles_n, kps);
+                       tiles_n, kps, tiles_m * tiles_n);
   const int64_t groups = (int64_t)p.M * (p.N / 4);
   const int blocks = (int)(i2v_cdiv(groups, 256) < 2048 ? i2v_cdiv(groups, 256) : 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, splits, vec4);
@@ -800,8 +936,9 @@ int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4) {
   if (plan != 256 && plan != 128) return 0;
   if (p.a_mode != I2V_A_PLAIN || p.a2 != nullptr) return 0;   // the K loop must stream whole rows of ONE source
   if (p.rowvec && p.rowvec_period > 0 && (p.rowvec_period & (p.rowvec_period - 1)) != 0) return 0;
+  if (p.residual) return 0;   // no consumer of a folded LayerNorm adds a residual; the LNF epilogues do not carry the path
   if (p.store_mode == I2V_STORE_ROWMAJOR || p.store_mode == I2V_STORE_ROWPERM)
-    return (p.epilogue == I2V_EPI_NONE || (p.epilogue == I2V_EPI_GEGLU && !p.rowvec && !p.residual)) ? 1 : 0;
+    return (p.epilogue == I2V_EPI_NONE || (p.epilogue == I2V_EPI_GEGLU && !p.rowvec)) ? 1 : 0;
   if (p.store_mode == I2V_STORE_VT_T)
     return (p.vt_len % 8 == 0 && p.M % 8 == 0 && p.vt_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15) == 0 &&
             (!p.rowvec || (p.rowvec_period >= 8 && (p.rowvec_period & (p.rowvec_period - 1)) == 0 && p.ld_rowvec % 8 == 0)))

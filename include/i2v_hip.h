@@ -98,7 +98,7 @@ typedef struct i2v_gemm_params {
      where mean_m / rstd_m = 1 / sqrt(var_m + ln_eps) are the statistics of row m of A over its K columns, computed
      INSIDE the kernel from the A tiles its K loop streams anyway: the normalised activations are never written to /
      read back from HBM and there is no statistics pass.  NULL = plain GEMM.  Only the 8-wave LDS-DMA kernel
-     implements it (single-source A): i2v_gemm_ln_supported() tells whether a problem qualifies. */
+     implements it (single-source A, no residual): i2v_gemm_ln_supported() tells whether a problem qualifies. */
   const void* ln_wsum;
   float ln_eps;
   void* c;              /* fp16                                                                      */

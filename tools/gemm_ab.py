@@ -13,7 +13,8 @@ def timeit(fn, iters=20, warm=5):
     return s.elapsed_time(e) / iters * 1e3
 out = []
 for M, N, K, kind in [(131072, 320, 320, "plain"), (131072, 2560, 320, "geglu"), (32768, 640, 640, "plain"), (32768, 5120, 640, "geglu"),
-                      (131072, 320, 1280, "resid"), (131072, 320, 320, "vt")]:
+                      (131072, 320, 1280, "resid"), (131072, 320, 320, "resid"), (32768, 640, 640, "resid"), (8192, 1280, 1280, "resid"),
+                      (131072, 320, 320, "vt")]:
     a = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * K ** -0.5).half()
     b = torch.randn(N, device=dev).half()
     if kind == "plain": fn = lambda: k.gemm(a, w, b)
