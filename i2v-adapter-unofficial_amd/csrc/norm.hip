@@ -192,6 +192,117 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   }
 }
 
+// One-launch GroupNorm for the small levels (8 x 8 ... 32 x 32): a workgroup owns a whole (statistics group, block of
+// GB channel groups) slab -- fps * hw rows x GB * cpg channels, <= 64 KiB of fp16 -- reads it ONCE into LDS, takes the
+// exact two-pass statistics there (mean, then sum of squared deviations: no partials, no merge), applies scale / shift
+// (+ SiLU, + the row permutation) and writes it once.  Against the three-launch form (statistics, finalize, apply: two
+// reads + one write and ~3 launch latencies, 20-40 us at these sizes) it is one read + one write in one launch.
+__global__ __launch_bounds__(256) void gn_slab_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2, int c2,
+                                                      const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                      f16* __restrict__ y, int hw, int fps, int groups, int gb, float eps,
+                                                      int silu, int out_perm, int frames) {
+  extern __shared__ __attribute__((aligned(16))) char gn_lds[];
+  __shared__ float red[4];
+  const int C = c1 + c2, cpg = C / groups, cb = gb * cpg, vpr = cb / 8;
+  const int rows = fps * hw;
+  const int ch0 = blockIdx.x * cb, sg = blockIdx.y, tid = threadIdx.x;
+  f16* slab = reinterpret_cast<f16*>(gn_lds);
+  float* coef = reinterpret_cast<float*>(gn_lds + (size_t)rows * cb * 2);   // (a, b) per channel of the block
+  const int nvec = rows * vpr;
+  for (int i = tid; i < nvec; i += 256) {
+    const int r = i / vpr, v = i - r * vpr;
+    const int ch = ch0 + v * 8;
+    const int64_t grow = (int64_t)sg * rows + r;                            // = (sg * fps + frame) * hw + pixel
+    const f16x8 val = ch < c1 ? ld_global_16B(x1 + grow * c1 + ch) : ld_global_16B(x2 + grow * c2 + (ch - c1));
+    *reinterpret_cast<f16x8*>(slab + (size_t)r * cb + v * 8) = val;
+  }
+  __syncthreads();
+  const int qpg = cpg / 4;                 // 8-byte quads per row and group (cpg % 4 == 0, checked on the host)
+  const int nquad = rows * qpg;
+  const float inv_cnt = 1.0f / ((float)rows * (float)cpg);
+  for (int g = 0; g < gb; ++g) {
+    float s = 0.f;
+    for (int i = tid; i < nquad; i += 256) {
+      const int r = i / qpg, q = i - r * qpg;
+      const f16x4 v4 = *reinterpret_cast<const f16x4*>(slab + (size_t)r * cb + g * cpg + q * 4);
+      s += ((float)v4[0] + (float)v4[1]) + ((float)v4[2] + (float)v4[3]);
+    }
+    const float mean = block_sum_256(s, red) * inv_cnt;
+    float m2 = 0.f;
+    for (int i = tid; i < nquad; i += 256) {
+      const int r = i / qpg, q = i - r * qpg;
+      const f16x4 v4 = *reinterpret_cast<const f16x4*>(slab + (size_t)r * cb + g * cpg + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = (float)v4[e] - mean;
+        m2 += d * d;
+      }
+    }
+    const float rstd = rsqrtf(block_sum_256(m2, red) * inv_cnt + eps);
+    for (int i = tid; i < cpg; i += 256) {
+      const int c = g * cpg + i;
+      const float ga = (float)gamma[ch0 + c] * rstd;
+      coef[2 * c] = ga;
+      coef[2 * c + 1] = (float)beta[ch0 + c] - mean * ga;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nvec; i += 256) {
+    const int r = i / vpr, v = i - r * vpr;
+    const f16x8 val = *reinterpret_cast<const f16x8*>(slab + (size_t)r * cb + v * 8);
+    const float4* cf = reinterpret_cast<const float4*>(coef + v * 16);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 ab = cf[e];
+      float r0 = (float)val[2 * e] * ab.x + ab.y;
+      float r1 = (float)val[2 * e + 1] * ab.z + ab.w;
+      if (silu) {
+        r0 = silu_f(r0);
+        r1 = silu_f(r1);
+      }
+      o[2 * e] = (f16)r0;
+      o[2 * e + 1] = (f16)r1;
+    }
+    int64_t orow = (int64_t)sg * rows + r;
+    if (out_perm) {   // images are (b, f): output row = (b * hw + pixel) * frames + f
+      const int64_t img = orow / hw;
+      const int pix = (int)(orow - img * hw);
+      const int64_t b = img / frames;
+      const int f = (int)(img - b * frames);
+      orow = (b * hw + pix) * frames + f;
+    }
+    *reinterpret_cast<f16x8*>(y + orow * C + ch0 + v * 8) = o;
+  }
+}
+
+// channel groups per workgroup of the slab kernel for this problem, 0 = use the three-launch form
+static int gn_slab_plan(int n_img, int hw, int C, int groups, int fps, size_t* lds_bytes) {
+  static const int off = getenv("I2V_GN_SLAB") ? (atoi(getenv("I2V_GN_SLAB")) == 0) : 0;
+  if (off) return 0;
+  const int cpg = C / groups;
+  if (cpg % 4 != 0) return 0;
+  const int64_t rows = (int64_t)fps * hw;
+  // measured (tools/gn_probe.py): slabs up to 64 KiB win (8 x 8: 15 -> 9 us, 28 -> 12 us with the skip concatenated;
+  // 16 x 16: 30 -> 23, 54 -> 39, 41 -> 32 us); the 80 KiB slabs of the 32 x 32 level leave one workgroup per CU with
+  // its load / statistics / store phases in series and LOSE (37 -> 65 us), so that level keeps the three-launch form.
+  // Smallest block of groups whose rows are >= 64 contiguous bytes: small slabs = many workgroups per CU.
+  static const int64_t MAX_LDS = getenv("I2V_GN_SLAB_MAX") ? atoi(getenv("I2V_GN_SLAB_MAX")) : 64 * 1024;
+  static const int ROWB = getenv("I2V_GN_SLAB_ROWB") ? atoi(getenv("I2V_GN_SLAB_ROWB")) : 64;
+  int best = 0;
+  for (int gb = 1; gb <= groups; gb *= 2) {
+    if (groups % gb != 0 || (gb * cpg) % 8 != 0) continue;
+    const int64_t bytes = rows * gb * cpg * 2 + (int64_t)gb * cpg * 8;
+    if (bytes > MAX_LDS) break;
+    const int64_t wgs = (int64_t)(groups / gb) * (n_img / fps);
+    if (wgs < 128) break;                          // too few workgroups for the chip: keep the many-chunk form
+    best = gb;
+    if (gb * cpg * 2 >= ROWB) break;   // rows of >= ROWB contiguous bytes
+  }
+  if (best && lds_bytes) *lds_bytes = (size_t)(rows * best * cpg * 2 + (int64_t)best * cpg * 8);
+  return best;
+}
+
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // one wave per R consecutive rows; the rows live in registers (NV 16-byte vectors per lane and row) so the variance
 // is an exact second pass over registers.  R > 1 is memory-level parallelism: a 320-channel row is one 640-byte load
@@ -333,6 +444,22 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(al16(p.x) && al16(p.y) && (!p.x2 || al16(p.x2)) && al16(p.workspace) && al16(p.gamma) && al16(p.beta),
                 "i2v_groupnorm_f16: pointers must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    size_t lds = 0;
+    const int gb = gn_slab_plan(p.n_img, p.hw, C, p.groups, p.frames_per_stat, &lds);
+    if (gb > 0) {
+      static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_slab_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 97 * 1024) == hipSuccess;
+      if (attr_ok) {
+        hipLaunchKernelGGL(gn_slab_kernel, dim3(p.groups / gb, p.n_img / p.frames_per_stat), dim3(256), lds, s,
+                           reinterpret_cast<const f16*>(p.x), p.c1, reinterpret_cast<const f16*>(p.x2), p.c2,
+                           reinterpret_cast<const f16*>(p.gamma), reinterpret_cast<const f16*>(p.beta),
+                           reinterpret_cast<f16*>(p.y), p.hw, p.frames_per_stat, p.groups, gb, p.eps, p.silu, p.out_perm,
+                           p.frames);
+        return i2v_check_launch("i2v_groupnorm_f16(slab)");
+      }
+    }
+  }
   const int rpc = gn_rows_per_chunk(p.n_img, p.hw);
   const int nchunk = (int)i2v_cdiv(p.hw, rpc);
   float* partial = reinterpret_cast<float*>(p.workspace);

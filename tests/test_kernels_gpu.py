@@ -314,7 +314,11 @@ def test_temporal_attention(dev, npix, frames, heads, d):
     (4, 8, 8, 32, 0, 8, 1, True, False), (2, 16, 16, 320, 0, 32, 1, True, False),
     (4, 8, 8, 64, 0, 32, 4, False, True), (2, 20, 20, 64, 32, 32, 1, True, False),
     (2, 4, 4, 1280, 1280, 32, 1, True, False), (8, 5, 7, 40, 0, 4, 2, False, False),
-    (2, 32, 32, 320, 0, 32, 2, False, True)])
+    (2, 32, 32, 320, 0, 32, 2, False, True),
+    # batches that fill the chip at the small levels run the one-launch slab kernel (whole statistics group in LDS)
+    (32, 8, 8, 1280, 0, 32, 1, True, False), (32, 16, 16, 1280, 1280, 32, 1, True, False),
+    (32, 32, 32, 640, 0, 32, 1, True, False), (32, 16, 16, 1920, 0, 32, 1, False, False),
+    (64, 8, 8, 640, 0, 32, 4, False, True), (32, 8, 8, 1280, 640, 32, 1, True, False)])
 def test_groupnorm(dev, n, hh, ww, c1, c2, groups, fps, silu, perm):
     _groupnorm_case(dev, n, hh, ww, c1, c2, groups, fps, silu, perm, mean=0.5, std=2.0)
 
@@ -325,6 +329,7 @@ def test_groupnorm_large_mean(dev, mean, std):
     E[x^2] - mean^2 cancellation (per-chunk shifted sums + Chan merge).  Spatial and clip-wide statistics."""
     _groupnorm_case(dev, 4, 32, 32, 320, 0, 32, 1, True, False, mean=mean, std=std)
     _groupnorm_case(dev, 4, 16, 16, 64, 64, 32, 2, False, True, mean=mean, std=std)
+    _groupnorm_case(dev, 32, 16, 16, 640, 0, 32, 1, True, False, mean=mean, std=std)      # slab kernel
 
 
 def _groupnorm_case(dev, n, hh, ww, c1, c2, groups, fps, silu, perm, mean, std):
