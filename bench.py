@@ -317,9 +317,13 @@ def main():
         value = sample_steps / elapsed
         step_flops = FLOPS_PER_STEP.get((F, args.size, ip))
         cfg_name = ("configs[3]: batch of pairs, data-parallel" if args.pairs else
-                    "configs[4]" if (F, args.size) == (32, 768) else "configs[2]" if ip else "configs[1]")
+                    "configs[4]" if (F, args.size) == (32, 768) else
+                    "configs[0] shape" if (F, args.size) == (8, 256) else
+                    "configs[2]" if ip and (F, args.size) == (16, 512) else
+                    "configs[1]" if (F, args.size) == (16, 512) else "no BASELINE config")
         out = {
-            "metric": "denoising steps/sec @ 16fx512x512 SD1.5+I2V-Adapter", "value": value,
+            "metric": ("denoising steps/sec @ 16fx512x512 SD1.5+I2V-Adapter" if (F, args.size) == (16, 512) else
+                       f"denoising steps/sec @ {F}fx{args.size}x{args.size} SD1.5+I2V-Adapter"), "value": value,
             "unit": "denoising steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if not args.pairs else "strong",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",

@@ -1,7 +1,9 @@
 #!/bin/bash
 # One GPU-box call that produces every measurement artefact of the round (copy gpurun_out/<tag>_* to profiles/):
 #   <tag>_bench_default.json      python bench.py (configs[1], with the CPU-oracle baseline + parity)
-#   <tag>_bench_configs.jsonl     configs[2] (--ip), configs[4] (32 f x 768^2), configs[3] on one GPU (--pairs 8, batch 1/2/4)
+#   <tag>_bench_configs.jsonl     configs[0] (8 f x 256^2), configs[2] (--ip), configs[4] (32 f x 768^2), configs[3] on one GPU
+#                                 (--pairs 8, batch 1/2/4)
+#   <tag>_step_shapes.txt         where one step's time sits per (kernel, problem shape) (bench.py --shapes)
 #   <tag>_kernel_stats.txt        rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2`
 #   <tag>_pmc_summary.txt         per-kernel PMC table (tools/pmc_step.sh)
 #   <tag>_traffic.json            bytes below L2 per launch by kernel class (tools/pmc_traffic.sh)
@@ -9,8 +11,9 @@ set -e
 cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-r2}
 export TMPDIR=/tmp
-python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
+python bench.py --shapes gpurun_out/${tag}_step_shapes.txt > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 : > gpurun_out/${tag}_bench_configs.jsonl
+python bench.py --frames 8 --size 256 --no-cpu-baseline 2>/dev/null >> gpurun_out/${tag}_bench_configs.jsonl
 python bench.py --ip --no-cpu-baseline 2>/dev/null >> gpurun_out/${tag}_bench_configs.jsonl
 python bench.py --frames 32 --size 768 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null >> gpurun_out/${tag}_bench_configs.jsonl
 for b in 1 2 4; do
