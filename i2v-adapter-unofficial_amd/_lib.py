@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # I2V_LIB_PATH selects another build of the same ABI (same-box A/B of two kernels, tools/ab_bench.sh); the in-tree
 # library is never overwritten by tooling
 LIB_PATH = os.environ.get("I2V_LIB_PATH") or os.path.join(_HERE, "libi2v_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
 I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
@@ -40,6 +40,8 @@ class GemmParams(C.Structure):
         ("n_img", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("cin", C.c_int32),
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32),
         ("asym_pad", C.c_int32),
+        ("w_batch_stride", C.c_int64), ("rows_per_w", C.c_int32),
+        ("a_perm_frames", C.c_int32), ("a_perm_hw", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
@@ -98,11 +100,13 @@ SIGNATURES = {
     "i2v_last_error": (C.c_char_p, []),
     "i2v_gemm_f16": (C.c_int, [C.POINTER(GemmParams), _P]),
     "i2v_gemm_ln_supported": (C.c_int, [C.POINTER(GemmParams)]),
+    "i2v_gemm_batch_supported": (C.c_int, [C.POINTER(GemmParams)]),
     "i2v_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmParams)]),
     "i2v_attention_f16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "i2v_temporal_attention_f16": (C.c_int, [C.POINTER(TAttnParams), _P]),
     "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_groupnorm_f16": (C.c_int, [C.POINTER(GnParams), _P]),
+    "i2v_groupnorm_fold_f16": (C.c_int, [C.POINTER(GnParams), _P, C.c_int64, _P, C.c_int32, _P, _P, _P]),
     "i2v_layernorm_f16": (C.c_int, [C.POINTER(LnParams), _P]),
     "i2v_softmax_rows_f16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "i2v_nchw_to_tokens": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

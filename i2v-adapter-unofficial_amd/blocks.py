@@ -141,6 +141,48 @@ class ProjectedTemb:
         return self.all_proj[:, off: off + n]
 
 
+GN_FOLD = os.environ.get("I2V_GN_FOLD", "1") != "0"
+
+
+def gn_proj_in(x, gamma, beta, groups, eps, w, bias, frames=0):
+    """proj_in(GroupNorm(x)) at the entry of a spatial transformer (i2v:218-226) or, with frames > 0, of a motion module
+    (statistics over the clip's frames, rows re-ordered to (b, pixel, frame)).  x: [N, H, W, C] tokens.
+
+    Where it pays -- the per-group weight stack is small beside the activations -- the norm is FOLDED into the GEMM: its
+    per-image (per-clip) scale multiplies the weights, its shift becomes a per-image bias (`K.groupnorm_fold`), and the
+    GEMM reads the un-normalised x directly (for the motion module through the permuted row gather).  The normalised
+    tensor is neither written nor read back: one pass over x for the statistics instead of two passes + one write."""
+    n, hh, ww, c = x.shape
+    hw = hh * ww
+    fps = frames if frames > 0 else 1
+    s_groups, n_out = n // fps, w.shape[0]
+    if GN_FOLD and 4 * s_groups * n_out <= n * hw:            # weight stack <= a quarter of the activation bytes
+        kw = dict(rows_per_vec=fps * hw, w_rows=fps * hw, a_perm=(frames, hw) if frames > 0 else None)
+        if _fold_supported(x, s_groups, n_out, kw):
+            w_s, b_s = K.groupnorm_fold(x, gamma, beta, groups, eps, w, bias, frames_per_stat=fps)
+            return K.gemm(x.view(-1, c), w_s, None, rowvec=b_s, **kw)
+    if frames > 0:
+        h = K.groupnorm(x, gamma, beta, groups, eps, frames_per_stat=frames, out_perm=True, frames=frames)
+    else:
+        h = K.groupnorm(x, gamma, beta, groups, eps).view(-1, c)
+    return K.gemm(h, w, bias)
+
+
+_FOLD_OK = {}
+
+
+def _fold_supported(x, s_groups, n_out, kw):
+    """does the library implement the batched-weight (+ permuted gather) GEMM for this shape?  (asked once per shape)"""
+    key = (tuple(x.shape), s_groups, n_out, kw["w_rows"], kw["a_perm"])
+    ok = _FOLD_OK.get(key)
+    if ok is None:
+        c = x.shape[3]
+        w_s = torch.empty((s_groups, n_out, c), dtype=f16, device=x.device)
+        b_s = torch.empty((s_groups, n_out), dtype=f16, device=x.device)
+        ok = _FOLD_OK[key] = K.gemm(x.view(-1, c), w_s, None, rowvec=b_s, query_batch_support=True, **kw)
+    return ok
+
+
 def to_tokens(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
     """reference NCHW tensor -> token-major fp16 [N, H, W, C]."""
     return K.nchw_to_tokens(x, c_pad)
@@ -624,9 +666,7 @@ class TransformerTemporalModel(HipModule):
         if n % num_frames != 0:
             raise ValueError(f"batch {n} is not a multiple of num_frames {num_frames}")
         n_pixels = (n // num_frames) * hh * ww
-        h = K.groupnorm(x, p["g"], p["b"], self.groups, 1e-6, frames_per_stat=num_frames, out_perm=True,
-                        frames=num_frames)                                   # rows now (b, pixel, frame)
-        t = K.gemm(h, p["wi"], p["bi"])
+        t = gn_proj_in(x, p["g"], p["b"], self.groups, 1e-6, p["wi"], p["bi"], frames=num_frames)   # rows now (b, pixel, frame)
         for blk in self.transformer_blocks:
             t = blk._fwd(t, n_pixels, num_frames)
         out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c), store=I2V_STORE_ROWPERM, frames=num_frames,

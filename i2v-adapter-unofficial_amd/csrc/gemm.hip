@@ -339,6 +339,11 @@ extern "C" int i2v_gemm_ln_supported(const i2v_gemm_params* pp) {
   return i2v_gemm_big_ln_ok(*pp, vector_epilogue_ok(*pp));
 }
 
+extern "C" int i2v_gemm_batch_supported(const i2v_gemm_params* pp) {
+  if (pp == nullptr || pp->M <= 0 || pp->N <= 0 || pp->K <= 0) return 0;
+  return i2v_gemm_big_unsplit_ok(*pp, vector_epilogue_ok(*pp));
+}
+
 extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(pp != nullptr, "i2v_gemm_f16: null params");
   const i2v_gemm_params& p = *pp;
@@ -412,6 +417,13 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
                p.store_mode);
   }
 
+  if (p.rows_per_w > 0 || p.a_perm_frames > 0) {
+    I2V_CHECK_ARG(p.rows_per_w >= 0 && p.a_perm_frames >= 0 && p.w_batch_stride >= 0, "i2v_gemm_f16: negative batch / permutation field");
+    if (!i2v_gemm_big_unsplit_ok(p, vec4))
+      I2V_FAIL(I2V_ERR_INVALID_ARG, "i2v_gemm_f16: per-batch weights / the permuted A gather are not implemented for this "
+               "problem (M %d N %d K %d, rows_per_w %d, a_perm %d x %d): they need the 8-wave kernel with full row tiles",
+               p.M, p.N, p.K, p.rows_per_w, p.a_perm_frames, p.a_perm_hw);
+  }
   // large problems whose N is a multiple of 320 go to the 8-wave LDS-DMA kernel (gemm_big.hip)
   {
     const int big = i2v_gemm_big_try(p, vec4, reinterpret_cast<hipStream_t>(stream));

@@ -135,8 +135,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const int c8 = lc ^ ((u0 >> 1) & 7);         // logical chunk this lane fetches (swizzle on the SOURCE side)
   const int r0 = BK == 64 ? u0 : 2 * u0 + (c8 >> 2);
   const int lane_k = (BK == 64 ? c8 : (c8 & 3)) * 8;   // k offset (halfs) of the chunk inside a K tile
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W), 0,
-                                                      (int)(((int64_t)(N - 1) * p.ldw + K) * 2), 0x00020000);
+  const int n_wbatch = p.rows_per_w > 0 ? M / p.rows_per_w : 1;
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<f16*>(W), 0, (int)(((int64_t)(n_wbatch - 1) * p.w_batch_stride + (int64_t)(N - 1) * p.ldw + K) * 2), 0x00020000);
   const int64_t a_extent = AMODE == I2V_A_CONV3X3 ? ((int64_t)p.n_img * p.in_h * p.in_w - 1) * p.lda + p.cin
                                                   : (int64_t)(M - 1) * p.lda + ksp;
   const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(A), 0, (int)(a_extent * 2), 0x00020000);
@@ -146,7 +147,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   // output tile; the tile's first row / column, the group's row step and the K tile all go into the instruction's SCALAR
   // offset.  So the K loop carries two address registers per lane whatever the tile, and the next tile's first K tile
   // can be issued with scalar arithmetic only.
-  const unsigned a_lane = (unsigned)((r0 * (int)p.lda + lane_k) * 2);
+  // a_perm (motion-module entry): output rows are (b, pixel, frame), A rows (b, frame, pixel).  A 1 KiB group holds 8
+  // consecutive output rows; with frames | 64 the frame of a lane's row is r0 % frames for every group and tile, and its
+  // pixel is (a scalar) + r0 / frames: the gather is a different per-lane constant plus a different scalar offset.
+  const int pf = p.a_perm_frames;
+  const int pf_shift = pf > 0 ? 31 - __builtin_clz(pf) : 0;
+  const unsigned a_lane = pf > 0 ? (unsigned)((((r0 & (pf - 1)) * p.a_perm_hw + (r0 >> pf_shift)) * (int)p.lda + lane_k) * 2)
+                                 : (unsigned)((r0 * (int)p.lda + lane_k) * 2);
   const unsigned w_lane = (unsigned)((r0 * (int)p.ldw + lane_k) * 2);
   // conv: output pixel of each of the lane's AG rows (first pixel of its image, oy, ox)
   auto conv_rows = [&](int tm0, int (&cp)[AG], int (&cy)[AG], int (&cx)[AG]) {
@@ -195,11 +202,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         tap += 1;
       }
     } else if (FAST || (kb < ksp && tm0 + BM <= M)) {
+      int arow0 = tm0, astep = RSTEP;   // first A row of group 0, rows between groups
+      if (pf > 0) {                     // (b, pixel, frame) rows tm0 .. : clip b, first pixel tp
+        const int per = pf * p.a_perm_hw;
+        const int tb = tm0 / per, tp = (tm0 - tb * per) >> pf_shift;
+        arow0 = tb * per + tp;
+        astep = RSTEP >> pf_shift;
+      }
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
         // (opaque scalar: otherwise the compiler folds the group's row step into AG per-lane offsets kept in registers
         // through the whole loop, which the accumulator-bound 256-row LayerNorm kernels cannot afford)
-        int soff = ((tm0 + RSTEP * i) * (int)p.lda + kb) * 2;
+        int soff = ((arow0 + astep * i) * (int)p.lda + kb) * 2;
         asm volatile("" : "+s"(soff));
         bdma16(rs_a, sa + (wave + 8 * i) * 1024, a_lane, soff);
       }
@@ -224,11 +238,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           bdma16(rs_a2, sa + (wave + 8 * i) * 1024, voff, (kb - ksp) * 2);
       }
     }
+    const int wb_off = p.rows_per_w > 0 ? (int)((tm0 / p.rows_per_w) * p.w_batch_stride * 2) : 0;   // this tile's weights
 #pragma unroll
     for (int i = 0; i < WG; ++i) {
       const bool in_tile = (WGT % 8 == 0) || (wave + 8 * i < WGT);   // wave-uniform
       bdma16(rs_w, in_tile ? sw + (wave + 8 * i) * 1024 : smem + NS * STAGE, in_tile ? w_lane : OOB,
-             ((tn0 + RSTEP * i) * (int)p.ldw + kb) * 2);
+             ((tn0 + RSTEP * i) * (int)p.ldw + kb) * 2 + wb_off);
     }
   };
 
@@ -904,6 +919,19 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
     if (p.rowvec && (p.ld_rowvec % 8 != 0 || !a16(p.rowvec))) return 0;
   }
   if (p.rowvec && p.M >= (1 << 24)) return 0;   // the epilogue's reciprocal division of the row index is exact below 2^24
+  if (p.rows_per_w > 0 || p.a_perm_frames > 0) {
+    // per-batch weights / the permuted A gather exist only in the full-tile DMA path of the un-split kernel
+    if (p.a_mode != I2V_A_PLAIN || p.a2 != nullptr || p.M % 256 != 0) return 0;
+    if (p.rows_per_w > 0 && (p.rows_per_w % 256 != 0 || p.M % p.rows_per_w != 0 ||
+                             (int64_t)(p.M / p.rows_per_w) * p.w_batch_stride >= (1ll << 30)))
+      return 0;
+    if (p.a_perm_frames > 0) {
+      const int f = p.a_perm_frames;
+      if ((f & (f - 1)) != 0 || f > 64 || p.a_perm_hw <= 0 || p.a_perm_hw % (64 / f) != 0 ||
+          ((int64_t)f * p.a_perm_hw) % 256 != 0 || p.M % (f * p.a_perm_hw) != 0)
+        return 0;
+    }
+  }
   const int64_t tn = p.N / BIG_BN;
   const int64_t t256 = i2v_cdiv(p.M, 256) * tn, t128 = i2v_cdiv(p.M, 128) * tn;
   if (mode == 256 || mode == 128) return mode;
@@ -944,6 +972,12 @@ int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4) {
             (!p.rowvec || (p.rowvec_period >= 8 && (p.rowvec_period & (p.rowvec_period - 1)) == 0 && p.ld_rowvec % 8 == 0)))
                ? 1 : 0;
   return 0;
+}
+
+// 1 if the 8-wave kernel takes this problem un-split (per-batch weights and the permuted A gather exist only there)
+int i2v_gemm_big_unsplit_ok(const i2v_gemm_params& p, int vec4) {
+  const int plan = big_plan(p, vec4, nullptr, nullptr);
+  return plan == 256 || plan == 128;
 }
 
 int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {

@@ -118,5 +118,6 @@ __device__ __forceinline__ void gemm_store4(const i2v_gemm_params& p, const int 
 int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s);
 // 1 if gemm_big.hip takes this problem AND implements the LayerNorm fold (ln_wsum) for its epilogue
 int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4);
+int i2v_gemm_big_unsplit_ok(const i2v_gemm_params& p, int vec4);
 // fp32 scratch bytes with which gemm_big.hip would split K for this problem (0: no split)
 int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4);

@@ -303,6 +303,26 @@ static int gn_slab_plan(int n_img, int hw, int C, int groups, int fps, size_t* l
   return best;
 }
 
+// GroupNorm folded into the consuming Linear: one workgroup per (output row n, statistics group s)
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ coef, int fps, int C, const f16* __restrict__ w,
+                                                      int64_t ldw, const f16* __restrict__ bias, int n_out,
+                                                      f16* __restrict__ w_out, f16* __restrict__ bias_out) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, sg = blockIdx.y;
+  const float2* ab = reinterpret_cast<const float2*>(coef) + (int64_t)sg * fps * C;   // the group's first image
+  const f16* wr = w + (int64_t)n * ldw;
+  f16* wo = w_out + ((int64_t)sg * n_out + n) * C;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float2 v = ab[c];
+    const float wv = (float)wr[c];
+    wo[c] = (f16)(wv * v.x);
+    acc += wv * v.y;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) bias_out[(int64_t)sg * n_out + n] = (f16)(acc + (bias ? (float)bias[n] : 0.f));
+}
+
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // one wave per R consecutive rows; the rows live in registers (NV 16-byte vectors per lane and row) so the variance
 // is an exact second pass over registers.  R > 1 is memory-level parallelism: a 320-channel row is one 640-byte load
@@ -425,6 +445,38 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 extern "C" int64_t i2v_groupnorm_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels) {
   const int64_t nchunk = i2v_cdiv(hw, gn_rows_per_chunk(n_img, hw));
   return ((int64_t)n_img * nchunk * channels * 2 + (int64_t)n_img * channels * 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int i2v_groupnorm_fold_f16(const i2v_gn_params* pp, const void* w, int64_t ldw, const void* bias, int32_t n_out,
+                                      void* w_out, void* bias_out, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_groupnorm_fold_f16: null params");
+  const i2v_gn_params& p = *pp;
+  const int C = p.c1 + p.c2;
+  I2V_CHECK_ARG(p.x && p.gamma && p.beta && p.workspace && w && w_out && bias_out, "i2v_groupnorm_fold_f16: null pointer");
+  I2V_CHECK_ARG(p.n_img > 0 && p.hw > 0 && p.c1 > 0 && p.c2 >= 0 && n_out > 0 && ldw >= C,
+                "i2v_groupnorm_fold_f16: bad sizes");
+  I2V_CHECK_ARG((p.c2 == 0) == (p.x2 == nullptr), "i2v_groupnorm_fold_f16: x2 / c2 mismatch");
+  I2V_CHECK_ARG(p.c1 % 8 == 0 && p.c2 % 8 == 0, "i2v_groupnorm_fold_f16: channel counts must be multiples of 8");
+  I2V_CHECK_ARG(p.groups > 0 && C % p.groups == 0, "i2v_groupnorm_fold_f16: channels %d not divisible by groups %d", C,
+                p.groups);
+  I2V_CHECK_ARG(p.frames_per_stat > 0 && p.n_img % p.frames_per_stat == 0,
+                "i2v_groupnorm_fold_f16: n_img %d not divisible by frames_per_stat %d", p.n_img, p.frames_per_stat);
+  I2V_CHECK_ARG(al16(p.x) && (!p.x2 || al16(p.x2)) && al16(p.workspace) && al16(p.gamma) && al16(p.beta),
+                "i2v_groupnorm_fold_f16: pointers must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rpc = gn_rows_per_chunk(p.n_img, p.hw);
+  const int nchunk = (int)i2v_cdiv(p.hw, rpc);
+  float* partial = reinterpret_cast<float*>(p.workspace);
+  float* coef = partial + (int64_t)p.n_img * nchunk * C * 2;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, reinterpret_cast<const f16*>(p.x), p.c1,
+                     reinterpret_cast<const f16*>(p.x2), p.c2, p.hw, rpc, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, partial, nchunk, C,
+                     p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
+                     reinterpret_cast<const f16*>(p.beta), coef);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(n_out, p.n_img / p.frames_per_stat), dim3(256), 0, s, coef, p.frames_per_stat, C,
+                     reinterpret_cast<const f16*>(w), ldw, reinterpret_cast<const f16*>(bias), n_out,
+                     reinterpret_cast<f16*>(w_out), reinterpret_cast<f16*>(bias_out));
+  return i2v_check_launch("i2v_groupnorm_fold_f16");
 }
 
 extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {

@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
-from .blocks import (Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
+from .blocks import (gn_proj_in, Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
                      to_tokens, w16)
 from .checkpoint import PretrainedMixin
 
@@ -299,8 +299,7 @@ class I2VAdapterTransformer2DModel(HipModule):
     def _fwd(self, x, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip):
         p = self.packed()
         n_img, hh, ww, c = x.shape
-        h = K.groupnorm(x, p["g"], p["b"], self.groups, 1e-6)                                # i2v:218
-        t = K.gemm(h.view(-1, c), p["wi"], p["bi"])                                          # i2v:219-226
+        t = gn_proj_in(x, p["g"], p["b"], self.groups, 1e-6, p["wi"], p["bi"])             # i2v:218-226
         for blk in self.transformer_blocks:                                                  # i2v:285-295
             t = blk._fwd(t, n_img, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip)
         out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c))                            # i2v:298-314

@@ -55,8 +55,12 @@ def pad8(n: int) -> int:
 # ---------------------------------------------------------------------------------------------- GEMM / conv
 def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0, epilogue=I2V_EPI_NONE,
          out=None, store=I2V_STORE_ROWMAJOR, frames=0, hw=0, vt_len=0, vt_ld=0, out_scale=1.0, ln=None,
-         rowvec_period=0, query_ln_support=False):
+         rowvec_period=0, query_ln_support=False, w_rows=0, a_perm=None, query_batch_support=False):
     """C = epi(A W^T + bias + rowvec + residual) * out_scale   (see i2v_gemm_f16).
+
+    w may be a stack [S, N, K] of weight matrices with w_rows = rows of A per matrix (GroupNorm folded into proj_in,
+    groupnorm_fold).  a_perm = (frames, hw): A's rows are (batch, frame, pixel) and are read as (batch, pixel, frame).
+    query_batch_support=True launches nothing and returns whether the library implements those two for this problem.
 
     ln = (wsum fp32 [N], eps): LayerNorm of A's rows folded into the GEMM (w = W o gamma, bias = W beta + b; the row
     statistics are computed inside the kernel; see i2v_gemm_params.ln_wsum).  rowvec_period > 0: rowvec row = m % period (with a VT_T store the
@@ -64,10 +68,20 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
     implements the fold for exactly this problem."""
     lib = _lib.load()
     a, lda = _mat(a, "a")
+    w_stack = None
+    if w.dim() == 3:
+        _req(w, "w")
+        if w_rows <= 0 or not w.is_contiguous() or a.shape[0] != w.shape[0] * w_rows:
+            raise ValueError(f"stacked w {tuple(w.shape)} needs contiguous storage and w_rows with S * w_rows == M")
+        w_stack, w = w, w[0]
     w, ldw = _mat(w, "w")
     M, K1 = a.shape
     N, K = w.shape
     p = GemmParams()
+    if w_stack is not None:
+        p.w_batch_stride, p.rows_per_w = w_stack.stride(0), w_rows
+    if a_perm is not None:
+        p.a_perm_frames, p.a_perm_hw = int(a_perm[0]), int(a_perm[1])
     p.a, p.lda = _p(a), lda
     if a2 is not None:
         a2, lda2 = _mat(a2, "a2")
@@ -128,6 +142,8 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
     p.out_scale = out_scale
     if query_ln_support:
         return bool(lib.i2v_gemm_ln_supported(C.byref(p)))
+    if query_batch_support:
+        return bool(lib.i2v_gemm_batch_supported(C.byref(p)))
     ws = _attach_splitk_workspace(lib, p, a.device)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16")
     del ws
@@ -324,6 +340,49 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_st
     p.workspace = _p(ws)
     _lib.check(lib.i2v_groupnorm_f16(C.byref(p), _stream()), "i2v_groupnorm_f16")
     return y
+
+
+def groupnorm_fold(x, gamma, beta, groups, eps, w, bias, *, x2=None, frames_per_stat=1):
+    """GroupNorm (no activation) of x [N, H, W, C1] (+ x2 along C) folded into the Linear (w [n_out, C], bias) that
+    consumes it: returns (w_s [S, n_out, C], bias_s [S, n_out]) with S = N / frames_per_stat statistics groups, such that
+    Linear(GroupNorm(x)) = x w_s[s]^T + bias_s[s] for the rows of group s (i2v_groupnorm_fold_f16)."""
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"x must be contiguous [N, H, W, C], got {tuple(x.shape)}")
+    n, h, wd, c1 = x.shape
+    c2 = 0
+    if x2 is not None:
+        _req(x2, "x2")
+        if x2.dim() != 4 or not x2.is_contiguous() or x2.shape[:3] != x.shape[:3]:
+            raise ValueError("x2 must be contiguous [N, H, W, C2] with the same N, H, W as x")
+        c2 = x2.shape[3]
+    Cc = c1 + c2
+    _req(gamma, "gamma")
+    _req(beta, "beta")
+    w2, ldw = _mat(w, "w")
+    if gamma.numel() != Cc or beta.numel() != Cc or w2.shape[1] != Cc:
+        raise ValueError(f"gamma / beta / w columns must have {Cc} elements")
+    n_out = w2.shape[0]
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != n_out or not bias.is_contiguous():
+            raise ValueError("bias must be a contiguous vector of n_out elements")
+    if frames_per_stat <= 0 or n % frames_per_stat != 0:
+        raise ValueError(f"batch {n} is not a multiple of frames_per_stat {frames_per_stat}")
+    S = n // frames_per_stat
+    ws = torch.empty((lib.i2v_groupnorm_workspace_bytes(n, h * wd, Cc) + 3) // 4, dtype=torch.float32, device=x.device)
+    w_s = torch.empty((S, n_out, Cc), dtype=f16, device=x.device)
+    b_s = torch.empty((S, n_out), dtype=f16, device=x.device)
+    p = GnParams()
+    p.x, p.c1, p.x2, p.c2 = _p(x), c1, _p(x2), c2
+    p.gamma, p.beta = _p(gamma.contiguous()), _p(beta.contiguous())
+    p.n_img, p.hw, p.groups, p.frames_per_stat = n, h * wd, groups, frames_per_stat
+    p.eps = eps
+    p.workspace = _p(ws)
+    _lib.check(lib.i2v_groupnorm_fold_f16(C.byref(p), _p(w2), ldw, _p(bias), n_out, _p(w_s), _p(b_s), _stream()),
+               "i2v_groupnorm_fold_f16")
+    return w_s, b_s
 
 
 def layernorm(x, gamma, beta, eps, *, pe=None, pe_period=0):

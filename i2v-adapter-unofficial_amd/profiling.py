@@ -52,6 +52,11 @@ def _work_gn(args, kw, out):
     return "groupnorm", 0.0, 3 * _numel_bytes(out), "x".join(map(str, out.shape))
 
 
+def _work_gn_fold(args, kw, out):
+    x = args[0]   # statistics pass: one read of x (+ x2); the weight stack is small beside it
+    return "groupnorm", 0.0, _numel_bytes(x, kw.get("x2")), "fold " + "x".join(map(str, x.shape))
+
+
 def _work_ln(args, kw, out):
     return "layernorm", 0.0, 2 * _numel_bytes(out), "x".join(map(str, out.shape))
 
@@ -64,7 +69,7 @@ def _work_misc(name):
 
 _WRAPPED = {
     "gemm": _work_gemm, "conv3x3": _work_conv, "attention": _work_attn, "temporal_attention": _work_tattn,
-    "groupnorm": _work_gn, "layernorm": _work_ln, "silu": _work_misc("elementwise"),
+    "groupnorm": _work_gn, "groupnorm_fold": _work_gn_fold, "layernorm": _work_ln, "silu": _work_misc("elementwise"),
     "copy3d": _work_misc("elementwise"), "timestep_embedding": _work_misc("elementwise"),
     "ddim_prep": _work_misc("elementwise"), "ddim_cfg_step": _work_misc("elementwise"),
     "nchw_to_tokens": _work_misc("elementwise"), "tokens_to_nchw": _work_misc("elementwise"),

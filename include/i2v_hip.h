@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 2
+#define I2V_ABI_VERSION 3
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -115,6 +115,16 @@ typedef struct i2v_gemm_params {
      bottom / right = diffusers Downsample2D(padding=0) of the VAE encoder (F.pad(x, (0, 1, 0, 1)) + conv stride 2).
      M = n_img * out_h * out_w. */
   int32_t n_img, in_h, in_w, cin, out_h, out_w, stride, upsample, asym_pad;
+  /* Per-batch weights (GroupNorm folded into the proj_in GEMM of a transformer / motion-module entry, i2v:218-226, A9:
+     the norm's per-image scale multiplies the weights, its shift becomes a per-image bias -- i2v_groupnorm_fold_f16):
+     rows [i * rows_per_w, (i + 1) * rows_per_w) of A use the weight matrix w + i * w_batch_stride (elements).
+     rows_per_w = 0: one weight matrix.  8-wave kernel only (N % 320 == 0, M and rows_per_w multiples of the row tile). */
+  int64_t w_batch_stride;
+  int32_t rows_per_w;
+  /* A rows gathered through the (batch, frame, pixel) -> (batch, pixel, frame) permutation (the motion modules' entry,
+     SURVEY A9): output row m = (b * a_perm_hw + p) * a_perm_frames + f reads A row (b * a_perm_frames + f) * a_perm_hw + p.
+     a_perm_frames = 0: none; otherwise a power of two <= 64.  Same kernel restriction. */
+  int32_t a_perm_frames, a_perm_hw;
   /* optional fp32 scratch for split-K (small M, long K: the 8 x 8 level's convolutions): when it holds at least
      i2v_gemm_workspace_bytes(p) bytes the K loop is split over several workgroups whose fp32 partial tiles are
      summed by a second kernel that applies the epilogue; NULL / too small => no split. */
@@ -125,6 +135,8 @@ typedef struct i2v_gemm_params {
 int i2v_gemm_f16(const i2v_gemm_params* p, i2v_stream_t stream);
 /* 1 if i2v_gemm_f16 accepts this problem with ln_wsum set (pointers are not dereferenced), else 0. */
 int i2v_gemm_ln_supported(const i2v_gemm_params* p);
+/* 1 if i2v_gemm_f16 accepts this problem with rows_per_w / a_perm_frames set (pointers are not dereferenced), else 0. */
+int i2v_gemm_batch_supported(const i2v_gemm_params* p);
 /* bytes of `workspace` with which i2v_gemm_f16 would split K for this problem (0: it would not split). */
 int64_t i2v_gemm_workspace_bytes(const i2v_gemm_params* p);
 
@@ -197,6 +209,16 @@ typedef struct i2v_gn_params {
 
 int64_t i2v_groupnorm_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels);
 int i2v_groupnorm_f16(const i2v_gn_params* p, i2v_stream_t stream);
+/* GroupNorm (no activation) folded into the Linear / 1x1 conv that consumes it (the entry of every spatial transformer
+ * and motion module: norm -> proj_in, i2v:218-226): the statistics of p->x are computed as above, then instead of
+ * writing the normalised tensor, per statistics group s (= image, or clip when frames_per_stat > 1)
+ *     w_out[s][n][c]  = fp16(w[n][c] * a[s][c])              a = gamma * rstd
+ *     bias_out[s][n]  = fp16(bias[n] + sum_c w[n][c] b[s][c])  b = beta - mean * a
+ * so that proj_in(GroupNorm(x)) = x w_out[s]^T + bias_out[s] (i2v_gemm_params.w_batch_stride / rows_per_w, bias through
+ * rowvec / rows_per_vec): the normalised activations are never written to / read back from HBM.  p->y, silu, out_perm
+ * are ignored.  w [n_out, ldw >= C] fp16, w_out [n_img / frames_per_stat, n_out, C], bias_out [.., n_out] fp16. */
+int i2v_groupnorm_fold_f16(const i2v_gn_params* p, const void* w, int64_t ldw, const void* bias, int32_t n_out,
+                           void* w_out, void* bias_out, i2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis (fp32 statistics), optional additive positional embedding

@@ -332,6 +332,48 @@ def test_groupnorm_large_mean(dev, mean, std):
     _groupnorm_case(dev, 32, 16, 16, 640, 0, 32, 1, True, False, mean=mean, std=std)      # slab kernel
 
 
+@pytest.mark.parametrize("n,hh,c,n_out,fps,mean", [(32, 32, 320, 320, 1, 0.5), (32, 32, 320, 640, 16, 2.0),
+                                                   (32, 64, 320, 320, 16, 0.0), (16, 32, 640, 640, 1, 20.0)])
+def test_groupnorm_folded_into_gemm(dev, n, hh, c, n_out, fps, mean):
+    """GroupNorm -> Linear as ONE GEMM over per-statistics-group scaled weights (i2v_groupnorm_fold_f16 +
+    i2v_gemm_params.w_batch_stride / rows_per_w), and for the motion modules' entry (statistics over a clip's frames) the
+    (b, frame, pixel) -> (b, pixel, frame) row gather in the same GEMM (a_perm_*)."""
+    k = K()
+    g = torch.Generator().manual_seed(n + c + fps)
+    x = h(torch.randn(n, c, hh, hh, generator=g) * 1.5 + mean)
+    ga, be = h(1 + 0.3 * torch.randn(c, generator=g)), h(0.3 * torch.randn(c, generator=g))
+    w = h(torch.randn(n_out, c, generator=g) / math.sqrt(c))
+    b = h(torch.randn(n_out, generator=g))
+    hw = hh * hh
+    if fps == 1:
+        y = F.group_norm(x, 32, ga, be, eps=1e-6)
+    else:   # statistics over (C / G, frames, H, W) of each clip (SURVEY A9)
+        xc = x.view(n // fps, fps, c, hh, hh).permute(0, 2, 1, 3, 4)
+        y = F.group_norm(xc, 32, ga, be, eps=1e-6).permute(0, 2, 1, 3, 4).reshape(n, c, hh, hh)
+    tok = y.permute(0, 2, 3, 1).reshape(n * hw, c)
+    if fps > 1:
+        tok = tok.view(n // fps, fps, hw, c).permute(0, 2, 1, 3).reshape(n * hw, c)
+    ref = tok @ w.T + b
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    w_s, b_s = k.groupnorm_fold(xt, ga.half().to(dev), be.half().to(dev), 32, 1e-6, w.half().to(dev), b.half().to(dev),
+                                frames_per_stat=fps)
+    assert w_s.shape == (n // fps, n_out, c) and b_s.shape == (n // fps, n_out)
+    kw = dict(rowvec=b_s, rows_per_vec=fps * hw, w_rows=fps * hw, a_perm=(fps, hw) if fps > 1 else None)
+    assert k.gemm(xt.view(-1, c), w_s, None, query_batch_support=True, **kw)
+    got = k.gemm(xt.view(-1, c), w_s, None, **kw)
+    close(got, ref, name="GroupNorm folded into proj_in")
+
+
+def test_gemm_batched_weights_unsupported_shapes_fail_loudly(dev):
+    import i2v_adapter_unofficial_amd as pkg
+    k = K()
+    x = torch.randn(2048, 320, device=dev).half()
+    w = torch.randn(8, 320, 320, device=dev).half()
+    assert not k.gemm(x, w, None, w_rows=256, query_batch_support=True)      # too few tiles for the 8-wave kernel
+    with pytest.raises(pkg.HipLibraryError, match="not implemented for this"):
+        k.gemm(x, w, None, w_rows=256)
+
+
 def _groupnorm_case(dev, n, hh, ww, c1, c2, groups, fps, silu, perm, mean, std):
     k = K()
     g = torch.Generator().manual_seed(n + c1)
