@@ -142,6 +142,7 @@ class ProjectedTemb:
 
 
 GN_FOLD = os.environ.get("I2V_GN_FOLD", "1") != "0"
+GN_FOLD_RATIO = float(os.environ.get("I2V_GN_FOLD_RATIO", "4"))   # fold when activations >= ratio x the weight stack
 
 
 def gn_proj_in(x, gamma, beta, groups, eps, w, bias, frames=0):
@@ -156,7 +157,7 @@ def gn_proj_in(x, gamma, beta, groups, eps, w, bias, frames=0):
     hw = hh * ww
     fps = frames if frames > 0 else 1
     s_groups, n_out = n // fps, w.shape[0]
-    if GN_FOLD and 4 * s_groups * n_out <= n * hw:            # weight stack <= a quarter of the activation bytes
+    if GN_FOLD and GN_FOLD_RATIO * s_groups * n_out <= n * hw:   # weight stack small beside the activation bytes
         kw = dict(rows_per_vec=fps * hw, w_rows=fps * hw, a_perm=(frames, hw) if frames > 0 else None)
         if _fold_supported(x, s_groups, n_out, kw):
             w_s, b_s = K.groupnorm_fold(x, gamma, beta, groups, eps, w, bias, frames_per_stat=fps)

@@ -66,6 +66,9 @@ __device__ __forceinline__ uint32_t pack_rn(float a, float b) {
 // the MFMA compute the row sum.
 // The head_dim 40 variant (the 64 x 64 level: 80 % of the attention time) is held to 128 VGPRs = 4 waves / SIMD (its
 // few spills land outside the key loop): +5 % over the 154-VGPR / 3-wave build.  d = 64 spills inside the loop at 128.
+#ifndef I2V_ATTN_XCD_REMAP
+#define I2V_ATTN_XCD_REMAP 1
+#endif
 template <int DQK, int DPV, int QT, int KVT, bool SPARE>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(DQK == 64 && DPV == 48 && QT == 2 && KVT == 64 ? 4 : 1)))
@@ -85,10 +88,25 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  const int bq = blockIdx.z, h = blockIdx.y;
+  // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin in launch order, so with the natural order the
+  // query blocks of one (batch, head) -- which all stream the same K / V^T -- land on all 8 L2s and each L2 holds a slice
+  // of EVERY pair in flight.  Re-deal: XCD x takes pairs x, x + 8, ... and walks all query blocks of a pair before the
+  // next, so a pair's K / V^T (655 KB at the 64 x 64 level) is fetched into one L2 once.  Speed only.
+  int qb = blockIdx.x, h = blockIdx.y, bq = blockIdx.z;
+  {
+    const int nqb = gridDim.x, pairs = gridDim.y * gridDim.z;
+    if (I2V_ATTN_XCD_REMAP && pairs % 8 == 0) {
+      const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int xcd = lin & 7, slot = lin >> 3;
+      const int pair = (slot / nqb) * 8 + xcd;
+      qb = slot % nqb;
+      h = pair % (int)gridDim.y;
+      bq = pair / (int)gridDim.y;
+    }
+  }
   const int bkv = bq / p.kv_group;
   const int d = p.head_dim, lq = p.lq, lk = p.lk;
-  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const int q0 = qb * (64 * QT) + wave * (16 * QT);
 
   const f16* __restrict__ Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
   const f16* __restrict__ Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
@@ -393,6 +411,8 @@ inline bool al(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>
 
 }  // namespace
 
+int i2v_attention32_try(const i2v_attn_params& p, hipStream_t s);   // attention32.hip: head_dim 40 / 48 on 32x32x16 MFMAs
+
 extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(pp != nullptr, "i2v_attention_f16: null params");
   const i2v_attn_params& p = *pp;
@@ -418,6 +438,10 @@ extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream)
   const int d = p.head_dim;
   if (d <= 16) return launch_d<32, 16>(p, s);
   if (d <= 32) return launch_d<32, 32>(p, s);
+  if (d > 32 && d <= 48) {
+    const int rc = i2v_attention32_try(p, s);
+    if (rc != 0) return rc < 0 ? rc : I2V_OK;
+  }
   if (d <= 48) return launch_d<64, 48>(p, s);
   if (d <= 64) return launch_d<64, 64>(p, s);
   if (d <= 80) return launch_d<96, 80>(p, s);

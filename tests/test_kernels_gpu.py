@@ -274,6 +274,39 @@ def test_attention(dev, bq, group, heads, d, lq, lk):
     close(out2.view(bq, lq, c), prev.view(bq, lq, c) + 0.75 * ref, name="attention accumulate")
 
 
+def test_attention_32x32_formulation_opt_in(dev):
+    """the head_dim-40 kernel on 32x32x16 MFMAs (attention32.hip) is opt-in (I2V_ATTN32=1, read once per process): run
+    it in a child process against torch SDPA, with a query tail, a key tail, K/V sharing and the accumulate form."""
+    import os, subprocess, sys
+    code = r"""
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+import i2v_adapter_unofficial_amd as pkg
+k = pkg.kernels; dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+for bq, group, heads, lq, lk in ((4, 2, 8, 300, 700), (2, 1, 8, 1024, 1024)):
+    d = 40; c = heads * d; bkv = bq // group
+    hf = lambda t: t.half().float()
+    q, kk, v = hf(torch.randn(bq, lq, c, generator=g)), hf(torch.randn(bkv, lk, c, generator=g)), hf(torch.randn(bkv, lk, c, generator=g))
+    sp = lambda t, b: t.view(b, -1, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, bq), sp(kk.repeat_interleave(group, 0), bq), sp(v.repeat_interleave(group, 0), bq)).transpose(1, 2).reshape(bq, lq, c)
+    ld = k.pad8(lk); vt = torch.full((bkv, c, ld), float("nan")); vt[:, :, :lk] = v.permute(0, 2, 1)
+    args = (q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev))
+    kw = dict(batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    out = k.attention(*args, **kw).float().cpu().view(bq, lq, c)
+    err = (out - ref).abs().max().item()
+    prev = hf(torch.randn(bq * lq, c, generator=g)); out2 = prev.half().to(dev)
+    k.attention(*args, out=out2, accumulate=True, acc_scale=0.75, **kw)
+    err2 = (out2.float().cpu().view(bq, lq, c) - (prev.view(bq, lq, c) + 0.75 * ref)).abs().max().item()
+    print("ERR", err, err2)
+    assert err < 3e-3 and err2 < 5e-3, (err, err2)
+print("OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, I2V_ATTN32="1"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_attention_strided_qk_and_spike(dev):
     """q / k read as column slices of a fused projection; one spiked key forces the online-softmax rescale."""
     k = K()
