@@ -51,6 +51,10 @@ __device__ __forceinline__ float uniform_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
 
+#ifndef I2V_GEMM_PANEL
+#define I2V_GEMM_PANEL 8
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -247,6 +251,23 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     }
   };
 
+  // Tile id -> (row tile, column tile).  An XCD runs 32 consecutive ids at a time (xcd_remap): row-major ids make that
+  // 32 / tiles_n row tiles x tiles_n column tiles, i.e. with the 16 / 32 column tiles of the feed-forward GEMMs one or two
+  // A tiles against 16 / 32 different W tiles -- every CU of the XCD streams its own 820 KB of weights through an L2 that
+  // holds 4 MB.  Ids are therefore laid out in column panels of 8 (I2V_GEMM_PANEL): 32 consecutive ids = 4 row tiles x 8
+  // column tiles, each A tile shared by 8 CUs and each W tile by 4.
+  const int tiles_m_all = ntiles / tiles_n;
+  auto tile_coords = [&](int id, int& tm, int& tn) {
+    if (I2V_GEMM_PANEL > 0 && tiles_n > I2V_GEMM_PANEL && tiles_n % I2V_GEMM_PANEL == 0) {
+      const int per_panel = tiles_m_all * I2V_GEMM_PANEL;
+      const int panel = id / per_panel, r = id - panel * per_panel;
+      tm = r / I2V_GEMM_PANEL;
+      tn = panel * I2V_GEMM_PANEL + (r - tm * I2V_GEMM_PANEL);
+    } else {
+      tm = id / tiles_n;
+      tn = id - tm * tiles_n;
+    }
+  };
   // ---- tile loop.  One workgroup per tile by default (a single trip).  In the persistent form (FAST kernels launched
   //      with min(tiles, CUs) workgroups, see persistent_grid) workgroup b takes tile b of every round of gridDim.x
   //      tiles (the XCD remap applied inside a round, so a round's tiles are laid out over the XCDs as a
@@ -264,7 +285,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const int in_round = min((int)gridDim.x, ntiles - round0);
   if ((int)blockIdx.x >= in_round) break;
   const int tile = round0 + xcd_remap(blockIdx.x, in_round);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  int tile_m, tile_n;
+  tile_coords(tile, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int next0 = round0 + (int)gridDim.x;
   const bool has_next = PERSIST && next0 < ntiles && (int)blockIdx.x < min((int)gridDim.x, ntiles - next0);
 #if defined(I2V_PROBE) && I2V_PROBE == 5
@@ -287,7 +310,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   auto issue_next_first = [&](int stage) {   // K tile 0 of this workgroup's next output tile (plain A only)
     const int nt = next0 + xcd_remap(blockIdx.x, min((int)gridDim.x, ntiles - next0));
     int ntap = 0, nci = 0;
-    issue_at(0, stage, (nt / tiles_n) * BM, (nt % tiles_n) * BN, c_pix, c_oy, c_ox, ntap, nci);
+    int ntm, ntn;
+    tile_coords(nt, ntm, ntn);
+    issue_at(0, stage, ntm * BM, ntn * BN, c_pix, c_oy, c_ox, ntap, nci);
   };
 
   f32x4 acc[NI][MI];
