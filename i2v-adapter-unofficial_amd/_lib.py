@@ -39,7 +39,7 @@ class GemmParams(C.Structure):
         ("out_scale", C.c_float),
         ("n_img", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("cin", C.c_int32),
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32),
-        ("asym_pad", C.c_int32),
+        ("asym_pad", C.c_int32), ("conv_kblock", C.c_int32),
         ("w_batch_stride", C.c_int64), ("rows_per_w", C.c_int32),
         ("a_perm_frames", C.c_int32), ("a_perm_hw", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),

@@ -53,12 +53,16 @@ def w16(t: torch.Tensor) -> torch.Tensor:
 
 
 def pack_conv3x3(weight: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] -> [Cout, 9 * Cin'] with k = (ky * 3 + kx) * Cin' + ci (Cin zero-padded to Cin')."""
+    """[Cout, Cin, 3, 3] -> [Cout, 9 * Cin'] (Cin zero-padded to Cin') in the contraction order the conv kernel walks:
+    tap-major k = (ky * 3 + kx) * Cin' + ci, or, when Cin' % 64 == 0 (`K.conv_k_block`), channel-block-major
+    k = ((ci // 64) * 9 + ky * 3 + kx) * 64 + ci % 64."""
     co, ci = weight.shape[:2]
     w = weight.detach().permute(0, 2, 3, 1)
     if cin_pad is not None and cin_pad != ci:
         w = torch.nn.functional.pad(w, (0, cin_pad - ci))
         ci = cin_pad
+    if K.conv_k_block(ci):
+        w = w.reshape(co, 9, ci // 64, 64).permute(0, 2, 1, 3)          # [co, channel block, tap, 64]
     return w.reshape(co, 9 * ci).to(f16).contiguous()
 
 

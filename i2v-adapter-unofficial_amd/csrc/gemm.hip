@@ -91,7 +91,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
     const int k = kt * BK + cc * 8;
     const bool kok = k < K;
     if (AMODE == I2V_A_CONV3X3) {
-      const int tap = k / p.cin, ci = k - tap * p.cin;
+      int tap, ci;
+      if (p.conv_kblock) {   // k = ((ci / 64) * 9 + tap) * 64 + ci % 64
+        const int blk = k >> 6;
+        tap = blk % 9;
+        ci = (blk / 9) * 64 + (k & 63);
+      } else {
+        tap = k / p.cin;
+        ci = k - tap * p.cin;
+      }
       const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
@@ -361,6 +369,8 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     I2V_CHECK_ARG(p.stride == 1 || p.stride == 2, "i2v_gemm_f16: conv stride must be 1 or 2");
     I2V_CHECK_ARG(!(p.upsample && p.stride != 1), "i2v_gemm_f16: upsample conv must have stride 1");
     I2V_CHECK_ARG(!p.asym_pad || (p.stride == 2 && !p.upsample), "i2v_gemm_f16: asym_pad needs stride 2, no upsample");
+    I2V_CHECK_ARG(p.conv_kblock == 0 || (p.conv_kblock == 64 && p.cin % 64 == 0),
+                  "i2v_gemm_f16: conv_kblock must be 0 or 64 (with cin %% 64 == 0), got %d for cin %d", p.conv_kblock, p.cin);
     const int padsum = p.asym_pad ? 1 : 2;
     const int eh = p.upsample ? 2 * p.in_h : (p.in_h + padsum - 3) / p.stride + 1;
     const int ew = p.upsample ? 2 * p.in_w : (p.in_w + padsum - 3) / p.stride + 1;

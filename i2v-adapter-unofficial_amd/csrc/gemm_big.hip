@@ -200,10 +200,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         const unsigned voff = ok ? (unsigned)(((cp[i] + iy * p.in_w + ix) * (int)p.lda + ci + lane_k) * 2) : OOB;
         bdma16(rs_a, sa + (wave + 8 * i) * 1024, voff, 0);
       }
-      ci += BK;
-      if (ci >= p.cin) {
-        ci -= p.cin;
+      if (p.conv_kblock) {   // channel-block-major: the 9 taps of this 64-channel block, then the next block
         tap += 1;
+        if (tap == 9) {
+          tap = 0;
+          ci += BK;
+        }
+      } else {
+        ci += BK;
+        if (ci >= p.cin) {
+          ci -= p.cin;
+          tap += 1;
+        }
       }
     } else if (FAST || (kb < ksp && tm0 + BM <= M)) {
       int arow0 = tm0, astep = RSTEP;   // first A row of group 0, rows between groups
@@ -299,8 +307,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     conv_rows(m0, c_pix, c_oy, c_ox);
     if (SPLIT) {
       const int k_first = (int)blockIdx.y * kps * BK;
-      s_tap = k_first / p.cin;
-      s_ci = k_first - s_tap * p.cin;
+      if (p.conv_kblock) {
+        const int blk = k_first / BK;
+        s_tap = blk % 9;
+        s_ci = (blk / 9) * BK;
+      } else {
+        s_tap = k_first / p.cin;
+        s_ci = k_first - s_tap * p.cin;
+      }
     }
   } else {
 #pragma unroll
@@ -929,6 +943,7 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
   if ((int64_t)p.N * p.ldw >= (1ll << 30)) return 0;
   if (p.a_mode == I2V_A_CONV3X3) {
     if (p.cin % 64 != 0 || (int64_t)p.n_img * p.in_h * p.in_w * p.lda >= (1ll << 30)) return 0;
+    if (p.conv_kblock != 0 && p.conv_kblock != 64) return 0;
   } else if ((int64_t)p.M * p.lda >= (1ll << 30) || (int64_t)p.M * p.lda2 >= (1ll << 30)) {
     return 0;
   }

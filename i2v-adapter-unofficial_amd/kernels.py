@@ -6,6 +6,7 @@ torch.empty and launches the HIP kernel on torch's current stream through ctypes
 torch ops and nothing falls back to the CPU: a CPU tensor or a missing library raises.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -160,10 +161,18 @@ def _attach_splitk_workspace(lib, p, device):
     return ws
 
 
+def conv_k_block(cin: int) -> int:
+    """contraction order of the 3x3 convolution for this (padded) channel count: 64 = channel-block-major (the 9 taps
+    of a 64-channel block are consecutive, i2v_gemm_params.conv_kblock), 0 = tap-major.  `blocks.pack_conv3x3` lays the
+    weights out by the same rule."""
+    return 64 if cin % 64 == 0 and os.environ.get("I2V_CONV_KBLOCK", "1") != "0" else 0
+
+
 def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
             out_scale=1.0, asym_pad=False):
     """3x3 / pad 1 convolution of a token-major image x [N, H, W, Cin] with w_packed [Cout, 9 * Cin]
-    (k = (ky * 3 + kx) * Cin + ci); optional nearest-2x upsampling of the input first.  asym_pad (stride 2): no
+    (k ordered as `blocks.pack_conv3x3` lays it out: tap-major, or channel-block-major when Cin % 64 == 0, see
+    conv_k_block); optional nearest-2x upsampling of the input first.  asym_pad (stride 2): no
     padding at the top / left, one zero row / column at the bottom / right (the VAE encoder's Downsample2D(padding=0))."""
     lib = _lib.load()
     _req(x, "x")
@@ -211,6 +220,7 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     p.n_img, p.in_h, p.in_w, p.cin = n, h, wd, cin
     p.out_h, p.out_w, p.stride, p.upsample = oh, ow, stride, 1 if upsample else 0
     p.asym_pad = 1 if asym_pad else 0
+    p.conv_kblock = conv_k_block(cin)
     ws = _attach_splitk_workspace(lib, p, x.device)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16(conv3x3)")
     del ws

@@ -115,6 +115,11 @@ typedef struct i2v_gemm_params {
      bottom / right = diffusers Downsample2D(padding=0) of the VAE encoder (F.pad(x, (0, 1, 0, 1)) + conv stride 2).
      M = n_img * out_h * out_w. */
   int32_t n_img, in_h, in_w, cin, out_h, out_w, stride, upsample, asym_pad;
+  /* order of the 9 * cin contraction index of I2V_A_CONV3X3 (and of w's columns): 0 = tap-major, k = tap * cin + ci;
+     64 = channel-block-major, k = ((ci / 64) * 9 + tap) * 64 + ci % 64 (cin % 64 == 0): the 9 taps of one 64-channel
+     block are consecutive K tiles, so the 8 re-reads of an input pixel hit L2 instead of coming back from MALL / HBM
+     three K-panels later. */
+  int32_t conv_kblock;
   /* Per-batch weights (GroupNorm folded into the proj_in GEMM of a transformer / motion-module entry, i2v:218-226, A9:
      the norm's per-image scale multiplies the weights, its shift becomes a per-image bias -- i2v_groupnorm_fold_f16):
      rows [i * rows_per_w, (i + 1) * rows_per_w) of A use the weight matrix w + i * w_batch_stride (elements).

@@ -11,7 +11,7 @@ def pkg():
     return p
 
 
-def test_pack_conv3x3_is_tap_major():
+def test_pack_conv3x3_orders():
     from i2v_adapter_unofficial_amd.blocks import pack_conv3x3, pack_geglu
     w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
     p = pack_conv3x3(w, cin_pad=8)
@@ -22,6 +22,12 @@ def test_pack_conv3x3_is_tap_major():
                 for ci in range(8):
                     exp = w[co, ci, ky, kx] if ci < 3 else 0
                     assert p[co, (ky * 3 + kx) * 8 + ci] == exp
+    # channel counts that are multiples of 64 are laid out channel-block-major: k = ((ci // 64) * 9 + tap) * 64 + ci % 64
+    w2 = torch.randn(3, 128, 3, 3)
+    p2 = pack_conv3x3(w2)
+    assert p2.shape == (3, 9 * 128)
+    for co, ci, ky, kx in ((0, 0, 0, 0), (1, 63, 2, 1), (2, 64, 1, 2), (0, 127, 2, 2), (1, 70, 0, 1)):
+        assert p2[co, ((ci // 64) * 9 + ky * 3 + kx) * 64 + ci % 64] == w2[co, ci, ky, kx].half()
     wg, bg = pack_geglu(torch.arange(8.0).reshape(4, 2), torch.arange(4.0))
     assert wg[:, 0].tolist() == [0, 4, 2, 6] and bg.tolist() == [0, 2, 1, 3]       # (value_i, gate_i) interleaved
 

@@ -103,7 +103,7 @@ def test_gemm_and_conv_split_k(dev):
     rv = h(torch.randn(n, cout, generator=g))
     ref = F.conv2d(x, wc, bc, padding=1) + rv[:, :, None, None]
     xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
-    wp = wc.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().half().to(dev)
+    wp = _pack_conv(wc).to(dev)
     out = k.conv3x3(xt, wp, bc.half().to(dev), rowvec=rv.half().to(dev), rows_per_vec=hh * ww)
     close(out.permute(0, 3, 1, 2), ref, name="split-K conv")
 
@@ -133,7 +133,7 @@ def test_conv3x3_big_tiles(dev, n, hh, ww, cin, cout, stride, up):
     xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
     ref = F.conv2d(xi, w, b, stride=stride, padding=1)
     xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
-    wp = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().half().to(dev)
+    wp = _pack_conv(w).to(dev)
     out = k.conv3x3(xt, wp, b.half().to(dev), stride=stride, upsample=up)
     close(out.permute(0, 3, 1, 2), ref, name="big conv3x3")
 
@@ -226,12 +226,18 @@ def test_conv3x3(dev, n, hh, ww, cin, cout, stride, up):
     rv = h(torch.randn(n, cout, generator=g))
     res = h(torch.randn(n, cout, oh, ow, generator=g))
     xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
-    wp = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().half().to(dev)
+    wp = _pack_conv(w).to(dev)
     out = k.conv3x3(xt, wp, b.half().to(dev), stride=stride, upsample=up)
     close(out.permute(0, 3, 1, 2), ref, name="conv3x3")
     out = k.conv3x3(xt, wp, b.half().to(dev), stride=stride, upsample=up, rowvec=rv.half().to(dev),
                     rows_per_vec=oh * ow, residual=res.permute(0, 2, 3, 1).contiguous().half().to(dev))
     close(out.permute(0, 3, 1, 2), ref + rv[:, :, None, None] + res, name="conv3x3+temb+res")
+
+
+def _pack_conv(w):
+    """conv weights in the contraction order the kernel walks for this channel count (the product's packing function)"""
+    from i2v_adapter_unofficial_amd.blocks import pack_conv3x3
+    return pack_conv3x3(w)
 
 
 def _attn_ref(q, k_, v, heads, group):
