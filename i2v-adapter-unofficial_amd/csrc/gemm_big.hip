@@ -30,6 +30,9 @@ __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wa
                                            0);
 }
 
+// (Tried: an L2 prefetch of the A rows two / three K tiles ahead -- a 4-byte-per-lane LDS-DMA whose lanes touch one word
+// of 64 different cache lines -- left in flight across the barrier with vmcnt(1).  The GEMM class got 3 % SLOWER
+// (29.6 -> 30.5 ms per step): the cold-A projections are bound by HBM bandwidth, not by first-touch latency.)
 // m / d for 0 <= m < 2^24 (row indices): one multiply by the precomputed reciprocal and a +-1 fix-up instead of the
 // ~35-instruction integer division (the epilogue runs it once per 8-column task)
 __device__ __forceinline__ int fast_div(int m, int d, float inv_d) {
@@ -51,6 +54,9 @@ __device__ __forceinline__ float uniform_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
 
+#ifndef I2V_CONV_COLMAJOR
+#define I2V_CONV_COLMAJOR 1
+#endif
 #ifndef I2V_GEMM_PANEL
 #define I2V_GEMM_PANEL 8
 #endif
@@ -266,7 +272,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   // column tiles, each A tile shared by 8 CUs and each W tile by 4.
   const int tiles_m_all = ntiles / tiles_n;
   auto tile_coords = [&](int id, int& tm, int& tn) {
-    if (I2V_GEMM_PANEL > 0 && tiles_n > I2V_GEMM_PANEL && tiles_n % I2V_GEMM_PANEL == 0) {
+    if (I2V_CONV_COLMAJOR && AMODE == I2V_A_CONV3X3) {
+      // conv: a W tile (320 x 9 Cin) is ~18x the input footprint of an A tile, and with 2-4 column tiles it does not stay
+      // in L2: column-major ids give an XCD's 32 concurrent tiles ONE W tile (and 32 neighbouring pixel tiles).
+      // Same box: conv class 15.03 -> 14.89 ms per step.
+      tn = id / tiles_m_all;
+      tm = id - tn * tiles_m_all;
+    } else if (I2V_GEMM_PANEL > 0 && tiles_n > I2V_GEMM_PANEL && tiles_n % I2V_GEMM_PANEL == 0) {
       const int per_panel = tiles_m_all * I2V_GEMM_PANEL;
       const int panel = id / per_panel, r = id - panel * per_panel;
       tm = r / I2V_GEMM_PANEL;
