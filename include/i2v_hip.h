@@ -117,8 +117,8 @@ typedef struct i2v_gemm_params {
   int32_t n_img, in_h, in_w, cin, out_h, out_w, stride, upsample, asym_pad;
   /* order of the 9 * cin contraction index of I2V_A_CONV3X3 (and of w's columns): 0 = tap-major, k = tap * cin + ci;
      64 = channel-block-major, k = ((ci / 64) * 9 + tap) * 64 + ci % 64 (cin % 64 == 0): the 9 taps of one 64-channel
-     block are consecutive K tiles, so the 8 re-reads of an input pixel hit L2 instead of coming back from MALL / HBM
-     three K-panels later. */
+     block are consecutive K tiles, so the 8 re-reads of an input pixel follow each other closely (measured: conv class
+     12.40 -> 12.24 ms per step). */
   int32_t conv_kblock;
   /* Per-batch weights (GroupNorm folded into the proj_in GEMM of a transformer / motion-module entry, i2v:218-226, A9:
      the norm's per-image scale multiplies the weights, its shift becomes a per-image bias -- i2v_groupnorm_fold_f16):
