@@ -94,13 +94,17 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
 // FAST: plain A from one source with M % BM == 0 -- no ragged rows, no second source, so a K tile's DMA is a fixed list of
 // instructions with scalar offsets; these problems (every transformer GEMM of the step) run the persistent tile loop.
 // Everything else (conv, split-K, ragged M, channel-concatenated A) runs one tile per workgroup.
+// BNT: columns per tile, 320 (every channel count of the SD-1.5 UNet) or 256 / 128 (the VAE's 128 / 256 / 512 channels:
+// 4 N-waves x 64 or 32 columns); the LayerNorm fold and split-K exist for 320 only.
 template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true, bool LNF = false,
-          bool FAST = false>
+          bool FAST = false, int BNT = 320>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps,
                                                        const int ntiles) {
   static_assert(NS == 2, "the cross-tile prefetch of the persistent tile loop is written for two stages");
-  constexpr int BN = BIG_BN;
-  constexpr int WM = BM / 2, MI = WM / 16, NI = 5;
+  constexpr int BN = BNT;
+  constexpr int WNC = BN / 4;               // columns per N-wave: 80 / 64 / 32
+  constexpr int WM = BM / 2, MI = WM / 16, NI = WNC / 16;
+  static_assert(BN % 64 == 0 && (BN == 320 || (!LNF && !SPLIT)), "the LayerNorm fold and split-K are written for BN = 320");
   constexpr int AG = BM * BK / 4096;        // 1 KiB (8-unit) A groups per wave: BM * BK * 2 / 1024 groups over 8 waves
   constexpr int WGT = BN * BK * 2 / 1024;   // W groups per tile (40 or 20)
   constexpr int WG = (WGT + 7) / 8;         // per wave; for BK = 32 the third one exists for waves 0-3 only
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   // the nine registers the accumulator-bound LayerNorm kernels spilled to scratch INSIDE the K loop (a scratch reload
   // there waits on vmcnt, i.e. on the DMA it should overlap).
   const int fa_lane = big_lds_addr<BK>(wm * WM + l15, g);
-  const int fw_lane = BM * BK * 2 + big_lds_addr<BK>(wn * 80 + l15, g);
+  const int fw_lane = BM * BK * 2 + big_lds_addr<BK>(wn * WNC + l15, g);
   auto read_frags = [&](int cur, int ks, f16x8 (&wf)[NI], f16x8 (&af)[MI]) {
     if constexpr (BK == 64) {
       int so = cur * STAGE;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       const char* sw = sa + BM * BK * 2;
 #pragma unroll
       for (int i = 0; i < NI; ++i)
-        wf[i] = *reinterpret_cast<const f16x8*>(sw + big_lds_addr<BK>(wn * 80 + i * 16 + l15, ks * 4 + g));
+        wf[i] = *reinterpret_cast<const f16x8*>(sw + big_lds_addr<BK>(wn * WNC + i * 16 + l15, ks * 4 + g));
 #pragma unroll
       for (int j = 0; j < MI; ++j)
         af[j] = *reinterpret_cast<const f16x8*>(sa + big_lds_addr<BK>(wm * WM + j * 16 + l15, ks * 4 + g));
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       if (m < M) {
         static_for<NI>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          *reinterpret_cast<f32x4*>(ws + (int64_t)m * N + n0 + wn * 80 + i * 16 + g * 4) = acc[i][j];
+          *reinterpret_cast<f32x4*>(ws + (int64_t)m * N + n0 + wn * WNC + i * 16 + g * 4) = acc[i][j];
         });
       }
     });
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         }
         static_for<NI>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          const float ws = lds_ws[wn * 80 + i * 16 + l15];
+          const float ws = lds_ws[wn * WNC + i * 16 + l15];
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[i][j][r] = rs[r] * (acc[i][j][r] - mu[r] * ws);
         });
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       for (int q = 0; q < NT / 64; ++q) {
         const int t = lane + 64 * q;
         const int row = t / TPR, c = t - row * TPR;
-        const int n = n0 + wn * 80 + i * 16 + row;
+        const int n = n0 + wn * WNC + i * 16 + row;
         const int m = m0 + wm * WM + c * 8;
         if (m < M) {   // M % 8 == 0 and vt_len % 8 == 0: the 8 keys are in range and in one batch
           const float bn = bias ? (float)bias[n] : 0.f;
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   if (STORE == I2V_STORE_VT_T) {
     static_for<NI>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const int n = n0 + wn * 80 + i * 16 + l15;
+      const int n = n0 + wn * WNC + i * 16 + l15;
       const float bn = bias ? (float)bias[n] : 0.f;
       static_for<MI>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     });
     return;
   }
-  const int ncol0 = n0 + wn * 80 + g * 4;
+  const int ncol0 = n0 + wn * WNC + g * 4;
   f16x4 b4[NI];
   static_for<NI>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -617,10 +621,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
     // barrier beyond the one that retires the K loop's stages; LDS executes one wave's operations in order) and
     // re-reads it so that a lane owns 8 consecutive columns of one row: 16-byte residual / time-embedding loads and
     // stores, 160 contiguous bytes per row, half the instructions.  Rounding is unchanged (fp32 until the final cast).
-    constexpr int OC = EPI == I2V_EPI_GEGLU ? 40 : 80;   // output columns per wave
+    constexpr int OC = EPI == I2V_EPI_GEGLU ? WNC / 2 : WNC;   // output columns per wave
     constexpr int LDS_LD = OC + 4;                        // floats; 84 / 44: 16 rows start on 16 distinct bank groups
     constexpr int TPR = OC / 8, NT = 16 * TPR;            // 8-column tasks per row / per 16-row block
-    const int out_col0 = EPI == I2V_EPI_GEGLU ? (n0 >> 1) + wn * 40 : n0 + wn * 80;
+    const int out_col0 = EPI == I2V_EPI_GEGLU ? (n0 >> 1) + wn * (WNC / 2) : n0 + wn * WNC;
     // One 8-column task of the 16-row block j: (valid, row m, destination row, first column)
     constexpr int QN = (NT + 63) / 64;
     auto task = [&](int j, int q, int& row, int& c, int& m, int64_t& m_out, int& n) {
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
       f32x4 ws4[NI];
       static_for<NI>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        ws4[i] = *reinterpret_cast<const f32x4*>(lds_ws + wn * 80 + g * 4 + i * 16);
+        ws4[i] = *reinterpret_cast<const f32x4*>(lds_ws + wn * WNC + g * 4 + i * 16);
       });
       static_for<MI>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -858,6 +862,17 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   return rc < 0 ? rc : 1;
 }
 
+// 3x3 convolutions whose channel count is not a multiple of 320 (the VAE: 128 / 256 / 512): column tiles of 256 or 128
+template <int BM, int BN>
+int launch_big_conv_bn(const i2v_gemm_params& p, hipStream_t s) {
+  const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BN;
+  const int ntiles = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm_big_kernel<BM, 64, 2, I2V_A_CONV3X3, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false, true, false, false, BN>),
+                     dim3(ntiles), dim3(512), 0, s, p, tiles_n, 0, ntiles);
+  const int rc = i2v_check_launch("i2v_gemm_f16(big conv)");
+  return rc < 0 ? rc : 1;
+}
+
 // Pipeline shape: two 64-deep stages.  Four 32-deep stages (three tiles in flight, <BM, 32, 4, ...>) measured 5-12 %
 // slower on every shape of the step (profiles/r1_tile_sweep.txt): the loop is not bound by DMA latency.
 template <int BM>
@@ -928,11 +943,23 @@ int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4) {
 }
 
 namespace {
+// columns per tile for this problem: 320 (UNet), or for 3x3 convolutions 256 / 128 (VAE channel counts); 0 = none
+int big_bn(const i2v_gemm_params& p) {
+  if (p.N % BIG_BN == 0) return BIG_BN;
+  static const int vae = getenv("I2V_GEMM_BIG_VAE") ? atoi(getenv("I2V_GEMM_BIG_VAE")) : 1;
+  if (vae && p.a_mode == I2V_A_CONV3X3 && p.epilogue == I2V_EPI_NONE && p.store_mode == I2V_STORE_ROWMAJOR) {
+    if (p.N % 256 == 0) return 256;
+    if (p.N % 128 == 0) return 128;
+  }
+  return 0;
+}
+
 // dispatch decision for one problem: 0 = not for this kernel, 256 / 128 = tile height, -1 = split-K (*splits, *kps set)
 int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) {
   static const int mode = getenv("I2V_GEMM_BIG") ? atoi(getenv("I2V_GEMM_BIG")) : -1;  // 0 off, 256 / 128 force
   if (mode == 0) return 0;
-  if (p.N % BIG_BN != 0) return 0;
+  const int bn = big_bn(p);
+  if (bn == 0) return 0;
   // the kernel addresses each operand through a buffer descriptor with 32-bit byte offsets (< 2 GiB per operand) and
   // moves whole BK-deep K tiles (K, the concat split and the conv channel count must be multiples of 64)
   if (p.K % 64 != 0 || (p.a2 != nullptr && p.k_split % 64 != 0)) return 0;
@@ -968,7 +995,7 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
         return 0;
     }
   }
-  const int64_t tn = p.N / BIG_BN;
+  const int64_t tn = p.N / bn;
   const int64_t t256 = i2v_cdiv(p.M, 256) * tn, t128 = i2v_cdiv(p.M, 128) * tn;
   if (mode == 256 || mode == 128) return mode;
   static const int min_k = getenv("I2V_GEMM_BIG_MINK") ? atoi(getenv("I2V_GEMM_BIG_MINK")) : 128;
@@ -980,6 +1007,7 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
   const double e128 = 0.82 * (double)t128 / (double)(i2v_cdiv(t128, 256) * 256);
   if (e256 >= e128 && e256 >= 0.40) return 256;
   if (e128 >= 0.40) return 128;
+  if (bn != BIG_BN) return 0;   // (split-K exists for 320-column tiles only)
   // too few output tiles for the chip: split K when the caller supplied the fp32 scratch
   int kps = 0;
   const int splits = splitk_plan(p, vec4, &kps);
@@ -1019,6 +1047,11 @@ int i2v_gemm_big_unsplit_ok(const i2v_gemm_params& p, int vec4) {
 int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   int splits = 0, kps = 0;
   const int plan = big_plan(p, vec4, &splits, &kps);
+  const int bn = big_bn(p);
+  if (bn == 256 && plan == 256) return launch_big_conv_bn<256, 256>(p, s);
+  if (bn == 256 && plan == 128) return launch_big_conv_bn<128, 256>(p, s);
+  if (bn == 128 && plan == 256) return launch_big_conv_bn<256, 128>(p, s);
+  if (bn == 128 && plan == 128) return launch_big_conv_bn<128, 128>(p, s);
   if (plan == 256) return launch_big<256>(p, vec4, s);
   if (plan == 128) return launch_big<128>(p, vec4, s);
   if (plan == -1) return launch_split(p, vec4, splits, kps, s);

@@ -123,7 +123,11 @@ def test_gemm_store_vt_t(dev, batches, L, C, Kd):
 
 
 @pytest.mark.parametrize("n,hh,ww,cin,cout,stride,up", [(12, 64, 64, 32, 320, 1, False), (12, 32, 32, 64, 320, 1, True),
-                                                         (16, 64, 64, 16, 640, 2, False), (4, 64, 64, 8, 320, 1, False)])
+                                                         (16, 64, 64, 16, 640, 2, False), (4, 64, 64, 8, 320, 1, False),
+                                                         # the VAE's channel counts: 256- and 128-column tiles of the 8-wave kernel
+                                                         (4, 64, 64, 128, 256, 1, False), (4, 32, 32, 128, 128, 1, True),
+                                                         (4, 64, 64, 256, 512, 1, False), (8, 64, 64, 64, 128, 2, False),
+                                                         (3, 50, 40, 128, 384, 1, False)])
 def test_conv3x3_big_tiles(dev, n, hh, ww, cin, cout, stride, up):
     k = K()
     g = torch.Generator().manual_seed(cin + cout)
