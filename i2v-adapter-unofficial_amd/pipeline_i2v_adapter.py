@@ -72,7 +72,7 @@ class I2VAdapterPipeline:
         self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
         self._vae_slicing = False
         self._graph = None
-        self._graph_key = None
+        self._graph_cache = {}
 
     def enable_vae_slicing(self):
         """pipe:122-128: decode the frames one at a time (peak activation memory / num_frames)."""
@@ -160,25 +160,54 @@ class I2VAdapterPipeline:
                              st["num_frames"])                                          # pipe:676-683
         K.ddim_cfg_step(st["latents"], y, st["coef"], st["step_idx"], st["guidance"], st["copies"])  # pipe:686-691
 
+    def _graph_key(self, st):
+        """everything a captured step has baked in besides the contents of the static buffers: shapes, the Python
+        scalars passed as launch arguments (guidance, IP scales) and the identity / version of every weight (the packed
+        kernel-layout copies are rebuilt when a parameter changes, and a graph captured before that reads the old ones)"""
+        unet = self.unet
+        wsig = hash(tuple((p.data_ptr(), p._version) for p in unet.parameters()))
+        ips = tuple((a.ip_num_tokens, float(a.ip_scale)) for a in unet._cross_attention_layers())
+        shp = lambda t: None if t is None else (tuple(t.shape), t.dtype)
+        return (tuple(st["latents"].shape), st["copies"], st["num_frames"], st["guidance"], shp(st["t_table"]),
+                shp(st["ctx_text"]), shp(st["ctx_ip"]), str(st["latents"].device), wsig, ips)
+
     def _run_steps(self, st, n_steps, use_graph):
         if not use_graph:
             for _ in range(n_steps):
                 self._step(st)
-            return
-        # warm-up outside capture: packs weights, sizes the allocator; then restore the state it advanced
-        saved = st["latents"].clone()
-        self._step(st)
-        st["latents"].copy_(saved)
-        st["step_idx"].zero_()
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+            return st["latents"]
+        # The captured step is kept across calls: a second sample of the same shape (the evaluation driver's loop) copies
+        # its inputs into the graph's static buffers and replays -- no eager warm-up step, no re-capture (~0.3 s of a
+        # 1.8 s sample at 16 f x 512 x 512).
+        key = self._graph_key(st)
+        cache = self._graph_cache
+        hit = cache.get(key)
+        if hit is not None:
+            graph, gst = hit
+            for name in ("latents", "cond", "t_table", "coef", "ctx_text", "ctx_ip"):
+                if st[name] is not None:
+                    gst[name].copy_(st[name])
+            gst["step_idx"].zero_()
+            self.unet.project_context(gst["ctx_text"], gst["ctx_ip"], out=gst["ctx_proj"])
+        else:
+            # warm-up outside capture: packs weights, sizes the allocator; then restore the state it advanced
+            saved = st["latents"].clone()
             self._step(st)
-        st["latents"].copy_(saved)      # capture does not execute, but keep the invariant explicit
-        st["step_idx"].zero_()
+            st["latents"].copy_(saved)
+            st["step_idx"].zero_()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._step(st)
+            st["latents"].copy_(saved)      # capture does not execute, but keep the invariant explicit
+            st["step_idx"].zero_()
+            gst = dict(st)                  # its own dict: the caller goes on to rebind entries of `st`
+            cache.clear()                   # one shape at a time: a graph pins its workspace
+            cache[key] = (graph, gst)
         self._graph = graph
         for _ in range(n_steps):
             graph.replay()
+        return gst["latents"].clone()     # the static buffer stays with the graph; the caller gets its own tensor
 
     # ------------------------------------------------------------------------------------------ __call__
     @torch.no_grad()
@@ -272,7 +301,7 @@ class I2VAdapterPipeline:
         # K / V^T of the prompt (+ image) context for all 16 cross-attention layers: once per sample, not once per step
         st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
         if callback is None:
-            self._run_steps(st, len(timesteps), use_graph)
+            st["latents"] = self._run_steps(st, len(timesteps), use_graph)
         else:
             for i, t in enumerate(timesteps):                                                   # pipe:666-697
                 self._step(st)

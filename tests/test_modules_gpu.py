@@ -255,3 +255,21 @@ def test_pipeline_trajectory(dev, use_graph):
     again = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, condition_image_latents=cond, use_graph=use_graph,
                  **kw, **gens()).frames
     assert torch.equal(got, again), "same seeds must reproduce the trajectory bit for bit"
+    assert again.data_ptr() != got.data_ptr()
+    if use_graph:
+        # the captured step is reused by later calls of the same shape: a DIFFERENT sample through the cached graph must
+        # equal that sample through a fresh pipeline (inputs really are copied into the graph's static buffers), and the
+        # first call's result must not have been overwritten
+        g2 = torch.Generator().manual_seed(77)
+        pe2, ne2 = h(torch.randn(1, 7, 64, generator=g2)), h(torch.randn(1, 7, 64, generator=g2))
+        cond2 = torch.randn(1, 4, 16, 16, generator=g2)
+        gens2 = lambda: dict(generator=torch.Generator().manual_seed(15), prior_mask_generator=torch.Generator().manual_seed(16),
+                             prior_noise_generator=torch.Generator().manual_seed(17))
+        keep = got.clone()
+        assert len(pipe._graph_cache) == 1
+        other = pipe(prompt_embeds=pe2, negative_prompt_embeds=ne2, condition_image_latents=cond2, use_graph=True,
+                     **kw, **gens2()).frames
+        assert len(pipe._graph_cache) == 1 and torch.equal(got, keep)
+        fresh = pkg().I2VAdapterPipeline(unet=hu)(prompt_embeds=pe2, negative_prompt_embeds=ne2,
+                                                  condition_image_latents=cond2, use_graph=True, **kw, **gens2()).frames
+        assert torch.equal(other, fresh) and not torch.equal(other, got)
