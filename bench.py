@@ -6,7 +6,9 @@
   python bench.py --pairs 64 [--batch B]                    configs[3]: 64 (image, prompt) pairs sharded over the ranks,
                                                             B samples per graph replay, K steps per pair
   python bench.py --frames 32 --size 768                    configs[4]: 32 f x 768 x 768
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+  --gpus N ...` (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE from the environment), or plain `python bench.py --gpus N`,
+  which starts that launcher as a child process before anything touches the GPU and relays rank 0's JSON line.
 
 One *step* = one iteration of the reference loop pipe:666-697 for one (image, prompt) sample: frame-0 overwrite,
 CFG duplicate (B = 2), UNet forward, CFG combine, DDIM update -- replayed as one hipGraph.  Inputs are synthetic
@@ -37,6 +39,9 @@ FLOPS_PER_STEP = {(16, 512, False): 40.199e12, (16, 512, True): 40.205e12, (8, 2
                   (32, 768, False): 225.074e12}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
+# max-abs error of the HIP CFG forward against the fp32 CPU oracle above which the run is a FAILURE (exit code 3):
+# tests/test_full_width_gpu.py FWD_ABS_TOL
+PARITY_ABS_TOL = 4.0e-3
 
 SD15 = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
             layers_per_block=2, cross_attention_dim=768, num_attention_heads=8, norm_num_groups=32,
@@ -82,9 +87,10 @@ def sample_inputs(index, frames, h_lat, ip):
     return d
 
 
-def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev):
-    """ONE CFG UNet forward (B = 2) of this workload through the CPU oracle on the host cores, with the HIP model's
-    weights; timed, and compared with the HIP forward of the same inputs."""
+def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev, n_forwards=3):
+    """`n_forwards` CFG UNet forwards (B = 2) of this workload through the CPU oracle on the host cores, with the HIP
+    model's weights; the MEDIAN time is the baseline, and the forward is compared with the HIP forward of the
+    same inputs."""
     from oracle import blocks as oblocks
     from oracle.unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel as OracleUNet
     import torch.nn.functional as F
@@ -113,17 +119,21 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev):
     torch.set_num_threads(cores)
     try:
         with torch.no_grad():
-            t0 = time.time()
-            ref = ou(x, t, True, ctx, added_cond_kwargs=added).sample
-            dt = time.time() - t0
+            times = []
+            for _ in range(max(1, n_forwards)):
+                t0 = time.time()
+                ref = ou(x, t, True, ctx, added_cond_kwargs=added).sample
+                times.append(time.time() - t0)
+            dt = sorted(times)[len(times) // 2]
             got = model(x.to(dev), t.to(dev), True, ctx.to(dev), added_cond_kwargs=added_d).sample.float().cpu()
     finally:
         oblocks.Attention._sdpa = orig
     err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
     base = {"value": 1.0 / dt, "unit": "denoising steps/sec", "cores": cores, "kind": "port",
-            "sample": (f"one fp32 CFG UNet forward (B = 2) of the CPU oracle at {frames}f x {h_lat * 8}x{h_lat * 8} took "
-                       f"{dt:.1f} s on {cores} threads of a {os.cpu_count()}-thread host (torch {torch.__version__}); a "
-                       "step is that forward plus negligible elementwise work")}
+            "sample": (f"median of {len(times)} fp32 CFG UNet forwards (B = 2) of the CPU oracle at {frames}f x "
+                       f"{h_lat * 8}x{h_lat * 8}: {dt:.1f} s ({', '.join(f'{v:.1f}' for v in times)}) on {cores} threads of a "
+                       f"{os.cpu_count()}-thread host (torch {torch.__version__}); a step is that forward plus "
+                       "negligible elementwise work")}
     parity = {"max_abs_err": err, "max_abs_ref": scale, "rel": err / max(scale, 1e-30),
               "what": "HIP UNet forward vs the fp32 CPU oracle forward timed above (same weights, same inputs)"}
     return base, parity
@@ -142,6 +152,118 @@ def write_shape_table(prof, path, what):
                     f"{1e3 * d['ms'] / d['calls']:10.1f} {d['tflops']:8.1f} {d['gbps']:7.0f}\n")
 
 
+def plan_groups(n_pairs_total, rank, world, batch):
+    """this rank's (image, prompt) pair indices, `batch` per graph replay: static block partition of the pairs over the
+    ranks (sharding.shard_range), no per-step collective."""
+    from i2v_adapter_unofficial_amd.sharding import shard_range
+    if n_pairs_total % (world * batch) != 0:
+        raise SystemExit(f"--pairs {n_pairs_total} must be a multiple of ranks x batch = {world * batch}")
+    lo, hi = shard_range(n_pairs_total, rank, world)
+    idx = list(range(lo, hi))
+    return [idx[i: i + batch] for i in range(0, len(idx), batch)]
+
+
+def run_windows(groups, steps, n_windows, n_tab, load_group, run_step, reset_step_index, sync, world, device):
+    """The timed region, `n_windows` times: exactly `steps` steps for every group of this rank between barrier + sync on
+    both sides, elapsed = MAX over ranks (an all-reduce of one double OUTSIDE the timed bracket).  Returns the list of
+    window times (identical on every rank)."""
+    import torch.distributed as dist
+    windows = []
+    for _ in range(max(1, n_windows)):
+        load_group(groups[0])
+        sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for gi, grp in enumerate(groups):
+            if gi:
+                load_group(grp)
+            for done in range(steps):
+                if done % n_tab == 0 and done:
+                    reset_step_index()      # wrap the timestep table (the kernels also clamp the index)
+                run_step()
+        sync()
+        if world > 1:
+            dist.barrier()
+        w_elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([w_elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            w_elapsed = float(tt.item())
+        windows.append(w_elapsed)
+    return windows
+
+
+def dry_run(args, rank, world):
+    """the N-rank plumbing of main() on CPU (gloo): everything but the kernels and RCCL."""
+    import torch.distributed as dist
+    from i2v_adapter_unofficial_amd.i2v_adapter import I2VAdapterModule
+    from i2v_adapter_unofficial_amd.sharding import broadcast_model_weights
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1234 + rank)                        # different weights per rank until the broadcast
+    model = I2VAdapterModule(2, (32, 64, 64), 4)
+    nbytes = broadcast_model_weights(model, src=0) if world > 1 else 0
+    checksum = float(sum(p.detach().double().sum() for p in model.parameters()))
+    B = args.batch
+    n_pairs_total = args.pairs if args.pairs > 0 else world * B
+    groups = plan_groups(n_pairs_total, rank, world, B)
+    done = {}
+
+    def run_step():
+        for i in current["grp"]:
+            done[i] = done.get(i, 0) + 1
+    current = {"grp": None}
+    windows = run_windows(groups, args.steps, 1, 25, lambda grp: current.update(grp=grp), run_step, lambda: None,
+                          lambda: None, world, torch.device("cpu"))
+    if world > 1:
+        sums = [None] * world
+        dist.all_gather_object(sums, (checksum, sorted(done.items())))
+    else:
+        sums = [(checksum, sorted(done.items()))]
+    if rank == 0:
+        covered = sorted(i for _, d in sums for i, _ in d)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "pairs": n_pairs_total, "batch": B,
+                          "ranks_in_group": dist.get_world_size() if world > 1 else 1, "broadcast_bytes": nbytes,
+                          "weights_equal_on_all_ranks": len({c for c, _ in sums}) == 1,
+                          "pairs_covered_once": covered == list(range(n_pairs_total)),
+                          "steps_per_pair": sorted({n for _, d in sums for _, n in d}),
+                          "window_s": windows[0]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py
+    ...` as a CHILD process (this process has not touched the GPU and never execs), relay its output -- rank 0's JSON line
+    on stdout -- and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def source_stamp():
+    """hash of the kernel sources the running library was built from (csrc/*.hip, *.h, include/i2v_hip.h): recorded next
+    to PMC traffic figures so that a figure measured on another binary is never attached to this one"""
+    import hashlib
+    csrc = os.path.join(ROOT, "i2v-adapter-unofficial_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(ROOT, "include", "i2v_hip.h"))
+    hsh = hashlib.sha256()
+    for f in files:
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,13 +277,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default="", help="write the per-shape time table of the instrumented step here")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--windows", type=int, default=5,
+                    help="the K-step timed window is repeated this many times (each bracketed by barrier + synchronize); "
+                         "the line reports the MEDIAN window, and min / max as `window_ms_per_step`")
+    ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (median)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the multi-rank plumbing on a box WITHOUT GPUs: launcher, rendezvous, gloo group, flat "
+                         "weight broadcast, pair sharding, timed loop with a stub step, MAX all-reduce, JSON line "
+                         "(marked \"dry_run\": true; not a measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))       # bare `python bench.py --gpus N`: one child launcher, N ranks
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} (or plain `python bench.py --gpus N`)")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -171,7 +306,7 @@ def main():
 
     import i2v_adapter_unofficial_amd as pkg
     from i2v_adapter_unofficial_amd.profiling import KernelProfile
-    from i2v_adapter_unofficial_amd.sharding import broadcast_model_weights, shard_range
+    from i2v_adapter_unofficial_amd.sharding import broadcast_model_weights
 
     # ---- weights: rank 0 draws them on its GPU, one flat RCCL broadcast to the other ranks
     t_start = time.time()
@@ -190,11 +325,7 @@ def main():
     # ---- this rank's samples (static block partition, no per-step collective)
     F, h_lat, B = args.frames, args.size // 8, args.batch
     n_pairs_total = args.pairs if args.pairs > 0 else world * B
-    if n_pairs_total % (world * B) != 0:
-        raise SystemExit(f"--pairs {n_pairs_total} must be a multiple of ranks x batch = {world * B}")
-    lo, hi = shard_range(n_pairs_total, rank, world)
-    mine = [sample_inputs(i, F, h_lat, ip) for i in range(lo, hi)]
-    groups = [mine[i: i + B] for i in range(0, len(mine), B)]
+    groups = [[sample_inputs(i, F, h_lat, ip) for i in grp] for grp in plan_groups(n_pairs_total, rank, world, B)]
 
     pipe = pkg.I2VAdapterPipeline(unet=model)
     sch = pipe.scheduler
@@ -242,29 +373,13 @@ def main():
             if i % n_tab == 0 and i:
                 st["step_idx"].zero_()
             run_step()
-        # ---- timed region: exactly K steps per group between barrier + synchronize on both sides
-        load_group(groups[0])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for gi, grp in enumerate(groups):
-            if gi:
-                load_group(grp)
-            for done in range(args.steps):
-                if done % n_tab == 0 and done:
-                    st["step_idx"].zero_()  # wrap the 25-entry timestep table (the kernels also clamp the index)
-                run_step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+        # ---- timed region: exactly K steps per group between barrier + synchronize on both sides.  The window is
+        #      repeated (a 20-step window is ~1 s of GPU time: box noise is +-5 %, and the driver's utilisation sampler
+        #      cannot see it); every window is timed the same way, MAX over ranks, and the MEDIAN window is reported.
+        windows = run_windows(groups, args.steps, args.windows, n_tab, load_group, run_step,
+                              lambda: st["step_idx"].zero_(), torch.cuda.synchronize, world, dev)
+        elapsed = sorted(windows)[len(windows) // 2]
         finite = bool(torch.isfinite(st["latents"]).all().item())
-
-        if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
 
         # ---- live per-kernel-class roofline (rank 0): one instrumented eager step behind a GPU backlog so that
         #      the event pairs bracket back-to-back kernels, not host launch gaps
@@ -291,21 +406,39 @@ def main():
             # HBM-side bytes per launch of that class: PMC counters cannot be read from inside the process, so this is
             # the committed result of the separate rocprofv3 --pmc passes over this same command
             # (tools/pmc_traffic.sh -> profiles/r2_traffic.json), valid for the default workload only
-            tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
             if os.path.exists(tpath) and (F, args.size, ip, B) == (16, 512, False, 1):
                 with open(tpath) as f:
-                    tcls = json.load(f).get("classes", {})
-                if dom in tcls:
+                    tj = json.load(f)
+                tcls = tj.get("classes", {})
+                if tj.get("source_stamp") != source_stamp():
+                    roof["traffic_source"] = (f"profiles/r3_traffic.json was measured on kernel sources "
+                                              f"{tj.get('source_stamp')}, this library is {source_stamp()}: not attached")
+                elif dom in tcls:
                     roof["traffic"] = tcls[dom]["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    roof["traffic_source"] = ("profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                              "over this command, same kernel sources)")
+            # fractions of the ceilings MEASURED on this chip (tools/ceilings.hip -> profiles/r3_ceilings.json), next to
+            # the vendor peaks the `frac` above uses
+            cpath = os.path.join(ROOT, "profiles", "r3_ceilings.json")
+            if os.path.exists(cpath):
+                with open(cpath) as f:
+                    cj = json.load(f)
+                pm = cj.get("mfma_f16_tflops") if roof["bound"] == "mfma" else cj.get("hbm_copy_gbps")
+                if pm:
+                    roof["peak_measured"] = pm
+                    roof["frac_of_measured"] = roof["achieved"] / pm
+                    roof["peak_measured_source"] = "profiles/r3_ceilings.json (MFMA-saturating loop / stream copy, this pool)"
 
     used_graph = graph is not None
     graph = None
     t_gpu_done = time.time()
     cpu_base, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_base, parity = cpu_baseline_and_parity(model, ip_sd, F, h_lat, dev)
-        if not (parity["max_abs_err"] <= 6e-3):         # tests/test_full_width_gpu.py FWD_ABS_TOL
+        cpu_base, parity = cpu_baseline_and_parity(model, ip_sd, F, h_lat, dev, n_forwards=args.cpu_forwards)
+        parity["tolerance"] = PARITY_ABS_TOL
+        parity["parity_ok"] = bool(parity["max_abs_err"] <= PARITY_ABS_TOL)
+        if not parity["parity_ok"]:
             print(f"# PARITY FAILURE: {parity}", file=sys.stderr)
     if rank == 0:
         print(f"# timings: build {t_built - t_start:.1f}s, gpu {t_gpu_done - t_built:.1f}s, cpu baseline "
@@ -325,7 +458,11 @@ def main():
             "metric": ("denoising steps/sec @ 16fx512x512 SD1.5+I2V-Adapter" if (F, args.size) == (16, 512) else
                        f"denoising steps/sec @ {F}fx{args.size}x{args.size} SD1.5+I2V-Adapter"), "value": value,
             "unit": "denoising steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if not args.pairs else "strong",
+            "ms_per_step": ms, "window_ms_per_step": {"n": len(windows), "median": ms,
+                                                      "min": min(windows) / (len(groups) * args.steps) * 1e3,
+                                                      "max": max(windows) / (len(groups) * args.steps) * 1e3},
+            "higher_is_better": True, "scaling": "weak" if not args.pairs else "strong",
+            "ranks_in_rccl_group": (dist.get_world_size() if world > 1 else 1),
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SD-v1.5 + motion-adapter-v1-5-2 + I2V-Adapter topology, {F}f x {args.size}x{args.size}, "
                                    f"CFG 7.5 (B=2 per sample), DDIM 25-step table, fp16, IP {'on' if ip else 'off'}, "
@@ -341,9 +478,11 @@ def main():
             "kernel_classes": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                                for k, v in (classes or {}).items()},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if parity is not None and not parity["parity_ok"]:
+        raise SystemExit(3)          # a numerically broken build must not look like a benchmark record (rc != 0)
 
 
 if __name__ == "__main__":

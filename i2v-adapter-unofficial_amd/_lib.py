@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # I2V_LIB_PATH selects another build of the same ABI (same-box A/B of two kernels, tools/ab_bench.sh); the in-tree
 # library is never overwritten by tooling
 LIB_PATH = os.environ.get("I2V_LIB_PATH") or os.path.join(_HERE, "libi2v_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
 I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
@@ -43,6 +43,7 @@ class GemmParams(C.Structure):
         ("w_batch_stride", C.c_int64), ("rows_per_w", C.c_int32),
         ("a_perm_frames", C.c_int32), ("a_perm_hw", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("c_is_f32", C.c_int32),
     ]
 
 
@@ -110,7 +111,7 @@ SIGNATURES = {
     "i2v_layernorm_f16": (C.c_int, [C.POINTER(LnParams), _P]),
     "i2v_softmax_rows_f16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "i2v_nchw_to_tokens": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
-    "i2v_tokens_to_nchw": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_tokens_to_nchw": (C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_timestep_embedding": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     "i2v_silu_f16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "i2v_repeat_rows_f16": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int32, _P]),
@@ -120,8 +121,8 @@ SIGNATURES = {
     "i2v_gaussian_sample_f32": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_first_frame_prior_f32": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
-    "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_int32, _P]),
+    "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, _P]),
 }
 
 _lib = None

@@ -95,6 +95,7 @@ class PretrainedMixin:
         else:
             raise EnvironmentError(f"Error no file named {_add_variant(SAFETENSORS_WEIGHTS_NAME, variant)} or "
                                    f"{_add_variant(WEIGHTS_NAME, variant)} found in directory {path}.")
+        state = convert_deprecated_attention_keys(state, model.state_dict())
         missing, unexpected = model.load_state_dict(state, strict=False)
         # recomputable buffers (the sinusoidal table) may be absent from third-party files; anything else is an error
         missing = [k for k in missing if not k.endswith("pos_embed.pe")]
@@ -104,6 +105,29 @@ class PretrainedMixin:
         if torch_dtype is not None:
             model = model.to(torch_dtype)
         return model.eval()
+
+
+_DEPRECATED_ATTENTION_NAMES = ((".query.", ".to_q."), (".key.", ".to_k."), (".value.", ".to_v."),
+                               (".proj_attn.", ".to_out.0."))
+
+
+def convert_deprecated_attention_keys(state: dict, target: dict) -> dict:
+    """diffusers converts the attention names of old checkpoints on load (`_convert_deprecated_attention_blocks`, reached
+    from `AutoencoderKL.from_pretrained`, pipe:754): many SD-1.5 `vae/` folders (runwayml/stable-diffusion-v1-5,
+    sd-vae-ft-mse) still store `mid_block.attentions.0.{query,key,value,proj_attn}`, which the current module tree calls
+    `{to_q,to_k,to_v,to_out.0}`.  Keys the target already knows are left alone; a 1x1-conv weight [C, C, 1, 1] is
+    squeezed where the target parameter is a matrix."""
+    out = {}
+    for k, v in state.items():
+        nk = k
+        if k not in target and ".attentions." in k:
+            for old, new in _DEPRECATED_ATTENTION_NAMES:
+                if old in nk:
+                    nk = nk.replace(old, new)
+        if nk in target and v.dim() == 4 and target[nk].dim() == 2 and v.shape[2:] == (1, 1):
+            v = v[:, :, 0, 0]
+        out[nk] = v
+    return out
 
 
 def load_ip_adapter_file(pretrained_model_name_or_path_or_dict, subfolder: Optional[str] = None,

@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const void* __restr
   }
 }
 
-template <bool DST_F32>
-__global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const f16* __restrict__ src, int64_t ld, void* __restrict__ dst,
+template <bool SRC_F32, bool DST_F32>
+__global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const void* __restrict__ src, int64_t ld, void* __restrict__ dst,
                                                              int n, int c, int hw) {
   const int64_t total = (int64_t)n * c * hw;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -38,11 +38,12 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const f16* __restri
     const int64_t t = i / hw;
     const int ch = (int)(t % c);
     const int64_t img = t / c;
-    const f16 v = src[(img * hw + p) * ld + ch];
+    const int64_t si = (img * hw + p) * ld + ch;
+    const float v = SRC_F32 ? reinterpret_cast<const float*>(src)[si] : (float)reinterpret_cast<const f16*>(src)[si];
     if (DST_F32)
-      reinterpret_cast<float*>(dst)[i] = (float)v;
+      reinterpret_cast<float*>(dst)[i] = v;
     else
-      reinterpret_cast<f16*>(dst)[i] = v;
+      reinterpret_cast<f16*>(dst)[i] = (f16)v;
   }
 }
 
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void ddim_prep_kernel(float* __restrict__ late
   }
 }
 
-__global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ latents, const f16* __restrict__ np, int64_t ld_np,
+template <typename NP>
+__global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ latents, const NP* __restrict__ np, int64_t ld_np,
                                                         const float* __restrict__ coef, int n_steps,
                                                         const int32_t* __restrict__ step_index, float guidance, int b,
                                                         int f, int c, int hw, int copies) {
@@ -214,17 +216,20 @@ extern "C" int i2v_nchw_to_tokens(const void* src, int32_t src_is_f32, void* dst
   return i2v_check_launch("i2v_nchw_to_tokens");
 }
 
-extern "C" int i2v_tokens_to_nchw(const void* src, int64_t ld, void* dst, int32_t dst_is_f32, int32_t n, int32_t c,
-                                  int32_t hw, i2v_stream_t stream) {
+extern "C" int i2v_tokens_to_nchw(const void* src, int32_t src_is_f32, int64_t ld, void* dst, int32_t dst_is_f32, int32_t n,
+                                  int32_t c, int32_t hw, i2v_stream_t stream) {
   I2V_CHECK_ARG(src && dst && n > 0 && c > 0 && hw > 0 && ld >= c, "i2v_tokens_to_nchw: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t total = (int64_t)n * hw * c;
-  if (dst_is_f32)
-    hipLaunchKernelGGL(tokens_to_nchw_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, s,
-                       reinterpret_cast<const f16*>(src), ld, dst, n, c, hw);
+  const dim3 grid(ew_blocks(total)), block(256);
+  if (src_is_f32 && dst_is_f32)
+    hipLaunchKernelGGL((tokens_to_nchw_kernel<true, true>), grid, block, 0, s, src, ld, dst, n, c, hw);
+  else if (src_is_f32)
+    hipLaunchKernelGGL((tokens_to_nchw_kernel<true, false>), grid, block, 0, s, src, ld, dst, n, c, hw);
+  else if (dst_is_f32)
+    hipLaunchKernelGGL((tokens_to_nchw_kernel<false, true>), grid, block, 0, s, src, ld, dst, n, c, hw);
   else
-    hipLaunchKernelGGL(tokens_to_nchw_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, s,
-                       reinterpret_cast<const f16*>(src), ld, dst, n, c, hw);
+    hipLaunchKernelGGL((tokens_to_nchw_kernel<false, false>), grid, block, 0, s, src, ld, dst, n, c, hw);
   return i2v_check_launch("i2v_tokens_to_nchw");
 }
 
@@ -276,17 +281,22 @@ extern "C" int i2v_ddim_prep(float* latents, const float* cond, void* model_in, 
   return i2v_check_launch("i2v_ddim_prep");
 }
 
-extern "C" int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, const float* coef,
-                                 int32_t n_steps, int32_t* step_index, float guidance_scale, int32_t b, int32_t f,
-                                 int32_t c, int32_t hw, int32_t cfg_copies, i2v_stream_t stream) {
+extern "C" int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int32_t np_is_f32, int64_t ld_np,
+                                 const float* coef, int32_t n_steps, int32_t* step_index, float guidance_scale, int32_t b,
+                                 int32_t f, int32_t c, int32_t hw, int32_t cfg_copies, i2v_stream_t stream) {
   I2V_CHECK_ARG(latents && noise_pred && coef && step_index && b > 0 && f > 0 && c > 0 && hw > 0 && ld_np >= c &&
                     n_steps > 0,
                 "i2v_ddim_cfg_step: bad arguments");
   I2V_CHECK_ARG(cfg_copies == 1 || cfg_copies == 2, "i2v_ddim_cfg_step: cfg_copies must be 1 or 2");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_blocks((int64_t)b * f * c * hw)), dim3(256), 0, s, latents,
-                     reinterpret_cast<const f16*>(noise_pred), ld_np, coef, n_steps, step_index, guidance_scale, b, f, c,
-                     hw, cfg_copies);
+  if (np_is_f32)
+    hipLaunchKernelGGL(ddim_step_kernel<float>, dim3(ew_blocks((int64_t)b * f * c * hw)), dim3(256), 0, s, latents,
+                       reinterpret_cast<const float*>(noise_pred), ld_np, coef, n_steps, step_index, guidance_scale, b, f,
+                       c, hw, cfg_copies);
+  else
+    hipLaunchKernelGGL(ddim_step_kernel<f16>, dim3(ew_blocks((int64_t)b * f * c * hw)), dim3(256), 0, s, latents,
+                       reinterpret_cast<const f16*>(noise_pred), ld_np, coef, n_steps, step_index, guidance_scale, b, f,
+                       c, hw, cfg_copies);
   hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step_index, n_steps);
   return i2v_check_launch("i2v_ddim_cfg_step");
 }

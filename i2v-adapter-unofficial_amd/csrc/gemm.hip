@@ -283,6 +283,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
             }
           }
         }
+      } else if (p.c_is_f32) {
+        float* dst = reinterpret_cast<float*>(p.c) + m_out * p.ldc + n;
+        if (vec4) {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) dst[r] = v[r];
+        }
       } else {
         f16* dst = C + m_out * p.ldc + n;
         if (vec4) {
@@ -329,6 +338,8 @@ int vector_epilogue_ok(const i2v_gemm_params& p) {
     vec4 = (p.vt_len % 4 == 0 && p.vt_ld % 4 == 0 && aligned_to(p.c, 8) && p.M % 4 == 0) ? 1 : 0;
   } else if (p.epilogue == I2V_EPI_GEGLU) {
     if (p.ldc % 2 != 0 || !aligned_to(p.c, 4)) vec4 = 0;
+  } else if (p.c_is_f32) {
+    if (p.ldc % 4 != 0 || !aligned_to(p.c, 16)) vec4 = 0;
   } else {
     if (p.ldc % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
   }
@@ -401,6 +412,10 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
                   "i2v_gemm_f16: VT_T store takes no residual, and a rowvec only as the transposed positional table of a "
                   "LayerNorm-folded projection");
   }
+  if (p.c_is_f32)
+    I2V_CHECK_ARG(p.c_is_f32 == 1 && p.epilogue != I2V_EPI_GEGLU && p.store_mode == I2V_STORE_ROWMAJOR && p.ln_wsum == nullptr &&
+                      p.rows_per_w == 0 && p.a_perm_frames == 0 && p.N <= 64 && aligned_to(p.c, 4),
+                  "i2v_gemm_f16: an fp32 result (c_is_f32) is a row-major store of a narrow (N <= 64), plain problem");
   if (p.rowvec) I2V_CHECK_ARG(p.rows_per_vec > 0 || p.rowvec_period > 0, "i2v_gemm_f16: rows_per_vec must be positive");
   if (p.store_mode == I2V_STORE_ROWPERM) {
     I2V_CHECK_ARG(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0,

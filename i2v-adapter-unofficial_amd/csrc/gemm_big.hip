@@ -945,6 +945,7 @@ int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4) {
 namespace {
 // columns per tile for this problem: 320 (UNet), or for 3x3 convolutions 256 / 128 (VAE channel counts); 0 = none
 int big_bn(const i2v_gemm_params& p) {
+  if (p.c_is_f32) return 0;   // fp32 results exist in the generic kernel only (narrow outputs)
   if (p.N % BIG_BN == 0) return BIG_BN;
   static const int vae = getenv("I2V_GEMM_BIG_VAE") ? atoi(getenv("I2V_GEMM_BIG_VAE")) : 1;
   if (vae && p.a_mode == I2V_A_CONV3X3 && p.epilogue == I2V_EPI_NONE && p.store_mode == I2V_STORE_ROWMAJOR) {

@@ -169,11 +169,12 @@ def conv_k_block(cin: int) -> int:
 
 
 def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
-            out_scale=1.0, asym_pad=False):
+            out_scale=1.0, asym_pad=False, out_f32=False):
     """3x3 / pad 1 convolution of a token-major image x [N, H, W, Cin] with w_packed [Cout, 9 * Cin]
     (k ordered as `blocks.pack_conv3x3` lays it out: tap-major, or channel-block-major when Cin % 64 == 0, see
     conv_k_block); optional nearest-2x upsampling of the input first.  asym_pad (stride 2): no
-    padding at the top / left, one zero row / column at the bottom / right (the VAE encoder's Downsample2D(padding=0))."""
+    padding at the top / left, one zero row / column at the bottom / right (the VAE encoder's Downsample2D(padding=0)).
+    out_f32: the result stays fp32 (narrow outputs only, Cout <= 64: the UNet's conv_out feeding the DDIM / CFG kernel)."""
     lib = _lib.load()
     _req(x, "x")
     if x.dim() != 4 or not x.is_contiguous():
@@ -193,8 +194,11 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
         padsum = 1 if asym_pad else 2
         oh, ow = (h + padsum - 3) // stride + 1, (wd + padsum - 3) // stride + 1
     M = n * oh * ow
-    out = torch.empty((n, oh, ow, cout), dtype=f16, device=x.device)
+    if out_f32 and (cout > 64 or residual is not None):
+        raise ValueError("out_f32 is for narrow outputs (Cout <= 64) without a residual")
+    out = torch.empty((n, oh, ow, cout), dtype=torch.float32 if out_f32 else f16, device=x.device)
     p = GemmParams()
+    p.c_is_f32 = 1 if out_f32 else 0
     p.a, p.lda = _p(x), cin
     p.a_mode = I2V_A_CONV3X3
     p.w, p.ldw = _p(w_packed), ldw
@@ -448,9 +452,11 @@ def nchw_to_tokens(src, c_pad=None):
 
 
 def tokens_to_nchw(src, c=None, dtype=f16):
-    """token-major fp16 [N, H, W, ld] -> [N, c, H, W] in `dtype` (fp16 / fp32)."""
+    """token-major fp16 / fp32 [N, H, W, ld] -> [N, c, H, W] in `dtype` (fp16 / fp32)."""
     lib = _lib.load()
-    _req(src, "src")
+    _req(src, "src", dtype=None)
+    if src.dtype not in (torch.float32, f16):
+        raise TypeError("src must be fp16 or fp32")
     if src.dim() != 4 or not src.is_contiguous():
         raise ValueError("src must be contiguous [N, H, W, C]")
     n, h, w, ld = src.shape
@@ -458,8 +464,8 @@ def tokens_to_nchw(src, c=None, dtype=f16):
     if dtype not in (torch.float32, f16):
         raise TypeError("dtype must be fp32 or fp16")
     dst = torch.empty((n, c, h, w), dtype=dtype, device=src.device)
-    _lib.check(lib.i2v_tokens_to_nchw(_p(src), ld, _p(dst), 1 if dtype == torch.float32 else 0, n, c, h * w,
-                                      _stream()), "i2v_tokens_to_nchw")
+    _lib.check(lib.i2v_tokens_to_nchw(_p(src), 1 if src.dtype == torch.float32 else 0, ld, _p(dst),
+                                      1 if dtype == torch.float32 else 0, n, c, h * w, _stream()), "i2v_tokens_to_nchw")
     return dst
 
 
@@ -564,12 +570,14 @@ def ddim_prep(latents, cond, c_pad, cfg_copies):
 
 
 def ddim_cfg_step(latents, noise_pred, coef, step_index, guidance_scale, cfg_copies):
-    """In-place DDIM update of latents fp32 [B, F, C, H, W] from noise_pred tokens fp16
+    """In-place DDIM update of latents fp32 [B, F, C, H, W] from noise_pred tokens (fp32, or fp16)
     [cfg_copies * B * F, H, W, ld]; coef fp32 [steps, 4]; step_index device int32 scalar (advanced by one, wrapping
     to 0 at the end of the table)."""
     lib = _lib.load()
     _req(latents, "latents", dtype=torch.float32)
-    _req(noise_pred, "noise_pred")
+    _req(noise_pred, "noise_pred", dtype=None)
+    if noise_pred.dtype not in (torch.float32, f16):
+        raise TypeError("noise_pred must be fp32 or fp16")
     _req(coef, "coef", dtype=torch.float32)
     _req(step_index, "step_index", dtype=torch.int32)
     b, f, c, h, w = latents.shape
@@ -578,7 +586,8 @@ def ddim_cfg_step(latents, noise_pred, coef, step_index, guidance_scale, cfg_cop
         raise ValueError(f"noise_pred must be contiguous [{cfg_copies * b * f}, {h}, {w}, >={c}]")
     if coef.dim() != 2 or coef.shape[1] != 4 or not coef.is_contiguous():
         raise ValueError("coef must be contiguous [steps, 4]")
-    _lib.check(lib.i2v_ddim_cfg_step(_p(latents), _p(noise_pred), noise_pred.shape[3], _p(coef), coef.shape[0],
+    _lib.check(lib.i2v_ddim_cfg_step(_p(latents), _p(noise_pred), 1 if noise_pred.dtype == torch.float32 else 0,
+                                     noise_pred.shape[3], _p(coef), coef.shape[0],
                                      _p(step_index), float(guidance_scale), b, f, c, h * w, cfg_copies, _stream()),
                "i2v_ddim_cfg_step")
     return latents

@@ -41,7 +41,13 @@ def draw_blur_sigma(generator=None, sigma_min: float = 0.1, sigma_max: float = 2
 
 def _draw(fn, shape, generator, device):
     """one seeded draw on the generator's own device (host generators reproduce the CPU oracle's numbers bit for bit;
-    a torch.Generator(device="cuda") keeps the whole prior on the GPU), moved to `device`."""
+    a torch.Generator(device="cuda") keeps the whole prior on the GPU), moved to `device`.  A list of generators draws
+    one sample (leading index) per generator, as `prepare_latents` does (pipe:287-290): a sample's noise then does not
+    depend on which other samples share its call."""
+    if isinstance(generator, (list, tuple)):
+        if len(generator) != shape[0]:
+            raise ValueError(f"{len(generator)} generators for a batch of {shape[0]}")
+        return torch.cat([_draw(fn, (1,) + tuple(shape[1:]), g, device) for g in generator], dim=0)
     gdev = generator.device if generator is not None else torch.device("cpu")
     return fn(shape, generator=generator, dtype=torch.float32, device=gdev).to(device)
 
@@ -173,6 +179,7 @@ class I2VAdapterPipeline:
 
     def _run_steps(self, st, n_steps, use_graph):
         if not use_graph:
+            st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
             for _ in range(n_steps):
                 self._step(st)
             return st["latents"]
@@ -190,6 +197,11 @@ class I2VAdapterPipeline:
             gst["step_idx"].zero_()
             self.unet.project_context(gst["ctx_text"], gst["ctx_ip"], out=gst["ctx_proj"])
         else:
+            # one shape at a time (a graph pins its workspace): the old graph and its pool go before the new capture,
+            # so two pools never coexist at the peak
+            cache.clear()
+            self._graph = None
+            st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
             # warm-up outside capture: packs weights, sizes the allocator; then restore the state it advanced
             saved = st["latents"].clone()
             self._step(st)
@@ -202,7 +214,6 @@ class I2VAdapterPipeline:
             st["latents"].copy_(saved)      # capture does not execute, but keep the invariant explicit
             st["step_idx"].zero_()
             gst = dict(st)                  # its own dict: the caller goes on to rebind entries of `st`
-            cache.clear()                   # one shape at a time: a graph pins its workspace
             cache[key] = (graph, gst)
         self._graph = graph
         for _ in range(n_steps):
@@ -281,8 +292,9 @@ class I2VAdapterPipeline:
         # first-frame-similarity prior + add_noise (pipe:647-656) in ONE HIP kernel; the reference overwrites the
         # latents drawn above (its `latents = self.scheduler.add_noise(...)`, pipe:656), and so does this.  The random
         # draws (blur sigma, mask, noise) take explicit generators (the reference uses the unseeded global RNG).
-        if blur_sigma is None:
-            blur_sigma = draw_blur_sigma(prior_mask_generator)                                  # pipe:112
+        if blur_sigma is None:                                                                  # pipe:112
+            blur_sigma = draw_blur_sigma(prior_mask_generator[0] if isinstance(prior_mask_generator, (list, tuple))
+                                         else prior_mask_generator)
         shape = (batch_size, num_frames) + tuple(cond_dev.shape[1:])
         mask_u = _draw(torch.rand, shape, prior_mask_generator, dev)                            # pipe:652
         noise = _draw(torch.randn, shape, prior_noise_generator, dev)                           # pipe:655
@@ -299,10 +311,11 @@ class I2VAdapterPipeline:
             ctx_ip=self.unet._project_image_embeds(
                 {"image_embeds": image_embeds.to(dev)} if image_embeds is not None else None))
         # K / V^T of the prompt (+ image) context for all 16 cross-attention layers: once per sample, not once per step
-        st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
+        # (projected where it is consumed: a graph-cache hit projects straight into the graph's static buffers)
         if callback is None:
             st["latents"] = self._run_steps(st, len(timesteps), use_graph)
         else:
+            st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
             for i, t in enumerate(timesteps):                                                   # pipe:666-697
                 self._step(st)
                 if i % callback_steps == 0:

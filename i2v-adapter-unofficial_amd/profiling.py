@@ -17,12 +17,12 @@ def _numel_bytes(*ts):
 
 def _work_gemm(args, kw, out):
     a, w = args[0], args[1]
-    M, N, Kd = a.shape[0], w.shape[0], w.shape[1]
-    if kw.get("a2") is not None:
-        Kd = w.shape[1]
+    M, N, Kd = a.shape[0], w.shape[-2], w.shape[-1]      # w may be a stack [S, N, K] of per-image weights (GroupNorm fold)
     tag = "".join(t for t, on in ((" geglu", kw.get("epilogue") == K.I2V_EPI_GEGLU), (" gelu", kw.get("epilogue") == K.I2V_EPI_GELU),
                                   (" +res", kw.get("residual") is not None), (" +ln", kw.get("ln") is not None),
                                   (" st%d" % kw.get("store", 0), bool(kw.get("store")))) if on)
+    if w.dim() == 3:
+        tag += " wstack%d" % w.shape[0] + (" perm" if kw.get("a_perm") is not None else "")
     return ("gemm", 2.0 * M * N * Kd, _numel_bytes(a, kw.get("a2"), w, kw.get("residual"), out),
             f"{M}x{N}x{Kd}{tag}")
 

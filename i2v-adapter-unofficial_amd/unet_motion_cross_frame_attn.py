@@ -659,7 +659,9 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
             else:
                 x = blk._fwd(x, r, temb_act, num_frames)
         x = K.groupnorm(x, p["g_out"], p["be_out"], self.config.norm_num_groups, self.config.norm_eps, silu=True)
-        return K.conv3x3(x, p["w_out"], p["b_out"])                                     # unet:1439-1443
+        # the 4-channel noise prediction stays fp32: the CFG combine (pipe:686-688) would amplify an fp16 rounding here
+        # by up to 2 * guidance - 1, and the reference returns `sample`'s dtype (fp32 latents in its driver)
+        return K.conv3x3(x, p["w_out"], p["b_out"], out_f32=True)                       # unet:1439-1443
 
     def _embed_time(self, timesteps_f32, t_index=None):
         """Timesteps -> TimestepEmbedding (unet:1336-1343); one row per sample (the per-frame repeat of unet:1344

@@ -199,7 +199,7 @@ class Decoder(_ConvEnds):
         for blk in self.up_blocks:
             x = blk._fwd(x)
         x = K.groupnorm(x, p["g"], p["be"], self.groups, 1e-6, silu=True)
-        return K.conv3x3(x, p["w_out"], p["b_out"])
+        return K.conv3x3(x, p["w_out"], p["b_out"], out_f32=True)      # the 3-channel image leaves in fp32
 
 
 class DiagonalGaussianDistribution:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 3
+#define I2V_ABI_VERSION 4
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -135,6 +135,11 @@ typedef struct i2v_gemm_params {
      summed by a second kernel that applies the epilogue; NULL / too small => no split. */
   void* workspace;
   int64_t workspace_bytes;
+  /* 1: c is FP32 [M, N] (ld = ldc elements) instead of fp16.  Row-major store, no GEGLU; narrow outputs only (the
+     generic 4-wave kernel): the UNet's 4-channel conv_out (unet:879-881, 1443) hands the noise prediction to
+     i2v_ddim_cfg_step without an fp16 rounding that the CFG combine (pipe:686-688) would amplify by up to
+     2 * guidance_scale - 1. */
+  int32_t c_is_f32;
 } i2v_gemm_params;
 
 int i2v_gemm_f16(const i2v_gemm_params* p, i2v_stream_t stream);
@@ -255,9 +260,10 @@ int i2v_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32
  * (sample.reshape + conv_in input, unet:1358). */
 int i2v_nchw_to_tokens(const void* src, int32_t src_is_f32, void* dst, int32_t n, int32_t c, int32_t hw,
                        int32_t c_pad, i2v_stream_t stream);
-/* token-major fp16 [n, hw, ld] (first c channels) -> NCHW (fp32 if dst_is_f32 else fp16) (unet:1446). */
-int i2v_tokens_to_nchw(const void* src, int64_t ld, void* dst, int32_t dst_is_f32, int32_t n, int32_t c,
-                       int32_t hw, i2v_stream_t stream);
+/* token-major (fp32 if src_is_f32 else fp16) [n, hw, ld] (first c channels) -> NCHW (fp32 if dst_is_f32 else fp16)
+ * (unet:1446). */
+int i2v_tokens_to_nchw(const void* src, int32_t src_is_f32, int64_t ld, void* dst, int32_t dst_is_f32, int32_t n,
+                       int32_t c, int32_t hw, i2v_stream_t stream);
 /* Timesteps(dim, flip_sin_to_cos=True, shift 0): out[b, :] = [cos(t*w) | sin(t*w)] fp16 (unet:763,1336).
  * t is fp32 [n]; if t_index != NULL, t is a table of t_rows entries and the single value
  * t[clamp(*t_index, 0, t_rows - 1)] is used for every row (graph replay). */
@@ -279,11 +285,12 @@ int i2v_copy3d_f16(const void* src, int64_t src_batch_stride, int64_t ld_src, vo
  *   step : eps = u + g (c - u) (pipe:686-688); x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);
  *          x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps (pipe:691); then *step_index advances by one
  *          and wraps to 0 after n_steps (the table row read is clamped to [0, n_steps - 1]).
- * latents fp32 [b, f, c, hw]; cond fp32 [b, c, hw]; noise_pred fp16 tokens [cfg_copies*b*f, hw, ld_np];
+ * latents fp32 [b, f, c, hw]; cond fp32 [b, c, hw]; noise_pred tokens [cfg_copies*b*f, hw, ld_np], fp32 if np_is_f32
+ * (the conv_out GEMM with c_is_f32) else fp16;
  * coef fp32 [n_steps][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}; step_index device int32. */
 int i2v_ddim_prep(float* latents, const float* cond, void* model_in, int32_t b, int32_t f, int32_t c,
                   int32_t hw, int32_t c_pad, int32_t cfg_copies, i2v_stream_t stream);
-int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int64_t ld_np, const float* coef, int32_t n_steps,
+int i2v_ddim_cfg_step(float* latents, const void* noise_pred, int32_t np_is_f32, int64_t ld_np, const float* coef, int32_t n_steps,
                       int32_t* step_index, float guidance_scale, int32_t b, int32_t f, int32_t c, int32_t hw,
                       int32_t cfg_copies, i2v_stream_t stream);
 

@@ -131,6 +131,65 @@ def ref_block_goldens():
     print("wrote ref_resblock_conv_gn")
 
 
+def ref_temporal_and_resblock_goldens():
+    """Round 3: two more compositions executed by reference-authored code (imports without diffusers).
+
+    * `VideoTransformer.forward` (src/modules/attention.py:79-131): the reference's frames-as-sequence path --
+      `(b t) s c -> (b s) t c`, a `BasicTransformerBlock` over the frame axis (LN -> self-attention -> +x, twice: with
+      no context its attn2 is self-attention too, :52), `(b s) t c -> (b t) s c` -- is exactly the geometry of the motion
+      module's double self-attention that the HIP path runs in (b, pixel, frame) row order.  The forward is
+      run WHOLE; the parts that are not under test are neutralised through their parameters (spatial attn1 / attn2
+      `to_out` zeroed => x_spatial = x; `frame_pos_embed` last Linear zeroed => emb_out = 0; time_mixer mix_factor =
+      -100 => alpha = sigmoid(-100) = 0 => output = x_temporal), so y - x is the temporal block's output, every
+      rearrangement done by the reference.  8 heads x 64 (the class's fixed defaults), 16 frames.
+    * `ResBlock.forward` (src/modules/resnet.py:63-72), whole: conv3x3 -> GroupNorm -> GELU, + emb_layer(t) broadcast
+      over pixels (Linear -> SiLU -> Linear), conv3x3 -> GroupNorm -> GELU, + 1x1 res_conv(x)."""
+    sys.path.insert(0, REFERENCE)
+    from src.modules.attention import VideoTransformer
+    from src.modules.resnet import ResBlock
+    torch.manual_seed(2024)
+    c, frames, hh, ww = 512, 16, 4, 4
+    vt = VideoTransformer(c).eval()
+    with torch.no_grad():
+        for a in (vt.attn1, vt.attn2):
+            a.to_out[0].weight.zero_()
+            a.to_out[0].bias.zero_()
+        vt.frame_pos_embed[2].weight.zero_()
+        vt.frame_pos_embed[2].bias.zero_()
+        vt.time_mixer.mix_factor.fill_(-100.0)
+        for n, p in vt.video_attn.named_parameters():
+            if "norm" in n:
+                p.add_(0.2 * torch.randn(p.shape))
+            p.copy_(h(p))
+    g = torch.Generator().manual_seed(2025)
+    x = h(torch.randn(frames, c, hh, ww, generator=g))                     # one clip: (b t) c h w with b = 1
+    with torch.no_grad():
+        y = vt(x, None, frames, torch.zeros(1, frames)) - x
+    t = {"x": x, "y": y}
+    t.update({k: v.detach().half() for k, v in vt.video_attn.state_dict().items()})   # fp16-representable: stored as fp16
+    save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(OUT, "ref_video_transformer_temporal.safetensors"),
+              metadata=dict(heads="8", head_dim="64", frames=str(frames)))
+    print("wrote ref_video_transformer_temporal", tuple(y.shape), float(y.abs().max()))
+
+    torch.manual_seed(88)
+    rb = ResBlock(64, 128, 32, group_nums=8).eval()
+    with torch.no_grad():
+        for n, p in rb.named_parameters():
+            if n in ("conv1.1.weight", "conv1.1.bias", "conv2.1.weight", "conv2.1.bias"):
+                p.add_(0.2 * torch.randn(p.shape))
+            p.copy_(h(p))
+    g = torch.Generator().manual_seed(89)
+    x = h(torch.randn(3, 64, 12, 12, generator=g))
+    ts = h(torch.randn(3, 32, generator=g))
+    with torch.no_grad():
+        y = rb(x, ts)
+    t = {"x": x, "timesteps": ts, "y": y}
+    t.update({k: v.detach().clone() for k, v in rb.state_dict().items()})
+    save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(OUT, "ref_resblock_forward.safetensors"),
+              metadata=dict(groups="8", eps="1e-05"))
+    print("wrote ref_resblock_forward", tuple(y.shape), float(y.abs().max()))
+
+
 def oracle_goldens():
     from oracle.blocks import DDPMScheduler
     from oracle.i2v_adapter import I2VAdapterTransformerBlock
@@ -187,8 +246,11 @@ def oracle_goldens():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if os.path.isdir(REFERENCE):
-        ref_attention_goldens()
-        ref_block_goldens()
+        if "--only-new" not in sys.argv:
+            ref_attention_goldens()
+            ref_block_goldens()
+        ref_temporal_and_resblock_goldens()
     else:
         print("reference not present: keeping the committed ref_attention_* fixtures")
-    oracle_goldens()
+    if "--only-new" not in sys.argv:
+        oracle_goldens()

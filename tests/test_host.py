@@ -204,3 +204,41 @@ def test_vae_container_layout_and_image_plumbing(tmp_path):
     vid = p.tensor2vid(t2[None].repeat(1, 3, 1, 1, 1), proc, "pil")
     path = p.export_to_gif(vid[0], str(tmp_path / "x.gif"))
     assert PIL.Image.open(path).n_frames >= 1
+
+
+def test_vae_from_pretrained_converts_deprecated_attention_names(tmp_path):
+    """SD-1.5 `vae/` folders in the wild (runwayml/stable-diffusion-v1-5, sd-vae-ft-mse) store the mid-block attention
+    as `attentions.0.{query,key,value,proj_attn}` (some as 1x1 convolutions); diffusers renames them on load
+    (`_convert_deprecated_attention_blocks`, reached from pipe:754).  `from_pretrained` must accept both layouts."""
+    import json
+    from safetensors.torch import save_file
+    p = pkg()
+    from i2v_adapter_unofficial_amd.vae import AutoencoderKL
+    from i2v_adapter_unofficial_amd.checkpoint import init_random_weights_
+    kw = dict(block_out_channels=(32, 64), layers_per_block=1, norm_num_groups=8, latent_channels=4)
+    vae = init_random_weights_(AutoencoderKL(**kw), seed=9, norm_jitter=0.1)
+    sd = vae.state_dict()
+    ren = ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn."))
+    old = {}
+    for k, v in sd.items():
+        nk = k
+        if ".attentions." in k:
+            for new_name, old_name in ren:
+                nk = nk.replace(new_name, old_name)
+            if nk != k and v.dim() == 2 and "encoder" in k:      # the conv-shaped variant of the same weights
+                v = v[:, :, None, None]
+        old[nk] = v.contiguous()
+    assert any(".query." in k for k in old) and not any(".to_q." in k for k in old)
+    d = tmp_path / "vae"
+    d.mkdir()
+    json.dump({"_class_name": "AutoencoderKL", **{k: list(v) if isinstance(v, tuple) else v for k, v in kw.items()}},
+              open(d / "config.json", "w"))
+    save_file(old, str(d / "diffusion_pytorch_model.safetensors"))
+    back = AutoencoderKL.from_pretrained(str(d))
+    for k, v in back.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # an unknown key is still an error, not silently dropped
+    old["decoder.mid_block.attentions.0.bogus.weight"] = torch.zeros(1)
+    save_file(old, str(d / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(RuntimeError, match="unexpected keys"):
+        AutoencoderKL.from_pretrained(str(d))

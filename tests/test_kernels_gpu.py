@@ -238,6 +238,31 @@ def test_conv3x3(dev, n, hh, ww, cin, cout, stride, up):
     close(out.permute(0, 3, 1, 2), ref + rv[:, :, None, None] + res, name="conv3x3+temb+res")
 
 
+@pytest.mark.parametrize("cout,cin", [(4, 320), (3, 128), (8, 64)])
+def test_conv3x3_fp32_result(dev, cout, cin):
+    """narrow convolutions can keep their result in fp32 (i2v_gemm_params.c_is_f32): the UNet's 4-channel conv_out
+    (unet:879-881) feeding the CFG / DDIM kernel, the VAE decoder's 3-channel image.  Same accumulators as the fp16 form,
+    without the final rounding: the error against the exact convolution drops to the fp32 accumulation order."""
+    k = K()
+    g = torch.Generator().manual_seed(cout * 100 + cin)
+    x = h(torch.randn(2, cin, 12, 10, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = h(torch.randn(cout, generator=g))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    wp = _pack_conv(w).to(dev)
+    out32 = k.conv3x3(xt, wp, b.half().to(dev), out_f32=True)
+    out16 = k.conv3x3(xt, wp, b.half().to(dev))
+    assert out32.dtype == torch.float32 and out16.dtype == torch.float16
+    close(out32.permute(0, 3, 1, 2), ref, rel=1e-5, name="conv3x3 fp32 result")
+    assert torch.equal(out32.half(), out16), "the fp16 form must be the rounding of the fp32 form"
+    # both edge kernels take the fp32 tokens
+    close(k.tokens_to_nchw(out32, dtype=torch.float32), ref, rel=1e-5, name="tokens_to_nchw fp32 source")
+    assert torch.equal(k.tokens_to_nchw(out32, dtype=torch.float16), k.tokens_to_nchw(out16))
+    with pytest.raises(ValueError):
+        k.conv3x3(xt, _pack_conv(h(torch.randn(128, cin, 3, 3, generator=g))).to(dev), out_f32=True)
+
+
 def _pack_conv(w):
     """conv weights in the contraction order the kernel walks for this channel count (the product's packing function)"""
     from i2v_adapter_unofficial_amd.blocks import pack_conv3x3
@@ -282,6 +307,29 @@ def test_attention(dev, bq, group, heads, d, lq, lk):
                 batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group, out=out2, accumulate=True,
                 acc_scale=0.75)
     close(out2.view(bq, lq, c), prev.view(bq, lq, c) + 0.75 * ref, name="attention accumulate")
+
+
+def test_attention_config5_key_length(dev):
+    """BASELINE config 5's L0 level: Lq = Lk = 9216 (96 x 96 latent), head_dim 40, in the self (kv_group 1) and the
+    cross-frame (every frame reads frame 0's K / V) forms, against torch SDPA on the host.  144 key tiles per query
+    block: the online-softmax rescale chain at a length the UNet-level property tests never compared with anything."""
+    import torch.nn.functional as F
+    k = K()
+    g = torch.Generator().manual_seed(9216)
+    heads, d, L = 8, 40, 9216
+    c = heads * d
+    for bq, group in ((1, 1), (2, 2)):
+        bkv = bq // group
+        q = h(torch.randn(bq, L, c, generator=g))
+        kk = h(torch.randn(bkv, L, c, generator=g))
+        v = h(torch.randn(bkv, L, c, generator=g))
+        sp = lambda t: t.view(t.shape[0], L, heads, d).transpose(1, 2)
+        ref = F.scaled_dot_product_attention(sp(q), sp(kk.repeat_interleave(group, 0)), sp(v.repeat_interleave(group, 0)))
+        ref = ref.transpose(1, 2).reshape(bq, L, c)
+        vt = v.permute(0, 2, 1).contiguous()
+        out = k.attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
+                          batch_q=bq, lq=L, lk=L, heads=heads, head_dim=d, kv_group=group)
+        close(out.view(bq, L, c), ref, name=f"attention Lq=Lk=9216 d=40 group={group}")
 
 
 def test_attention_32x32_formulation_opt_in(dev):
@@ -599,6 +647,14 @@ def test_ddim_prep_and_step(dev):
     lat3 = ref_lat.clone().to(dev)
     k.ddim_cfg_step(lat3, npred.half().to(dev), coef.to(dev), step, 7.5, 2)
     assert int(step.item()) == 0 and torch.equal(lat3, lat2)
+    # fp32 noise prediction (the UNet's conv_out result un-rounded): exact against the host formula on fp32 values
+    np32 = torch.randn(2 * b * f, hh, ww, 4, generator=g)
+    step.fill_(5)
+    lat4 = ref_lat.clone().to(dev)
+    k.ddim_cfg_step(lat4, np32.to(dev), coef.to(dev), step, 7.5, 2)
+    u32, c32 = np32[: b * f], np32[b * f:]
+    eps32 = (u32 + 7.5 * (c32 - u32)).permute(0, 3, 1, 2).reshape(b, f, c, hh, ww)
+    close(lat4, sch.step(eps32, ts[5], ref_lat), rel=1e-6, name="ddim step, fp32 noise prediction")
 
 
 @pytest.mark.parametrize("b,f,c,hh,ww,sigma", [(2, 3, 4, 8, 6, 1.0), (1, 16, 4, 64, 64, 0.37), (2, 2, 4, 1, 5, 1.9)])

@@ -47,7 +47,8 @@ def test_attention_matches_reference_basic_attention(path):
 def test_golden_fixture_count():
     assert len(glob.glob(os.path.join(GOLD, "ref_attention_*.safetensors"))) == 6
     assert len(glob.glob(os.path.join(GOLD, "ref_transformer_block_*.safetensors"))) == 2
-    for f in ("oracle_outputs", "ref_positional_emb", "ref_resblock_conv_gn"):
+    for f in ("oracle_outputs", "ref_positional_emb", "ref_resblock_conv_gn", "ref_video_transformer_temporal",
+              "ref_resblock_forward"):
         assert os.path.exists(os.path.join(GOLD, f + ".safetensors"))
 
 
@@ -63,6 +64,66 @@ def load_ref_block_into(block, t):
         block.ff.net[2].weight.zero_()
         block.ff.net[2].bias.zero_()
     return block
+
+
+def temporal_model_from_video_transformer_fixture(cls, t, meta):
+    """A TransformerTemporalModel of this repo set up so that `model(x, num_frames) - x` must equal the
+    reference-authored VideoTransformer's temporal path on the fixture's weights (tests/golden/
+    ref_video_transformer_temporal: src/modules/attention.py:79-131, `(b t) s c -> (b s) t c`, BasicTransformerBlock over
+    the frame axis, back):
+      * transformer block <- the reference block's attn1 / attn2 / norm1 / norm2; feed-forward off (ff.net.2 = 0);
+        positional table zeroed (the reference path under test adds none);
+      * proj_in = proj_out = identity;
+      * the entry GroupNorm made the identity ON THIS INPUT: with ONE clip its statistics are per group only, so
+        gamma = sqrt(var_g + eps), beta = mean_g (fp64 on the host) give GN(x) = x up to the rounding of the affine."""
+    heads, d, frames = int(meta["heads"]), int(meta["head_dim"]), int(meta["frames"])
+    c = heads * d
+    torch.manual_seed(0)
+    m = cls(num_attention_heads=heads, attention_head_dim=d, in_channels=c, norm_num_groups=32,
+            attention_bias=False, activation_fn="geglu", positional_embeddings="sinusoidal",
+            num_positional_embeddings=32).eval()
+    load_ref_block_into(m.transformer_blocks[0], {k: v.float() for k, v in t.items()})
+    x = t["x"].double()                                                  # (frames, c, h, w): one clip
+    xg = x.permute(1, 0, 2, 3).reshape(32, -1)                            # group g = channels [16 g, 16 g + 16)
+    mean, var = xg.mean(dim=1), xg.var(dim=1, unbiased=False)
+    with torch.no_grad():
+        m.norm.weight.copy_((var + 1e-6).sqrt().repeat_interleave(c // 32))
+        m.norm.bias.copy_(mean.repeat_interleave(c // 32))
+        for lin in (m.proj_in, m.proj_out):
+            lin.weight.copy_(torch.eye(c))
+            lin.bias.zero_()
+        m.transformer_blocks[0].pos_embed.pe.zero_()
+    return m, frames
+
+
+def test_temporal_model_matches_reference_video_transformer():
+    """the oracle's motion-module reshapes + double self-attention over frames (A9) == the reference's VideoTransformer
+    temporal path on its weights."""
+    from oracle.blocks import TransformerTemporalModel
+    t, meta = _load_ref(os.path.join(GOLD, "ref_video_transformer_temporal.safetensors"))
+    m, frames = temporal_model_from_video_transformer_fixture(TransformerTemporalModel, t, meta)
+    with torch.no_grad():
+        y = m(t["x"], num_frames=frames)[0] - t["x"]
+    err = (y - t["y"]).abs().max().item()
+    assert err <= 2e-5 * t["y"].abs().max().item(), err
+
+
+def test_functional_restatement_of_reference_resblock_forward():
+    """ResBlock.forward (src/modules/resnet.py:63-72) restated with the torch functional ops the HIP composition test
+    mirrors (tests/test_golden_gpu.py): pins that reading of the reference."""
+    t, meta = _load_ref(os.path.join(GOLD, "ref_resblock_forward.safetensors"))
+    y = resblock_forward_functional(t, F.conv2d, lambda v, w, b: F.group_norm(v, 8, w, b, 1e-5), F.gelu, F.silu, F.linear)
+    assert torch.allclose(y, t["y"], atol=5e-6, rtol=1e-5), (y - t["y"]).abs().max()
+
+
+def resblock_forward_functional(t, conv2d, group_norm, gelu, silu, linear):
+    x = t["x"]
+    hmid = gelu(group_norm(conv2d(x, t["conv1.0.weight"], None, padding=1), t["conv1.1.weight"], t["conv1.1.bias"]))
+    emb = linear(silu(linear(t["timesteps"], t["emb_layer.0.weight"], t["emb_layer.0.bias"])),
+                 t["emb_layer.2.weight"], t["emb_layer.2.bias"])
+    hmid = hmid + emb[..., None, None]
+    out = gelu(group_norm(conv2d(hmid, t["conv2.0.weight"], None, padding=1), t["conv2.1.weight"], t["conv2.1.bias"]))
+    return out + conv2d(x, t["res_conv.weight"], t["res_conv.bias"])
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ref_transformer_block_*.safetensors"))))

@@ -53,3 +53,49 @@ def test_broadcast_and_shard_world_size_2():
     assert n0 == n1 > 0
     assert s0 == [0, 1, 2] and s1 == [3, 4]
     assert g0 == [0.0, 1.0] and g1 is None
+
+
+def _bench(*argv, env=None):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True,
+                       text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_bare_launch_spawns_ranks_and_shards_config4():
+    """`python bench.py --gpus 2 --pairs 64 --batch 4` with NO launcher around it (how the driver invokes N = 1): bench.py
+    must start `torch.distributed.run` as a child process itself, and the ranks must rendezvous on 127.0.0.1, broadcast
+    the flat weight buffer, block-partition the 64 pairs, run exactly K steps for each and agree on MAX-over-ranks time.
+    (--dry-run: gloo + a stub step; the same launcher / sharding / timing code runs over RCCL on GPUs.)"""
+    r, d = _bench("--gpus", "2", "--pairs", "64", "--batch", "4", "--steps", "3", "--dry-run")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["ranks_in_group"] == 2
+    assert d["weights_equal_on_all_ranks"] and d["broadcast_bytes"] > 0
+    assert d["pairs_covered_once"] and d["steps_per_pair"] == [3] and d["pairs"] == 64
+
+
+def test_bench_launch_argument_errors():
+    r, d = _bench("--gpus", "2", "--pairs", "6", "--batch", "4", "--steps", "1", "--dry-run")
+    assert r.returncode != 0 and "multiple of ranks x batch" in (r.stdout + r.stderr)
+    # a launcher that gave a different world size than --gpus is an error, not a silent N = 1 run
+    r, d = _bench("--gpus", "1", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
+
+
+def test_plan_groups_matches_shard_range():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import plan_groups
+    seen = []
+    for rank in range(8):
+        g = plan_groups(64, rank, 8, 4)
+        assert len(g) == 2 and all(len(x) == 4 for x in g)
+        seen += [i for x in g for i in x]
+    assert seen == list(range(64))

@@ -4,7 +4,8 @@
 # usage (GPU box, repo root): bash tools/ab_bench.sh path/to/libA.so path/to/libB.so [rounds] [extra bench.py args]
 set -e
 cd "${GRAFT_REPO_ROOT:?}"
-A=$1; B=$2; rounds=${3:-2}; shift 3 || true
+A=$1; B=$2; rounds=${3:-2}; shift $(( $# < 3 ? $# : 3 ))
+mkdir -p gpurun_out
 for r in $(seq 1 "$rounds"); do
   for v in A B; do
     lib=$A; [ $v = B ] && lib=$B

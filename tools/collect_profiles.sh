@@ -9,6 +9,7 @@
 #   <tag>_traffic.json            bytes below L2 per launch by kernel class (tools/pmc_traffic.sh)
 set -e
 cd "${GRAFT_REPO_ROOT:?}"
+mkdir -p gpurun_out
 tag=${1:-r2}
 export TMPDIR=/tmp
 python bench.py --shapes gpurun_out/${tag}_step_shapes.txt > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err

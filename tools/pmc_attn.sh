@@ -3,6 +3,7 @@
 # LDS bank conflicts, in two passes (8 SQ counters each).  Output: gpurun_out/<tag>_{a,b}/ + a printed summary.
 set -e
 cd "${GRAFT_REPO_ROOT:?}"
+mkdir -p gpurun_out
 tag=${1:-pmc_attn}
 export TMPDIR=/tmp
 GRP=${GRP:-16} ITERS=3 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/${tag}_a -- python tools/attn_only.py > /dev/null 2>&1

@@ -3,6 +3,7 @@
 # delivery is held up.  Few counters per pass (8 TCP/TCC counters in one pass hang rocprofv3 on this pool), each pass
 # under its own timeout.
 cd "${GRAFT_REPO_ROOT:?}"
+mkdir -p gpurun_out
 export TMPDIR=/tmp
 out=gpurun_out/pmc_l2
 rm -rf $out; mkdir -p $out

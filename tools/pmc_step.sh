@@ -6,6 +6,7 @@
 # -> gpurun_out/<tag>_{a,b}/ and gpurun_out/<tag>_summary.txt (copy the summary to profiles/)
 set -e
 cd "${GRAFT_REPO_ROOT:?}"
+mkdir -p gpurun_out
 tag=${1:-pmc_step}
 export TMPDIR=/tmp
 CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph"

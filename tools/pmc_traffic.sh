@@ -5,6 +5,7 @@
 # Run on the GPU box from the repo root:  bash tools/pmc_traffic.sh   ->  gpurun_out/traffic.json
 set -e
 cd "${GRAFT_REPO_ROOT:?}"
+mkdir -p gpurun_out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- \

@@ -3,7 +3,10 @@
 FETCH_SIZE / WRITE_SIZE are in KiB (memory-side L2 request counters); on gfx950 FETCH_SIZE counts half the bytes of a
 wide coalesced read (MI355X_MICROARCH.md, section HBM), so reads are doubled.  Infinity-Cache hits are included: this is
 traffic below L2, an upper bound on DRAM traffic."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_stamp   # noqa: E402  (hash of the kernel sources: bench.py attaches these figures only to the same sources)
 
 
 def classify(name):
@@ -40,7 +43,7 @@ def collect(d, counter):
 
 fetch, calls = collect(sys.argv[1], "FETCH_SIZE")
 write, calls_w = collect(sys.argv[2], "WRITE_SIZE")
-out = {"note": "bytes below L2 per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches; one eager bench.py run "
+out = {"source_stamp": source_stamp(), "note": "bytes below L2 per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches; one eager bench.py run "
                "(--steps 1 --warmup 1 --no-graph: 3 UNet steps incl. the instrumented one)", "classes": {}}
 for c in sorted(calls):
     n = calls[c]
