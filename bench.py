@@ -387,7 +387,10 @@ def main():
         if rank == 0:
             load_group(groups[0])
             torch.cuda._sleep(int(2.0e8))   # ~0.1 s device-side spin (not one of our kernels): the host runs ahead
-            with KernelProfile() as prof:
+            # (single-stream for this one step: the event pairs must bracket one kernel each; the timed replays above
+            #  run the small levels' independent chains on two streams, streams.py)
+            from i2v_adapter_unofficial_amd import streams
+            with KernelProfile() as prof, streams.disabled():
                 pipe._step(st)
             classes = prof.summary()
             if args.shapes:

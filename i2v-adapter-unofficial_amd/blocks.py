@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
+from . import streams
 from ._lib import (I2V_EPI_GEGLU, I2V_EPI_GELU, I2V_EPI_NONE, I2V_STORE_ROWPERM, HipLibraryError)
 from .checkpoint import PretrainedMixin
 
@@ -277,21 +278,24 @@ class ResnetBlock2D(HipModule):
         cin = c1 + (x2.shape[3] if x2 is not None else 0)
         if cin != self.in_channels:
             raise ValueError(f"ResnetBlock2D expects {self.in_channels} input channels, got {cin}")
-        h = K.groupnorm(x, p["g1"], p["b1"], self.groups, self.eps, x2=x2, silu=True)
-        rowvec, rpv = None, 0
-        if self.time_emb_proj is not None and temb_act is not None:
-            rowvec = (temb_act.view_for(self) if isinstance(temb_act, ProjectedTemb)
-                      else K.gemm(temb_act, p["wt"], p["bt"]))
-            rpv = (n // rowvec.shape[0]) * hh * ww
-        h = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv)
-        h = K.groupnorm(h, p["g2"], p["b2"], self.groups, self.eps, silu=True)
-        if self.conv_shortcut is not None:
-            a2 = None if x2 is None else x2.view(-1, x2.shape[3])
-            s = K.gemm(x.view(-1, c1), p["ws"], p["bs"], a2=a2).view(n, hh, ww, self.out_channels)
-        else:
-            if x2 is not None:
-                raise ValueError("concat input needs a conv_shortcut")
-            s = x
+        if self.conv_shortcut is None and x2 is not None:
+            raise ValueError("concat input needs a conv_shortcut")
+        s = x
+        # the 1x1 shortcut depends only on the block's input: at the levels where one launch cannot fill the chip it runs
+        # on a side stream beside GroupNorm -> conv1 -> GroupNorm (streams.fork), joined before conv2 adds it
+        with streams.fork(self.conv_shortcut is not None and n * hh * ww <= streams.MAX_ROWS, x.device) as fk:
+            if self.conv_shortcut is not None:
+                with fk.side():
+                    a2 = None if x2 is None else x2.view(-1, x2.shape[3])
+                    s = K.gemm(x.view(-1, c1), p["ws"], p["bs"], a2=a2).view(n, hh, ww, self.out_channels)
+            h = K.groupnorm(x, p["g1"], p["b1"], self.groups, self.eps, x2=x2, silu=True)
+            rowvec, rpv = None, 0
+            if self.time_emb_proj is not None and temb_act is not None:
+                rowvec = (temb_act.view_for(self) if isinstance(temb_act, ProjectedTemb)
+                          else K.gemm(temb_act, p["wt"], p["bt"]))
+                rpv = (n // rowvec.shape[0]) * hh * ww
+            h = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv)
+            h = K.groupnorm(h, p["g2"], p["b2"], self.groups, self.eps, silu=True)
         return K.conv3x3(h, p["w2"], p["cb2"], residual=s, out_scale=1.0 / self.output_scale_factor)
 
     def forward(self, input_tensor, temb, scale: float = 1.0):
@@ -614,16 +618,21 @@ class TemporalTransformerBlock(HipModule):
         p = self.packed()
         c = self.dim
         fold_attn, fold_ff = self._fold_ok(t, frames)
+        overlap = t.shape[0] <= streams.MAX_ROWS       # q|k beside V^T on two streams where neither fills the chip
         for i in (1, 2):
-            if fold_attn:
-                qk = K.gemm(t, p[f"f_wqk{i}"], p[f"f_cqk{i}"], ln=(p[f"f_sqk{i}"], self.eps), rowvec=p[f"f_peqk{i}"],
-                            rowvec_period=frames)
-                vt = K.project_vt(t, p[f"f_wv{i}"], frames, bias=p[f"f_cv{i}"], ln=(p[f"f_sv{i}"], self.eps),
-                                  pe_t=p[f"f_pev{i}"], pe_period=frames)
-            else:
-                n = K.layernorm(t, p[f"g{i}"], p[f"b{i}"], self.eps, pe=p["pe"], pe_period=frames)
-                qk = K.gemm(n, p[f"wqk{i}"])
-                vt = K.project_vt(n, p[f"wv{i}"], frames)
+            n = None if fold_attn else K.layernorm(t, p[f"g{i}"], p[f"b{i}"], self.eps, pe=p["pe"], pe_period=frames)
+            with streams.fork(overlap, t.device) as fk:
+                with fk.side():
+                    if fold_attn:
+                        vt = K.project_vt(t, p[f"f_wv{i}"], frames, bias=p[f"f_cv{i}"], ln=(p[f"f_sv{i}"], self.eps),
+                                          pe_t=p[f"f_pev{i}"], pe_period=frames)
+                    else:
+                        vt = K.project_vt(n, p[f"wv{i}"], frames)
+                if fold_attn:
+                    qk = K.gemm(t, p[f"f_wqk{i}"], p[f"f_cqk{i}"], ln=(p[f"f_sqk{i}"], self.eps),
+                                rowvec=p[f"f_peqk{i}"], rowvec_period=frames)
+                else:
+                    qk = K.gemm(n, p[f"wqk{i}"])
             o = K.temporal_attention(qk[:, :c], qk[:, c:], vt, n_pixels=n_pixels, frames=frames, heads=self.heads,
                                      head_dim=self.dim_head, scale=self.dim_head ** -0.5)
             t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
+from . import streams
 from .blocks import (gn_proj_in, Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
                      to_tokens, w16)
 from .checkpoint import PretrainedMixin
@@ -163,32 +164,45 @@ class I2VAdapterTransformerBlock(HipModule):
                 raise ValueError(f'Batch size {n_img} must be divisible by the number of frames {num_frames}.')
         rows_qkq = 3 * c if enable_cross_frame_attn else 2 * c                               # q1 | k1 [| q_adapter]
         fold1, fold2, fold3 = self._fold_ok(x, L, rows_qkq)
-        if fold1:
-            # LayerNorm 1 (i2v:444-445) is never materialised: the q|k|q_ad and V^T GEMMs normalise inside their K loops
-            wf, ws, cb = p["f_qkq"]
-            proj = K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(ws[:rows_qkq], self.eps))
-            wv, sv, cv = p["f_v1"]
-            vt1 = K.project_vt(x, wv, L, bias=cv, ln=(sv, self.eps))
-            n = None
-        else:
-            n = K.layernorm(x, p["g1"], p["b1"], self.eps)                                   # i2v:444-445
-            proj = K.gemm(n, p["w_qkq"][:rows_qkq])
-            vt1 = K.project_vt(n, p["w_v1"], L)
-        o1 = K.attention(proj[:, :c], proj[:, c:2 * c], vt1, batch_q=n_img, lq=L, lk=L, heads=self.heads,
-                         head_dim=self.dim_head, scale=self.dim_head ** -0.5)                # i2v:468-473
-        if enable_cross_frame_attn:
-            clips = n_img // num_frames
-            first = torch.empty((clips, L, c), dtype=f16, device=x.device)
-            if n is None:   # frame-0 rows only: gather the raw rows, normalise just those (1 / num_frames of the work)
-                K.copy3d(x.view(clips, num_frames * L, c)[:, :L], first)
-                first = K.layernorm(first.view(-1, c), p["g1"], p["b1"], self.eps).view(clips, L, c)
+        # Where one launch cannot fill the chip (16 x 16 and 8 x 8 levels) the independent chains of this block run on
+        # two streams (streams.fork): [q | k | q_adapter projection] beside [V^T projection, frame-0 gather -> K0 / V0^T],
+        # then [attn1] beside [adapter attention]; joined before the dual out-projection.
+        overlap = x.shape[0] <= streams.MAX_ROWS
+        # LayerNorm 1 (i2v:444-445): folded into the q|k|q_ad and V^T GEMMs (never materialised) where the library
+        # implements the fold for this level, else one pass that both chains read
+        n = None if fold1 else K.layernorm(x, p["g1"], p["b1"], self.eps)
+        k0 = v0t = None
+        with streams.fork(overlap, x.device) as fk:
+            with fk.side():
+                if fold1:
+                    wv, sv, cv = p["f_v1"]
+                    vt1 = K.project_vt(x, wv, L, bias=cv, ln=(sv, self.eps))
+                else:
+                    vt1 = K.project_vt(n, p["w_v1"], L)
+                if enable_cross_frame_attn:
+                    clips = n_img // num_frames
+                    first = torch.empty((clips, L, c), dtype=f16, device=x.device)
+                    if n is None:   # frame-0 rows only: gather the raw rows, normalise just those (1 / num_frames of the work)
+                        K.copy3d(x.view(clips, num_frames * L, c)[:, :L], first)
+                        first = K.layernorm(first.view(-1, c), p["g1"], p["b1"], self.eps).view(clips, L, c)
+                    else:
+                        K.copy3d(n.view(clips, num_frames * L, c)[:, :L], first)             # i2v:484 (no repeat)
+                    f2d = first.view(-1, c)
+                    k0 = K.gemm(f2d, p["w_k_ad"])
+                    v0t = K.project_vt(f2d, p["w_v_ad"], L)
+            if fold1:
+                wf, ws, cb = p["f_qkq"]
+                proj = K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(ws[:rows_qkq], self.eps))
             else:
-                K.copy3d(n.view(clips, num_frames * L, c)[:, :L], first)                     # i2v:484 (no repeat)
-            f2d = first.view(-1, c)
-            k0 = K.gemm(f2d, p["w_k_ad"])
-            v0t = K.project_vt(f2d, p["w_v_ad"], L)
-            o2 = K.attention(proj[:, 2 * c:], k0, v0t, batch_q=n_img, lq=L, lk=L, heads=self.heads,
-                             head_dim=self.dim_head, kv_group=num_frames, scale=self.dim_head ** -0.5)
+                proj = K.gemm(n, p["w_qkq"][:rows_qkq])
+        with streams.fork(overlap and enable_cross_frame_attn, x.device) as fk:
+            if enable_cross_frame_attn:
+                with fk.side():
+                    o2 = K.attention(proj[:, 2 * c:], k0, v0t, batch_q=n_img, lq=L, lk=L, heads=self.heads,
+                                     head_dim=self.dim_head, kv_group=num_frames, scale=self.dim_head ** -0.5)
+            o1 = K.attention(proj[:, :c], proj[:, c:2 * c], vt1, batch_q=n_img, lq=L, lk=L, heads=self.heads,
+                             head_dim=self.dim_head, scale=self.dim_head ** -0.5)            # i2v:468-473
+        if enable_cross_frame_attn:
             x = K.gemm(o1, p["w_o_dual"], p["b_o_dual"], a2=o2, residual=x)                  # i2v:494,501
         else:
             x = K.gemm(o1, p["w_o1"], p["b_o1"], residual=x)                                 # i2v:501
