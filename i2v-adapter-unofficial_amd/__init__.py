@@ -5,7 +5,7 @@ gfx950 reached through a C ABI (include/i2v_hip.h, csrc/).  Import name: `i2v_ad
 (the directory carries the repository's hyphenated name; `i2v_adapter_unofficial_amd.py` at the repo root
 registers it under the importable name).
 """
-from . import _lib, kernels  # noqa: F401
+from . import _lib, kernels, streams  # noqa: F401
 from ._lib import HipLibraryError  # noqa: F401
 
 

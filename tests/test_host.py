@@ -242,3 +242,16 @@ def test_vae_from_pretrained_converts_deprecated_attention_names(tmp_path):
     save_file(old, str(d / "diffusion_pytorch_model.safetensors"))
     with pytest.raises(RuntimeError, match="unexpected keys"):
         AutoencoderKL.from_pretrained(str(d))
+
+
+def test_fresh_process_import_order():
+    """every lazily exported class resolves in a fresh interpreter whatever is touched first (a submodule imported through
+    the package's lazy `__getattr__` once re-entered it and died in a circular import on the GPU box only)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for first in ("UNetMotionCrossFrameAttnModel", "I2VAdapterPipeline", "TransformerTemporalModel", "AutoencoderKL",
+                  "I2VAdapterModule"):
+        code = (f"import sys; sys.path.insert(0, {root!r}); import i2v_adapter_unofficial_amd as p; p.{first}; "
+                "from i2v_adapter_unofficial_amd import streams, blocks, sharding; p.I2VAdapterPipeline; print('ok')")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "ok" in r.stdout, first + "\n" + r.stderr[-1500:]

@@ -21,6 +21,63 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
+// 4 independent 16-byte loads in flight per thread, then 4 stores
+__global__ __launch_bounds__(256) void copy4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+}
+__global__ __launch_bounds__(256) void read_kernel(const float4* __restrict__ src, float* __restrict__ sink, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    acc += a.x + b.y + c.z + d.w;
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+
+// The inner loop of the 8-wave GEMM kernel with NOTHING else: per k-step 8 A + 5 W fragments by ds_read_b128 from a
+// conflict-free image, then the 8 x 5 outer product of v_mfma_f32_16x16x32_f16 (160 accumulators), two waves per SIMD,
+// no DMA, no barrier, no epilogue: the ceiling of that loop structure on this chip.
+__global__ __launch_bounds__(512) void gemm_loop_kernel(const _Float16* __restrict__ seed, float* __restrict__ out,
+                                                        long long* __restrict__ stamps, int iters) {
+  __shared__ __attribute__((aligned(16))) _Float16 lds[13 * 8 * 512];    // 13 fragments x 8 waves x 1 KiB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 13 * 8 * 512; i += 512) lds[i] = seed[i & 4095];
+  __syncthreads();
+  f4 acc[5][8];
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 8; ++j) acc[i][j] = f4{0, 0, 0, 0};
+  const _Float16* mine = lds + wave * 13 * 512 + lane * 8;
+  const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+    h8 wf[5], af[8];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wf[i] = *reinterpret_cast<const h8*>(mine + i * 512);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[j] = *reinterpret_cast<const h8*>(mine + (5 + j) * 512);
+    asm volatile("" ::: "memory");   // the reads are re-issued every iteration
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sum = 0.f;
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][3];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+  if (threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = t1 - t0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
 
 // LDSFED = 0: operands in registers.  LDSFED = 1: 2 A + 2 B fragments re-read from LDS per 4 MFMAs (the per-MFMA LDS
 // traffic of a 128 x 128 per-wave tile... far below the GEMM kernels'), so this is an upper bound for an LDS-fed loop.
@@ -115,16 +172,28 @@ int main() {
   hipEventCreate(&a);
   hipEventCreate(&b);
   std::vector<double> bw;
-  for (int rep = 0; rep < 8; ++rep) {
-    hipEventRecord(a);
-    hipLaunchKernelGGL(copy_kernel, dim3(cus * 32), dim3(256), 0, 0, src, dst, n);
-    hipEventRecord(b);
-    hipEventSynchronize(b);
-    float ms;
-    hipEventElapsedTime(&ms, a, b);
-    if (rep >= 3) bw.push_back(2.0 * bytes / (ms * 1e-3) / 1e9);
+  double best_read = 0.0;
+  float* sink;
+  hipMalloc(&sink, 64);
+  const int grids[4] = {cus * 8, cus * 16, cus * 32, cus * 64};
+  int best_variant = -1;
+  for (int v = 0; v < 12; ++v) {          // plain / 4-in-flight copy, read-only, at four grid sizes: keep the best
+    std::vector<double> cur;
+    for (int rep = 0; rep < 6; ++rep) {
+      hipEventRecord(a);
+      if (v < 4) hipLaunchKernelGGL(copy_kernel, dim3(grids[v]), dim3(256), 0, 0, src, dst, n);
+      else if (v < 8) hipLaunchKernelGGL(copy4_kernel, dim3(grids[v - 4]), dim3(256), 0, 0, src, dst, n);
+      else hipLaunchKernelGGL(read_kernel, dim3(grids[v - 8]), dim3(256), 0, 0, src, sink, n);
+      hipEventRecord(b);
+      hipEventSynchronize(b);
+      float ms;
+      hipEventElapsedTime(&ms, a, b);
+      if (rep >= 2) cur.push_back((v < 8 ? 2.0 : 1.0) * bytes / (ms * 1e-3) / 1e9);
+    }
+    std::sort(cur.begin(), cur.end());
+    if (v < 8 && (bw.empty() || cur[cur.size() / 2] > bw[bw.size() / 2])) { bw = cur; best_variant = v; }
+    if (v >= 8) best_read = std::max(best_read, cur[cur.size() / 2]);
   }
-  std::sort(bw.begin(), bw.end());
   // ---- MFMA
   std::vector<_Float16> hs(4096);
   srand(12345);
@@ -140,10 +209,37 @@ int main() {
   run_mfma<0>(1, seed, out, stamps, cus, &t1, &g1);
   run_mfma<0>(2, seed, out, stamps, cus, &t2, &g2);
   run_mfma<1>(2, seed, out, stamps, cus, &tl, &gl);
+  // the GEMM kernel's inner loop alone
+  double tg = 0, gg = 0;
+  {
+    const int iters = 200000;
+    hipLaunchKernelGGL(gemm_loop_kernel, dim3(cus), dim3(512), 0, 0, seed, out, stamps, iters);
+    hipDeviceSynchronize();
+    std::vector<double> rates;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(a);
+      hipLaunchKernelGGL(gemm_loop_kernel, dim3(cus), dim3(512), 0, 0, seed, out, stamps, iters);
+      hipEventRecord(b);
+      hipEventSynchronize(b);
+      float ms;
+      hipEventElapsedTime(&ms, a, b);
+      rates.push_back((double)cus * 8 * iters * 40.0 * 2.0 * 16 * 16 * 32 / (ms * 1e-3) / 1e12);
+    }
+    std::sort(rates.begin(), rates.end());
+    tg = rates[1];
+    std::vector<long long> h(2 * cus);
+    hipMemcpy(h.data(), stamps, sizeof(long long) * 2 * cus, hipMemcpyDeviceToHost);
+    std::vector<double> clk;
+    for (int i = 0; i < cus; ++i) clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);
+    std::sort(clk.begin(), clk.end());
+    gg = clk[clk.size() / 2];
+  }
   printf("{\"cus\": %d, \"hbm_copy_gbps\": %.1f, \"hbm_copy_gbps_min_max\": [%.1f, %.1f], "
          "\"mfma_f16_tflops\": %.1f, \"mfma_clock_ghz\": %.3f, \"mfma_f16_tflops_1wave_per_simd\": %.1f, "
          "\"mfma_clock_ghz_1wave_per_simd\": %.3f, \"mfma_lds_f16_tflops\": %.1f, \"mfma_lds_clock_ghz\": %.3f, "
-         "\"vendor_peak_tflops\": 2500.0, \"vendor_peak_hbm_gbps\": 8000.0}\n",
-         cus, bw[bw.size() / 2], bw.front(), bw.back(), std::max(t1, t2), t2 >= t1 ? g2 : g1, t1, g1, tl, gl);
+         "\"gemm_inner_loop_tflops\": %.1f, \"gemm_inner_loop_clock_ghz\": %.3f, \"hbm_read_gbps\": %.1f, "
+         "\"copy_variant\": %d, \"vendor_peak_tflops\": 2500.0, \"vendor_peak_hbm_gbps\": 8000.0}\n",
+         cus, bw[bw.size() / 2], bw.front(), bw.back(), std::max(t1, t2), t2 >= t1 ? g2 : g1, t1, g1, tl, gl, tg, gg,
+         best_read, best_variant);
   return 0;
 }
