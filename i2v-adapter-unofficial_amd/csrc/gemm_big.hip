@@ -96,18 +96,25 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
 // Everything else (conv, split-K, ragged M, channel-concatenated A) runs one tile per workgroup.
 // BNT: columns per tile, 320 (every channel count of the SD-1.5 UNet) or 256 / 128 (the VAE's 128 / 256 / 512 channels:
 // 4 N-waves x 64 or 32 columns); the LayerNorm fold and split-K exist for 320 only.
+// NW: waves per workgroup.  8 = 2 (M) x 4 (N) waves, one workgroup per CU (the two waves of a SIMD belong to the same tile
+// and run staggered).  4 = 1 x 4 waves with a 128-row tile and 32-deep stages: 62 KiB of LDS and 256 registers per wave, so
+// TWO workgroups share a CU -- the two waves of a SIMD then belong to DIFFERENT output tiles at unrelated phases, and one
+// tile's prologue (first DMA wait) and epilogue (LayerNorm apply, GELU, transposes, stores: as long as the K loop itself
+// when K = 320) run beside the other tile's MFMAs instead of stopping the CU.
 template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true, bool LNF = false,
-          bool FAST = false, int BNT = 320>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n, const int kps,
-                                                       const int ntiles) {
+          bool FAST = false, int BNT = 320, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n,
+                                                                            const int kps, const int ntiles) {
   static_assert(NS == 2, "the cross-tile prefetch of the persistent tile loop is written for two stages");
+  static_assert(NW == 8 || (NW == 4 && !STAGGER && !SPLIT), "4-wave workgroups: one M-wave, no stagger partner, no split-K");
   constexpr int BN = BNT;
   constexpr int WNC = BN / 4;               // columns per N-wave: 80 / 64 / 32
-  constexpr int WM = BM / 2, MI = WM / 16, NI = WNC / 16;
+  constexpr int WM = BM / (NW / 4), MI = WM / 16, NI = WNC / 16;
   static_assert(BN % 64 == 0 && (BN == 320 || (!LNF && !SPLIT)), "the LayerNorm fold and split-K are written for BN = 320");
-  constexpr int AG = BM * BK / 4096;        // 1 KiB (8-unit) A groups per wave: BM * BK * 2 / 1024 groups over 8 waves
+  constexpr int AG = BM * BK / (512 * NW);  // 1 KiB (8-unit) A groups per wave: BM * BK * 2 / 1024 groups over NW waves
   constexpr int WGT = BN * BK * 2 / 1024;   // W groups per tile (40 or 20)
-  constexpr int WG = (WGT + 7) / 8;         // per wave; for BK = 32 the third one exists for waves 0-3 only
+  constexpr int WG = (WGT + NW - 1) / NW;   // per wave (the last round may cover only the first waves)
+  static_assert(AG >= 1 && (BM * BK) % (512 * NW) == 0, "the A tile must be whole 1 KiB groups per wave");
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int KSTEPS = BK / 32;
   // + 1 KiB that swallows the DMA of W groups past the tile (every wave issues the same count: one vmcnt for all)
@@ -143,9 +150,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   //      writes 0 to LDS for it (LDS-DMA cannot skip a lane).  Per K tile only the scalar offset changes, so the
   //      plain-GEMM prefetch costs no VALU work and no 64-bit address registers.
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int RSTEP = BK == 64 ? 64 : 128;   // tile rows between a wave's consecutive 1 KiB groups
+  constexpr int RSTEP = (BK == 64 ? 8 : 16) * NW;   // tile rows between a wave's consecutive 1 KiB groups
   const int lr = lane >> 3, lc = lane & 7;
-  const int u0 = 8 * wave + lr;                // 128-byte unit of group 0; group i is unit u0 + 64 i, same swizzle
+  const int u0 = 8 * wave + lr;                // 128-byte unit of group 0; group i is unit u0 + 8 NW i, same swizzle
   const int c8 = lc ^ ((u0 >> 1) & 7);         // logical chunk this lane fetches (swizzle on the SOURCE side)
   const int r0 = BK == 64 ? u0 : 2 * u0 + (c8 >> 2);
   const int lane_k = (BK == 64 ? c8 : (c8 & 3)) * 8;   // k offset (halfs) of the chunk inside a K tile
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
           ok = (iy >= 0) && (ix >= 0) && (iy < p.in_h) && (ix < p.in_w);
         }
         const unsigned voff = ok ? (unsigned)(((cp[i] + iy * p.in_w + ix) * (int)p.lda + ci + lane_k) * 2) : OOB;
-        bdma16(rs_a, sa + (wave + 8 * i) * 1024, voff, 0);
+        bdma16(rs_a, sa + (wave + NW * i) * 1024, voff, 0);
       }
     } else if (FAST || (kb < ksp && tm0 + BM <= M)) {
       int arow0 = tm0, astep = RSTEP;   // first A row of group 0, rows between groups
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         // through the whole loop, which the accumulator-bound 256-row LayerNorm kernels cannot afford)
         int soff = ((arow0 + astep * i) * (int)p.lda + kb) * 2;
         asm volatile("" : "+s"(soff));
-        bdma16(rs_a, sa + (wave + 8 * i) * 1024, a_lane, soff);
+        bdma16(rs_a, sa + (wave + NW * i) * 1024, a_lane, soff);
       }
     } else {
       // last row tile of a ragged M (rows >= M carry the out-of-range offset: zero fill), or the second source of a
@@ -252,16 +259,16 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
         const int m = tm0 + orow + RSTEP * i;
         const unsigned voff = m < M ? (unsigned)((m * (int)(first ? p.lda : p.lda2) + ok8) * 2) : OOB;
         if (first)
-          bdma16(rs_a, sa + (wave + 8 * i) * 1024, voff, kb * 2);
+          bdma16(rs_a, sa + (wave + NW * i) * 1024, voff, kb * 2);
         else
-          bdma16(rs_a2, sa + (wave + 8 * i) * 1024, voff, (kb - ksp) * 2);
+          bdma16(rs_a2, sa + (wave + NW * i) * 1024, voff, (kb - ksp) * 2);
       }
     }
     const int wb_off = p.rows_per_w > 0 ? (int)((tm0 / p.rows_per_w) * p.w_batch_stride * 2) : 0;   // this tile's weights
 #pragma unroll
     for (int i = 0; i < WG; ++i) {
-      const bool in_tile = (WGT % 8 == 0) || (wave + 8 * i < WGT);   // wave-uniform
-      bdma16(rs_w, in_tile ? sw + (wave + 8 * i) * 1024 : smem + NS * STAGE, in_tile ? w_lane : OOB,
+      const bool in_tile = (WGT % NW == 0) || (wave + NW * i < WGT);   // wave-uniform
+      bdma16(rs_w, in_tile ? sw + (wave + NW * i) * 1024 : smem + NS * STAGE, in_tile ? w_lane : OOB,
              ((tn0 + RSTEP * i) * (int)p.ldw + kb) * 2 + wb_off);
     }
   };
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   const int nkt_all = (K + BK - 1) / BK;
   const int kt0 = SPLIT ? (int)blockIdx.y * kps : 0;
   const int nkt = SPLIT ? min(nkt_all, kt0 + kps) : nkt_all;
-  static_assert(!FAST || (!SPLIT && AMODE == I2V_A_PLAIN), "FAST is a plain, un-split GEMM");
+  static_assert(!FAST || (!SPLIT && AMODE == I2V_A_PLAIN && NW == 8), "FAST is a plain, un-split, 8-wave GEMM");
   constexpr bool PERSIST = FAST;
   int sbase = 0;             // LDS stage of the current tile's first K tile
   bool have_first = false;   // ... which the previous tile's loop has already issued
@@ -343,10 +350,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   if (!have_first && kt0 < nkt) issue(kt0, sbase);
   if (LNF) {
     const float* lnws_g = reinterpret_cast<const float*>(p.ln_wsum);
-    if (tid < BN) {
-      const float ln_col = lnws_g[n0 + tid];
+    if (NW == 8) {
+      if (tid < BN) {
+        const float ln_col = lnws_g[n0 + tid];
+        wait_vmcnt<0>();
+        lds_ws[tid] = ln_col;
+      }
+    } else {   // 256 threads for 320 columns
+      const float c0 = lnws_g[n0 + tid];
+      const float c1 = tid < BN - 256 ? lnws_g[n0 + 256 + tid] : 0.f;
       wait_vmcnt<0>();
-      lds_ws[tid] = ln_col;
+      lds_ws[tid] = c0;
+      if (tid < BN - 256) lds_ws[256 + tid] = c1;
     }
     ws_buf ^= 1;
   }
@@ -494,7 +509,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const i2v_gemm_params p, 
   // epilogue's transpose slabs once every wave has left the loop (the epilogues' own barrier)
   sbase = (sbase + (nkt - kt0)) & 1;
   have_first = has_next;
-  char* const slab_stage = smem + (sbase ^ 1) * STAGE;
+  // (4-wave workgroups are never persistent: nothing is in flight after the loop and the slabs may span both stages --
+  //  the V^T epilogue's four 8.4 KiB slabs exceed one 28 KiB stage)
+  char* const slab_stage = NW == 4 ? smem : smem + (sbase ^ 1) * STAGE;
 
   // ---------------------------------------------------------------- epilogue (lane: row m, 4 consecutive n)
   // The (epilogue, store mode) pair is a template parameter and the accumulator indices are compile-time constants
@@ -862,6 +879,54 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   return rc < 0 ? rc : 1;
 }
 
+// Two workgroups of 4 waves per CU: 128 x 320 x 32 tiles (see the NW template parameter)
+template <int AMODE>
+int launch_big4(const i2v_gemm_params& p, hipStream_t s) {
+  constexpr int BM = 128;
+  const int tiles_m = (int)i2v_cdiv(p.M, BM), tiles_n = p.N / BIG_BN;
+  const int ntiles = tiles_m * tiles_n;
+  const dim3 grid(ntiles), block(256);
+#define I2V_BIG4_LAUNCH(EPI, STORE, LNF) \
+  hipLaunchKernelGGL((gemm_big_kernel<BM, 32, 2, AMODE, EPI, STORE, false, false, LNF, false, 320, 4>), grid, block, 0, s, p, tiles_n, 0, ntiles)
+  if (p.ln_wsum != nullptr) {
+    if constexpr (AMODE == I2V_A_PLAIN) {
+      if (p.epilogue == I2V_EPI_GEGLU)
+        I2V_BIG4_LAUNCH(I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, true);
+      else if (p.store_mode == I2V_STORE_VT_T)
+        I2V_BIG4_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT_T, true);
+      else if (p.store_mode == I2V_STORE_ROWPERM)
+        I2V_BIG4_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWPERM, true);
+      else
+        I2V_BIG4_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true);
+    }
+  } else if (p.epilogue == I2V_EPI_GEGLU) {
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG4_LAUNCH(I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, false);
+  } else if (p.store_mode == I2V_STORE_ROWPERM) {
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG4_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWPERM, false);
+  } else if (p.store_mode == I2V_STORE_VT) {
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG4_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT, false);
+  } else if (p.store_mode == I2V_STORE_VT_T) {
+    if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG4_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT_T, false);
+  } else {
+    I2V_BIG4_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false);
+  }
+#undef I2V_BIG4_LAUNCH
+  const int rc = i2v_check_launch("i2v_gemm_f16(big, 4-wave)");
+  return rc < 0 ? rc : 1;
+}
+
+// Which un-split problems take the 4-wave / two-workgroups-per-CU form: NONE by default.  Measured in round 3 on every
+// GEMM flavour of the step (tools/gemm4_ab.py, same box, profiles/r3_gemm_4wave_ab.txt): 5 - 40 % SLOWER on all of them
+// (131072 x 2560 x 320 GEGLU + LayerNorm 368 -> 386 us, 8192 x 1280 x 5120 + residual 104 -> 145 us, whole step 58.2 ->
+// 64.5 ms).  The overlap of one tile's epilogue with the other's MFMAs does not pay for what the 128 x 320 x 32 tile costs:
+// 91 FLOP per staged byte instead of 146 against a CU's ~70 GB/s LDS-DMA intake, and a barrier every 40 MFMAs per wave.
+// I2V_GEMM_4W=1 selects it for every eligible plain GEMM (kept as a tested A/B switch).
+bool use_4wave(const i2v_gemm_params& p, int plan_rows) {
+  static const int mode = getenv("I2V_GEMM_4W") ? atoi(getenv("I2V_GEMM_4W")) : 0;
+  (void)plan_rows;
+  return mode == 1 && p.a_mode == I2V_A_PLAIN && p.N % BIG_BN == 0 && p.K % 32 == 0;
+}
+
 // 3x3 convolutions whose channel count is not a multiple of 320 (the VAE: 128 / 256 / 512): column tiles of 256 or 128
 template <int BM, int BN>
 int launch_big_conv_bn(const i2v_gemm_params& p, hipStream_t s) {
@@ -1053,6 +1118,7 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   if (bn == 256 && plan == 128) return launch_big_conv_bn<128, 256>(p, s);
   if (bn == 128 && plan == 256) return launch_big_conv_bn<256, 128>(p, s);
   if (bn == 128 && plan == 128) return launch_big_conv_bn<128, 128>(p, s);
+  if ((plan == 256 || plan == 128) && use_4wave(p, plan)) return launch_big4<I2V_A_PLAIN>(p, s);
   if (plan == 256) return launch_big<256>(p, vec4, s);
   if (plan == 128) return launch_big<128>(p, vec4, s);
   if (plan == -1) return launch_split(p, vec4, splits, kps, s);

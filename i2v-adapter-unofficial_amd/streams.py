@@ -19,10 +19,15 @@ import os
 
 import torch
 
-# I2V_STREAMS=0: everything on one stream (same-box A/B, and the instrumented per-kernel timing of bench.py)
-ENABLED = os.environ.get("I2V_STREAMS", "1") != "0"
+# MEASURED (round 3, same box, tools/stream_probe.py and bench.py): a fork / join pair costs ~7 us in a
+# replayed hipGraph on ROCm 7.2.  Two 2048 x 1280 x 1280 GEMMs (32 workgroups each) take 46.8 us back to back and 39.9 us
+# forked; two 8192-row ones 60.5 -> 67.1 us (each fills the chip: nothing to overlap, only the join to pay); eager launches
+# lose everywhere (host-side event traffic).  Whole step: forks at the 16 x 16 and 8 x 8 levels 57.46 -> 57.48 ms, at the
+# 8 x 8 level only 58.24 -> 58.48 ms: the chains that can overlap are too short to pay for their joins.  OFF by default;
+# I2V_STREAMS=1 turns the forks on (the tests run both ways: replay == eager bit for bit either way).
+ENABLED = os.environ.get("I2V_STREAMS", "0") == "1"
 # fork only where one launch cannot fill the chip: token rows of the level (B*F*H*W) at or below this
-MAX_ROWS = int(os.environ.get("I2V_STREAMS_MAX_ROWS", "8192"))
+MAX_ROWS = int(os.environ.get("I2V_STREAMS_MAX_ROWS", "2048"))
 
 _side = {}
 _force_off = [False]

@@ -695,3 +695,16 @@ def test_bad_arguments_raise(dev):
     with pytest.raises(pkg.HipLibraryError):
         k.attention(torch.zeros(8, 12, dtype=torch.float16, device=dev), torch.zeros(8, 12, dtype=torch.float16, device=dev),
                     torch.zeros(1, 12, 8, dtype=torch.float16, device=dev), batch_q=1, lq=8, lk=8, heads=1, head_dim=12)
+
+
+def test_gemm_4wave_two_workgroups_per_cu_variant(dev):
+    """the 4-wave form of the big GEMM kernel (128 x 320 x 32 tiles, two workgroups per CU; gemm_big.hip `NW`) measured
+    slower on every shape of the step and is off by default; with I2V_GEMM_4W=1 (read once per process) every eligible
+    plain GEMM takes it.  The GEMM / LayerNorm-fold / GroupNorm-fold / V^T test set is re-run that way in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "(gemm or fold or project_vt) and not 4wave and not conv"], cwd=root,
+                       env=dict(os.environ, I2V_GEMM_4W="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

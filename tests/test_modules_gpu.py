@@ -297,3 +297,17 @@ def test_pipeline_trajectory_two_samples_with_ip(dev, use_graph):
     assert got.shape == (2, 4, 4, 16, 16) and torch.equal(got[:, 0].cpu(), cond)
     compare(got, ref, rel=REL_TOL_TRAJECTORY, name="DDIM trajectory, 2 samples per call + IP (5 steps)")
     assert (got[0] - got[1]).abs().max().item() > 0.1
+
+
+def test_stream_forks_opt_in_child_process(dev):
+    """I2V_STREAMS=1 (read at import) forks the independent chains of the 8 x 8 level onto a side stream (streams.py):
+    the module, UNet and pipeline tests (oracle parity, eager == hipGraph bit for bit, cached-graph replays) re-run that way
+    in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_modules_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "not opt_in_child"], cwd=root,
+                       env=dict(os.environ, I2V_STREAMS="1", I2V_STREAMS_MAX_ROWS="1000000"), capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
