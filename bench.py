@@ -107,7 +107,10 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev, n_forwards=3):
     orig = oblocks.Attention._sdpa
     oblocks.Attention._sdpa = lambda self, q, k, v: F.scaled_dot_product_attention(q, k, v, scale=self.scale)
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(2, frames, 4, h_lat, h_lat, generator=g).half().float()
+    # the batch the timed step runs: the SAME latents twice (pipe:672 `torch.cat([latents] * 2)`) against the negative and
+    # the positive prompt; the HIP forward takes the same route as the timed step (prefix shared between the halves or not)
+    lat = torch.randn(1, frames, 4, h_lat, h_lat, generator=g).half().float()
+    x = torch.cat([lat, lat])
     ctx = torch.randn(2, 77, 768, generator=g).half().float()
     added = None
     added_d = None
@@ -125,7 +128,9 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev, n_forwards=3):
                 ref = ou(x, t, True, ctx, added_cond_kwargs=added).sample
                 times.append(time.time() - t0)
             dt = sorted(times)[len(times) // 2]
-            got = model(x.to(dev), t.to(dev), True, ctx.to(dev), added_cond_kwargs=added_d).sample.float().cpu()
+            from i2v_adapter_unofficial_amd import pipeline_i2v_adapter as pl
+            got = model(x.to(dev), t.to(dev), True, ctx.to(dev), added_cond_kwargs=added_d,
+                        cross_attention_kwargs={"cfg_shared_prefix": pl.CFG_SHARED}).sample.float().cpu()
     finally:
         oblocks.Attention._sdpa = orig
     err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
@@ -135,7 +140,8 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev, n_forwards=3):
                        f"{os.cpu_count()}-thread host (torch {torch.__version__}); a step is that forward plus "
                        "negligible elementwise work")}
     parity = {"max_abs_err": err, "max_abs_ref": scale, "rel": err / max(scale, 1e-30),
-              "what": "HIP UNet forward vs the fp32 CPU oracle forward timed above (same weights, same inputs)"}
+              "what": ("HIP UNet forward of the CFG batch [latents ; latents] x [negative ; positive prompt], routed as the "
+                       "timed step routes it, vs the fp32 CPU oracle forward timed above (same weights, same inputs)")}
     return base, parity
 
 
@@ -452,6 +458,11 @@ def main():
         ms = elapsed / (len(groups) * args.steps) * 1e3  # one graph replay (B samples' step on one GPU)
         value = sample_steps / elapsed
         step_flops = FLOPS_PER_STEP.get((F, args.size, ip))
+        # FLOPs the step EXECUTES (sum over the instrumented step's launches): below the algorithmic count when the
+        # prompt-independent prefix is computed once for both CFG halves -- rates are quoted on the executed count
+        from i2v_adapter_unofficial_amd import pipeline_i2v_adapter as pl
+        exec_flops = sum(c["flops"] for c in classes.values()) / B if (classes and not args.pairs) else None
+        rate_flops = exec_flops if exec_flops else step_flops
         cfg_name = ("configs[3]: batch of pairs, data-parallel" if args.pairs else
                     "configs[4]" if (F, args.size) == (32, 768) else
                     "configs[0] shape" if (F, args.size) == (8, 256) else
@@ -472,9 +483,11 @@ def main():
                                    f"{n_pairs_total} sample(s) over {world} GPU(s), {B} per graph replay (BASELINE {cfg_name})",
                        "samples_total": n_pairs_total, "samples_per_replay": B, "graph": used_graph, "finite": finite,
                        "unet_forwards_per_cfg_half_per_sec": 2 * value,
+                       "cfg_shared_prefix": bool(pl.CFG_SHARED),
                        "step_tflops": None if step_flops is None else step_flops / 1e12,
-                       "achieved_tflops_per_gpu": None if step_flops is None else
-                       step_flops * sample_steps / elapsed / world / 1e12},
+                       "executed_tflops_per_step": None if exec_flops is None else exec_flops / 1e12,
+                       "achieved_tflops_per_gpu": None if rate_flops is None else
+                       rate_flops * sample_steps / elapsed / world / 1e12},
             "roofline": roof,
             "cpu_baseline": cpu_base,
             "parity": parity,

@@ -145,6 +145,12 @@ class ProjectedTemb:
         off, n = self.slices[resnet]
         return self.all_proj[:, off: off + n]
 
+    def first_half(self):
+        """the rows of the first CFG half of the batch (unet._fwd_tokens, cfg_shared): one row per batch entry -> the first
+        half of them; a single row (the pipeline's step: one timestep for the whole batch) serves either half"""
+        r = self.all_proj.shape[0]
+        return self if r == 1 else ProjectedTemb(self.all_proj[: r // 2], self.slices)
+
 
 GN_FOLD = os.environ.get("I2V_GN_FOLD", "1") != "0"
 GN_FOLD_RATIO = float(os.environ.get("I2V_GN_FOLD_RATIO", "4"))   # fold when activations >= ratio x the weight stack

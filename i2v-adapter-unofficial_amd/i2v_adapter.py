@@ -153,8 +153,11 @@ class I2VAdapterTransformerBlock(HipModule):
         return (self._plan.get((1, M, L, rows_qkq), probe1),
                 self.attn2 is not None and self._plan.get((2, M), probe2), self._plan.get((3, M), probe3))
 
-    def _fwd(self, x, n_img, L, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip):
-        """x [n_img * L, C] tokens; ctx_text [Bc, Lt, Dc] (+ ctx_ip [Bc, Li, Dc]) with n_img % Bc == 0."""
+    def _fwd(self, x, n_img, L, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip, cfg_expand=False):
+        """x [n_img * L, C] tokens; ctx_text [Bc, Lt, Dc] (+ ctx_ip [Bc, Li, Dc]) with n_img % Bc == 0.
+        cfg_expand: x holds ONE of the two identical CFG halves of the batch; the self- / cross-frame attention stage
+        (i2v:444-501, no dependence on the prompt) runs on it once, and the result is duplicated in front of the text
+        cross-attention, where the halves start to differ (returns 2 * n_img images)."""
         p = self.packed()
         c = self.dim
         if enable_cross_frame_attn:
@@ -206,6 +209,8 @@ class I2VAdapterTransformerBlock(HipModule):
             x = K.gemm(o1, p["w_o_dual"], p["b_o_dual"], a2=o2, residual=x)                  # i2v:494,501
         else:
             x = K.gemm(o1, p["w_o1"], p["b_o1"], residual=x)                                 # i2v:501
+        if cfg_expand:
+            x, n_img = K.duplicate_batch(x), 2 * n_img
         if self.attn2 is not None:                                                           # i2v:510-533
             if fold2:
                 wf, ws, cb = p["f_q2"]
@@ -310,12 +315,16 @@ class I2VAdapterTransformer2DModel(HipModule):
                     wi=w16(self.proj_in.weight.reshape(self.inner_dim, self.in_channels)), bi=w16(self.proj_in.bias),
                     wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias))
 
-    def _fwd(self, x, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip):
+    def _fwd(self, x, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip, cfg_expand=False):
+        """cfg_expand: x is one of the two identical CFG halves; the output has both (see the block's _fwd)."""
         p = self.packed()
         n_img, hh, ww, c = x.shape
         t = gn_proj_in(x, p["g"], p["b"], self.groups, 1e-6, p["wi"], p["bi"])             # i2v:218-226
-        for blk in self.transformer_blocks:                                                  # i2v:285-295
-            t = blk._fwd(t, n_img, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip)
+        for j, blk in enumerate(self.transformer_blocks):                                    # i2v:285-295
+            t = blk._fwd(t, n_img, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip,
+                         cfg_expand=cfg_expand and j == 0)
+            if cfg_expand and j == 0:
+                n_img, x = 2 * n_img, K.duplicate_batch(x)                                   # the residual of proj_out
         out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c))                            # i2v:298-314
         return out.view(n_img, hh, ww, c)
 

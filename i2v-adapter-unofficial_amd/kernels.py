@@ -513,6 +513,17 @@ def copy3d(src, dst):
     return dst
 
 
+def duplicate_batch(x):
+    """[x ; x] along the leading dimension (the second CFG half of a tensor computed once for both, unet._fwd_tokens)."""
+    _req(x, "x")
+    x = x.contiguous()
+    rows = x.shape[0]
+    y = torch.empty((2 * rows,) + tuple(x.shape[1:]), dtype=f16, device=x.device)
+    c = x.shape[-1]
+    copy3d(x.view(1, -1, c).expand(2, -1, c), y.view(2, -1, c))
+    return y
+
+
 def first_frame_prior(cond, mask_uniform, noise, sigma, strength, sqrt_alpha, sqrt_one_minus_alpha):
     """latents = sqrt_alpha * (mask * blur3x3_sigma(cond) + (1 - mask) * cond) + sqrt_one_minus_alpha * noise with
     mask = (mask_uniform < strength): the first-frame-similarity prior + add_noise of pipe:647-656 in one kernel.

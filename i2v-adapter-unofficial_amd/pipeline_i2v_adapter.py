@@ -14,6 +14,7 @@ AutoencoderKL (vae.py: pipe:300-320, 626-627) when a `vae` is given; pre / post-
 export are host-side plumbing (image_processor.py).  Out of scope: the CLIP text / image
 encoders -- pass `prompt_embeds`, `negative_prompt_embeds` and optional `image_embeds`.
 """
+import os
 from typing import Optional
 
 import torch
@@ -23,6 +24,11 @@ from ._lib import HipLibraryError
 from .blocks import DDIMScheduler
 from .image_processor import VaeImageProcessor, tensor2vid
 from .unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel
+
+# The two classifier-free-guidance halves of a step's batch are the same latents at the same timestep until the first text
+# cross-attention: that prefix of the UNet is computed once (same numbers bit for bit; I2V_CFG_SHARED=0 computes it twice,
+# as the reference does).
+CFG_SHARED = os.environ.get("I2V_CFG_SHARED", "1") != "0"
 
 f16 = torch.float16
 
@@ -162,8 +168,10 @@ class I2VAdapterPipeline:
         unet = self.unet
         x = K.ddim_prep(st["latents"], st["cond"], unet.packed()["cin_pad"], st["copies"])    # pipe:668-673
         temb = unet._embed_time(st["t_table"], t_index=st["step_idx"])
+        # the CFG halves are copies of one tensor at one timestep (pipe:672-673): what does not depend on the prompt is
+        # computed once (unet._fwd_tokens, cfg_shared)
         y = unet._fwd_tokens(x, temb, True, st.get("ctx_proj") or st["ctx_text"], st["ctx_ip"],
-                             st["num_frames"])                                          # pipe:676-683
+                             st["num_frames"], cfg_shared=CFG_SHARED and st["copies"] == 2)   # pipe:676-683
         K.ddim_cfg_step(st["latents"], y, st["coef"], st["step_idx"], st["guidance"], st["copies"])  # pipe:686-691
 
     def _graph_key(self, st):

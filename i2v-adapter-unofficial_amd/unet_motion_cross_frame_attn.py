@@ -65,12 +65,15 @@ class CrossFrameAttnDownBlockMotion(nn.Module):
                                                          padding=downsample_padding, name="op")])
                              if add_downsample else None)
 
-    def _fwd(self, x, temb_act, enable, ctx_text, ctx_ip, num_frames, additional_residuals=None):
+    def _fwd(self, x, temb_act, enable, ctx_text, ctx_ip, num_frames, additional_residuals=None, cfg_shared=False):
+        """cfg_shared (first down block only, unet._fwd_tokens): x is ONE of the two identical CFG halves; the first resnet
+        and the prompt-independent stage of the first transformer run on it, the outputs carry both halves."""
         states = ()
         n_layers = len(self.resnets)
         for i, (resnet, attn, motion) in enumerate(zip(self.resnets, self.attentions, self.motion_modules)):
-            x = resnet._fwd(x, temb_act)                                              # unet:312
-            x = attn._fwd(x, enable, num_frames, ctx_text, ctx_ip)                    # unet:313-322
+            shared = cfg_shared and i == 0
+            x = resnet._fwd(x, temb_act.first_half() if shared else temb_act)         # unet:312
+            x = attn._fwd(x, enable, num_frames, ctx_text, ctx_ip, cfg_expand=shared)   # unet:313-322
             x = motion._fwd(x, num_frames)                                            # unet:323-326
             if i == n_layers - 1 and additional_residuals is not None:
                 raise NotImplementedError("additional_residuals (ControlNet) are not on the hot path")
@@ -635,18 +638,30 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
             self._temb_packed, self._temb_packed_key = (w, b, slices), key
         return self._temb_packed
 
-    def _fwd_tokens(self, x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames):
+    def _fwd_tokens(self, x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=False):
         """x: model-input tokens [B*F, H, W, cin_pad] fp16; temb [B, 4*C0] fp16 (pre-SiLU); ctx_text [B, Lt, D]
         (+ ctx_ip [B, 4, D]) or a ProjectedContext; returns noise-prediction tokens [B*F, H, W, out_channels]."""
         p = self.packed()
         wt, bt, slices = self._temb_pack()
         # ResnetBlock2D: time_emb_proj(nonlinearity(temb)) of all 22 resnets in one GEMM
         temb_act = ProjectedTemb(K.gemm(K.silu(temb), wt, bt), slices)
+        # cfg_shared: the caller's batch is [unconditional half ; conditional half] of the SAME latents at the SAME timestep
+        # (pipe:672-673 `torch.cat([latents] * 2)`).  Until the first text cross-attention the two halves are the same
+        # numbers -- conv_in, the first resnet, GroupNorm / proj_in and the whole self- + cross-frame attention stage of the
+        # first transformer (two 4096 x 4096 attentions per frame at 512 x 512) -- so they are computed once and duplicated
+        # where the prompt enters.  Same arithmetic per element; the bits are identical whenever the dispatcher picks the same
+        # kernel forms for the half and the full batch (it does at 16 f x 512 x 512), else equal to reduction-order rounding
+        # (tests/test_full_width_gpu.py).
+        cfg_shared = (cfg_shared and x.shape[0] % (2 * num_frames) == 0 and (temb.shape[0] == 1 or temb.shape[0] % 2 == 0) and
+                      isinstance(self.down_blocks[0], CrossFrameAttnDownBlockMotion))
+        if cfg_shared:
+            x = x[: x.shape[0] // 2]
         x = K.conv3x3(x, p["w_in"], p["b_in"])                                          # unet:1359
-        res = (x,)
-        for blk in self.down_blocks:                                                    # unet:1362-1377
+        res = (K.duplicate_batch(x) if cfg_shared else x,)
+        for bi, blk in enumerate(self.down_blocks):                                     # unet:1362-1377
             if getattr(blk, "has_cross_attention", False):
-                x, r = blk._fwd(x, temb_act, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames)
+                x, r = blk._fwd(x, temb_act, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames,
+                                cfg_shared=cfg_shared and bi == 0)
             else:
                 x, r = blk._fwd(x, temb_act, num_frames)
             res += r
@@ -683,7 +698,10 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
                 added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 return_dict: bool = True):
-        """unet:1289-1451.  sample (B, F, C, H, W) -> noise prediction (B, F, C, H, W) in sample's dtype."""
+        """unet:1289-1451.  sample (B, F, C, H, W) -> noise prediction (B, F, C, H, W) in sample's dtype.
+        `cross_attention_kwargs={"cfg_shared_prefix": True}` (an addition; the reference ignores the dict on this path): the
+        caller asserts that sample[B/2:] == sample[:B/2] and that all timesteps are equal -- the classifier-free-guidance
+        batch of pipe:672-673 -- and the prompt-independent prefix of the network is computed once (see _fwd_tokens)."""
         if attention_mask is not None:
             raise NotImplementedError("attention masks are never passed on the hot path (SURVEY 8b)")
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
@@ -713,7 +731,8 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
             ctx_ip = self._project_image_embeds(added_cond_kwargs)
         p = self.packed()
         x = K.nchw_to_tokens(sample.reshape(b * num_frames, c, hh, ww), p["cin_pad"])     # unet:1358
-        y = self._fwd_tokens(x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames)
+        cfg_shared = bool(cross_attention_kwargs and cross_attention_kwargs.get("cfg_shared_prefix", False))
+        y = self._fwd_tokens(x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=cfg_shared)
         out_dt = sample.dtype if sample.dtype in (torch.float32, f16) else f16
         out = K.tokens_to_nchw(y, dtype=out_dt).reshape(b, num_frames, -1, hh, ww)        # unet:1446
         if not return_dict:

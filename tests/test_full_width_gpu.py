@@ -198,6 +198,44 @@ def test_full_size_properties(dev, pair, pair_ip, name, frames, size, ip):
     assert torch.equal(graph, again), f"{name}: same seeds must reproduce the trajectory bit for bit"
 
 
+@pytest.mark.parametrize("ip", [False, True])
+def test_cfg_shared_prefix(dev, pair, pair_ip, ip, monkeypatch):
+    """The step computes the prompt-independent prefix of the UNet (conv_in, the first resnet, the self- / cross-frame
+    attention stage of the first transformer) ONCE for the two CFG halves (pipeline CFG_SHARED; pipe:672-673 duplicates the
+    latents and the reference computes both halves).  The arithmetic per element is the same, but the half batch can be
+    dispatched to other tile forms (another summation order in a GroupNorm partial or a K loop), and a one-ulp difference
+    early in an fp16 network grows to the size of the fp16 path's own error at its output -- so the binding check is the
+    same as for the un-shared path: the fp32 oracle on the CFG-shaped batch, same tolerance.  Eager == replay bit for bit."""
+    import importlib
+    ou, hu = pair_ip if ip else pair
+    inp = _inputs(seed=9)
+    lat = inp["sample"][:1]
+    sample = torch.cat([lat, lat])                                   # pipe:672 `torch.cat([latents] * 2)`
+    added = {"image_embeds": inp["image_embeds"]} if ip else None
+    added_d = {"image_embeds": inp["image_embeds"].to(dev)} if ip else None
+    with torch.no_grad():
+        ref = ou(sample, inp["t"], True, inp["ctx"], added_cond_kwargs=added).sample
+        twice = hu(sample.to(dev), inp["t"].to(dev), True, inp["ctx"].to(dev), added_cond_kwargs=added_d).sample
+        once = hu(sample.to(dev), inp["t"].to(dev), True, inp["ctx"].to(dev), added_cond_kwargs=added_d,
+                  cross_attention_kwargs={"cfg_shared_prefix": True}).sample
+    e2, scale = compare(twice, ref, abs_tol=FWD_ABS_TOL, name=f"CFG batch, prefix computed twice (ip={ip})")
+    e1, _ = compare(once, ref, abs_tol=FWD_ABS_TOL, name=f"CFG batch, prefix computed once (ip={ip})")
+    print(f"CFG-shaped batch vs oracle: prefix twice {e2:.3e}, once {e1:.3e}, once vs twice "
+          f"{(once - twice).abs().max().item():.3e}, max|ref| {scale:.3e}")
+    assert (once[0] - once[1]).abs().max().item() > 10 * FWD_ABS_TOL     # the halves differ once the prompt has entered
+    # the pipeline's step: on / off, eager / replayed
+    pl = importlib.import_module(pkg().I2VAdapterPipeline.__module__)
+    monkeypatch.setattr(pl, "CFG_SHARED", False)
+    p_twice, _ = _pipeline_run(hu, dev, 8, 256, ip, use_graph=False)
+    monkeypatch.setattr(pl, "CFG_SHARED", True)
+    p_once, _ = _pipeline_run(hu, dev, 8, 256, ip, use_graph=False)
+    d = (p_once - p_twice).abs().max().item()
+    print(f"two steps at 8 f x 256^2, prefix once vs twice: max |diff| {d:.3e} at max {p_twice.abs().max().item():.3e}")
+    assert d <= 3e-3 * p_twice.abs().max().item()
+    p_graph, _ = _pipeline_run(hu, dev, 8, 256, ip, use_graph=True)
+    assert torch.equal(p_graph, p_once)
+
+
 def test_config2_full_size_forward_vs_oracle(dev, pair):
     """BASELINE configs[1] at its FULL size: one CFG forward (2, 16, 4, 64, 64) of the SD-1.5-width model against the
     fp32 CPU oracle (~50 s of host time on the GPU box; attention through F.scaled_dot_product_attention, the op the
