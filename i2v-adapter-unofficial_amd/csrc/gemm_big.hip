@@ -644,44 +644,66 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
     const int out_col0 = EPI == I2V_EPI_GEGLU ? (n0 >> 1) + wn * (WNC / 2) : n0 + wn * WNC;
     // One 8-column task of the 16-row block j: (valid, row m, destination row, first column)
     constexpr int QN = (NT + 63) / 64;
-    auto task = [&](int j, int q, int& row, int& c, int& m, int64_t& m_out, int& n) {
+    auto task = [&](int j, int q, int& m, int& m_out, int& n) {
       const int t = lane + 64 * q;
-      row = t / TPR;
-      c = t - row * TPR;
+      const int row = t / TPR, c = t - row * TPR;
       m = m0 + wm * WM + j * 16 + row;
       m_out = m;
       if (STORE == I2V_STORE_ROWPERM) {
         const int per = p.hw * p.frames;
         const int b = m / per, rem = m - b * per;
         const int pix = rem / p.frames, f = rem - pix * p.frames;
-        m_out = (int64_t)(b * p.frames + f) * p.hw + pix;
+        m_out = (b * p.frames + f) * p.hw + pix;
       }
       n = out_col0 + c * 8;
       return t < NT && m < M;
     };
-    // Residual rows are fetched RES_AHEAD blocks ahead of the block being written (the first ones before the barrier
-    // and the bias pass).  Fetched where they are added, each
-    // block paid a full memory round trip before its stores could go out: eight dependent round trips per tile,
-    // 22 us of a 131072 x 320 x 320 tile's 40 (tools/tile_timeline.py) against 4.6 us without a residual.
+    // Every global access of this epilogue is an UNCONDITIONAL raw buffer instruction: a lane with no task (row >= M, the
+    // partial last pass over a block's tasks) carries an out-of-range offset, so the descriptor's range check returns zeros
+    // for its load and drops its store, and an absent operand (no residual, no row vector) is a descriptor of size 0.
+    // Why: with the loads and stores under exec-mask branches (`if (task) ...`) the compiler cannot count how many memory
+    // operations were issued after a given load, and waits s_waitcnt vmcnt(0) before every use -- on CDNA4 vmcnt counts
+    // stores too, so each 8-column task waited for the previous task's STORE to be acknowledged and for the residual
+    // prefetch issued a moment earlier: "stage + store" was 15.7 us of a 131072 x 320 x 320 + residual tile's 35 and 4.7 us
+    // without a residual (tools/tile_timeline.py, round 3).  Straight-line buffer accesses get exact counted waits: the
+    // residual / row-vector rows of block j + RES_AHEAD stay in flight under block j's stores.
+    // (offsets are 32-bit: M * ldc, M * ldr < 2^30 elements, checked by big_plan)
+    constexpr unsigned EOOB = 0x80000000u;
+    // ONE added operand per problem: the residual (out-projections, conv2, proj_out) or the row-vector table (time
+    // embedding, positional table, per-image bias of a folded GroupNorm) -- big_plan sends a problem with both to the
+    // generic kernel -- so one set of prefetch registers serves either (two sets spilled 150-290 registers per lane)
+    const bool has_res = !LNF && EPI != I2V_EPI_GEGLU && resid != nullptr;
+    const bool has_rv = EPI != I2V_EPI_GEGLU && !has_res && rowvec != nullptr;
+    const bool has_add = has_res || has_rv;
+    const int n_out_cols = EPI == I2V_EPI_GEGLU ? N / 2 : N;
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)((((int64_t)M - 1) * p.ldc + n_out_cols) * 2), 0x00020000);
+    const int rv_rows = p.rowvec_period > 0 ? p.rowvec_period : (M - 1) / (p.rows_per_vec > 0 ? p.rows_per_vec : 1) + 1;
+    const int add_ld = has_res ? (int)p.ldr : (int)p.ld_rowvec;
+    const int64_t add_rows = has_res ? M : rv_rows;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(has_res ? resid : has_rv ? rowvec : C), 0,
+                                                        has_add ? (int)(((add_rows - 1) * add_ld + N) * 2) : 0, 0x00020000);
 #ifndef I2V_RES_AHEAD
 #define I2V_RES_AHEAD 3
 #endif
-    constexpr int RES_AHEAD = I2V_RES_AHEAD;
-    f16x8 rpre[MI][QN];
-    auto fetch_resid = [&](auto jc) {
+    // (behind a folded LayerNorm the added operand can only be a small row-vector table that sits in L2: fetched at the top
+    //  of its own block, under the block's LDS transpose, so the accumulator-bound LayerNorm kernels keep their registers)
+    constexpr int RES_AHEAD = LNF ? 0 : I2V_RES_AHEAD;
+    f16x8 xpre[MI][QN];
+    auto fetch_rows = [&](auto jc) {
       constexpr int j = decltype(jc)::value;
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
-        int row, c, m, n;
-        int64_t m_out;
-        rpre[j][q] = zero8();
-        if (task(j, q, row, c, m, m_out, n)) rpre[j][q] = ld_global_16B(resid + m_out * p.ldr + n);
+        int m, m_out, n;
+        const bool ok = task(j, q, m, m_out, n);
+        int xrow = m_out;
+        if (!has_res) xrow = p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : fast_div(m, p.rows_per_vec > 0 ? p.rows_per_vec : 1, inv_rpv);
+        const unsigned off = ok ? (unsigned)((xrow * add_ld + n) * 2) : EOOB;
+        xpre[j][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
       }
     };
     // (no residual behind a folded LayerNorm: those GEMMs feed q / k / v / the feed-forward; i2v_gemm_big_ln_ok refuses it)
-    const bool use_res = !LNF && EPI != I2V_EPI_GEGLU && resid != nullptr;
-    if (use_res) {
-      static_for<(RES_AHEAD < MI ? RES_AHEAD : MI)>([&](auto jc) { fetch_resid(jc); });
+    if (EPI != I2V_EPI_GEGLU) {
+      static_for<(RES_AHEAD < MI ? RES_AHEAD : MI)>([&](auto jc) { fetch_rows(jc); });
     }
     __builtin_amdgcn_s_barrier();                         // every wave has left the K loop: the stages are free
     float* stg = reinterpret_cast<float*>(slab_stage) + wave * (16 * LDS_LD);
@@ -720,8 +742,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
     I2V_STAMP(3);
     static_for<MI>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if constexpr (j + RES_AHEAD < MI) {
-        if (use_res) fetch_resid(std::integral_constant<int, j + RES_AHEAD>{});
+      if constexpr (j + RES_AHEAD < MI && EPI != I2V_EPI_GEGLU) {
+        fetch_rows(std::integral_constant<int, j + RES_AHEAD>{});
       }
       static_for<NI>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -732,31 +754,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
       });
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
-        int row, c, m, n;
-        int64_t m_out;
-        if (task(j, q, row, c, m, m_out, n)) {
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
-          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          if (EPI != I2V_EPI_GEGLU) {
-            if (rowvec) {
-              const int vrow = p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : fast_div(m, p.rows_per_vec, inv_rpv);
-              const f16x8 t8 = ld_global_16B(rowvec + (int64_t)vrow * p.ld_rowvec + n);
+        int m, m_out, n;
+        const bool ok = task(j, q, m, m_out, n);
+        // (a lane without a task re-reads some row of the slab -- row index wrapped into its 16 rows -- and its store is
+        //  dropped by the range check)
+        const int t = lane + 64 * q;
+        const int row = (t / TPR) & 15, c = t - (t / TPR) * TPR;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (EPI != I2V_EPI_GEGLU) {
+          if (has_add) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)t8[e];
-            }
-            if (use_res) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)rpre[j][q][e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= oscale;
+            for (int e = 0; e < 8; ++e) v[e] += (float)xpre[j][q][e];
           }
-          f16x8 o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-          *reinterpret_cast<f16x8*>(C + m_out * p.ldc + n) = o;
+          for (int e = 0; e < 8; ++e) v[e] *= oscale;
         }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+        const unsigned off = ok ? (unsigned)((m_out * (int)p.ldc + n) * 2) : EOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_c, off, 0, 0);
       }
     });
 #if defined(I2V_PROBE) && I2V_PROBE == 5
@@ -831,15 +850,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
 // already hides what the loop hides; what bounds these kernels is the K loop itself (2.3-2.8 us per 64-deep K tile
 // against 1.3 at the clock the chip holds under this load: one 72 KiB stage in flight does not cover the DMA's tail
 // latency, and LDS has no room for a third stage).  Kept as an A/B switch.
+int persist_mode() {   // 0 (default) never, 1 every eligible plain GEMM, 2 only the LayerNorm-folded row-major GEMMs
+  static const int mode = getenv("I2V_GEMM_PERSIST") ? atoi(getenv("I2V_GEMM_PERSIST")) : 0;
+  return mode;
+}
 int persistent_grid(int ntiles) {
   static const int cus = [] {
-    if (!getenv("I2V_GEMM_PERSIST") || atoi(getenv("I2V_GEMM_PERSIST")) == 0) return 0;
+    if (persist_mode() == 0) return 0;
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return 0;
     return n;
   }();
   return (cus > 0 && ntiles > cus) ? cus : ntiles;
+}
+// Round 3, per flavour (tools/gemm4_ab.py under I2V_GEMM_PERSIST=0 / 1 / 2): on one box the walk gained 3 - 14 % on the
+// LayerNorm-folded GEMMs with plain row-major stores (131072 x 960 x 320: 156 -> 134 us) and lost on residual / GEGLU / V^T
+// epilogues; on two other boxes mode 2 (those GEMMs only) measured 155.7 vs 159.2 us on that shape and 54.05 vs 54.09 ms
+// on the whole step -- no reproducible gain, so the default stays 0.
+bool want_persistent(const i2v_gemm_params& p) {
+  const int mode = persist_mode();
+  if (mode == 1) return true;
+  return mode == 2 && p.ln_wsum != nullptr && p.epilogue == I2V_EPI_NONE && p.store_mode == I2V_STORE_ROWMAJOR;
 }
 
 template <int BM, int BK, int NS, int AMODE, bool FAST>
@@ -944,7 +976,7 @@ template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   (void)vec4;
   if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, 64, 2, I2V_A_CONV3X3, false>(p, s);
-  if (p.a2 == nullptr && p.M % BM == 0 && persistent_grid(1 << 20) != (1 << 20))
+  if (p.a2 == nullptr && p.M % BM == 0 && want_persistent(p) && persistent_grid(1 << 20) != (1 << 20))
     return launch_big_mode<BM, 64, 2, I2V_A_PLAIN, true>(p, s);
   return launch_big_mode<BM, 64, 2, I2V_A_PLAIN, false>(p, s);
 }
@@ -1048,6 +1080,13 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
     if (p.rowvec && (p.ld_rowvec % 8 != 0 || !a16(p.rowvec))) return 0;
   }
   if (p.rowvec && p.M >= (1 << 24)) return 0;   // the epilogue's reciprocal division of the row index is exact below 2^24
+  // the row-contiguous epilogue prefetches ONE added operand (residual or row vector) and addresses C and it with 32-bit
+  // byte offsets (buffer ops)
+  if (p.residual && p.rowvec && p.epilogue != I2V_EPI_GEGLU) return 0;
+  const int64_t rv_rows = p.rowvec_period > 0 ? p.rowvec_period : (p.M - 1) / (p.rows_per_vec > 0 ? p.rows_per_vec : 1) + 1;
+  if ((int64_t)p.M * p.ldc >= (1ll << 30) || (p.residual && (int64_t)p.M * p.ldr >= (1ll << 30)) ||
+      (p.rowvec && rv_rows * p.ld_rowvec >= (1ll << 30)))
+    return 0;
   if (p.rows_per_w > 0 || p.a_perm_frames > 0) {
     // per-batch weights / the permuted A gather exist only in the full-tile DMA path of the un-split kernel
     if (p.a_mode != I2V_A_PLAIN || p.a2 != nullptr || p.M % 256 != 0) return 0;
