@@ -550,7 +550,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
     constexpr int LDS_LD = WM + 4;   // floats: 16 rows start on 16 distinct bank groups
     constexpr int TPR = WM / 8, NT = 16 * TPR;
     __builtin_amdgcn_s_barrier();    // every wave has left the K loop: the stages are free
-    float* stg = reinterpret_cast<float*>(slab_stage) + wave * (16 * LDS_LD);
+    // per wave: the [16 channels][WM keys] slab + its WNC bias values (fetched once, read back per task from LDS)
+    float* stg = reinterpret_cast<float*>(slab_stage) + wave * (16 * LDS_LD + WNC);
+    float* bslab = stg + 16 * LDS_LD;
     if (LNF) {
       // LayerNorm fold: accumulator rows are tokens m = .. + 4 g + r, the column is channel n (l15)
       static_for<MI>([&](auto jc) {
@@ -571,37 +573,68 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
         });
       });
     }
+    // Global accesses as unconditional raw buffer instructions (see the row-major epilogue below): per 8-key task the old
+    // form loaded ONE bias value and waited s_waitcnt vmcnt(0) for it -- 20 dependent memory round trips per wave and
+    // tile, each also waiting for the previous task's store.  Now: the wave's bias values are fetched once up front, the
+    // positional-table rows of block i + 1 are in flight under block i, lanes past M carry an out-of-range offset.
+    constexpr unsigned VOOB = 0x80000000u;
+    constexpr int QV = NT / 64;
+    const bool has_pe = rowvec != nullptr;
+    const int64_t vt_rows = (int64_t)(M / p.vt_len) * N;
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(((vt_rows - 1) * p.vt_ld + p.vt_len) * 2), 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(bias ? bias : C), 0, bias ? N * 2 : 0, 0x00020000);
+    const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(has_pe ? rowvec : C), 0,
+                                                        has_pe ? (int)((((int64_t)N - 1) * p.ld_rowvec + p.rowvec_period) * 2) : 0,
+                                                        0x00020000);
+#pragma unroll
+    for (int e0 = 0; e0 < WNC; e0 += 64) {
+      const int e = e0 + lane;
+      const unsigned short raw = __builtin_amdgcn_raw_buffer_load_b16(rs_b, e < WNC ? (unsigned)((n0 + wn * WNC + e) * 2) : VOOB, 0, 0);
+      if (e < WNC) bslab[e] = (float)__builtin_bit_cast(f16, raw);   // (an LDS write under the mask: no memory operation hides in the branch)
+    }
+    f16x8 pev[NI][QV];
+    auto fetch_pe = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+#pragma unroll
+      for (int q = 0; q < QV; ++q) {
+        const int t = lane + 64 * q;
+        const int row = t / TPR, c = t - row * TPR;
+        const int n = n0 + wn * WNC + i * 16 + row;
+        const int m = m0 + wm * WM + c * 8;
+        const unsigned off = m < M ? (unsigned)((n * (int)p.ld_rowvec + (m & (p.rowvec_period - 1))) * 2) : VOOB;
+        pev[i][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_v, off, 0, 0));
+      }
+    };
     static_for<NI>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
+      fetch_pe(ic);     // in flight under this block's LDS transpose (a small table that sits in L2)
       static_for<MI>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         *reinterpret_cast<f32x4*>(stg + l15 * LDS_LD + j * 16 + 4 * g) = acc[i][j];
       });
 #pragma unroll
-      for (int q = 0; q < NT / 64; ++q) {
+      for (int q = 0; q < QV; ++q) {
         const int t = lane + 64 * q;
         const int row = t / TPR, c = t - row * TPR;
         const int n = n0 + wn * WNC + i * 16 + row;
-        const int m = m0 + wm * WM + c * 8;
-        if (m < M) {   // M % 8 == 0 and vt_len % 8 == 0: the 8 keys are in range and in one batch
-          const float bn = bias ? (float)bias[n] : 0.f;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
-          const int bt = m / p.vt_len, kk = m - bt * p.vt_len;
-          float pe[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (rowvec) {   // transposed positional table [N][period]: the 8 keys are 8 consecutive positions
-            const f16x8 t8 = ld_global_16B(rowvec + (int64_t)n * p.ld_rowvec + (m & (p.rowvec_period - 1)));
+        const int m = m0 + wm * WM + c * 8;     // M % 8 == 0 and vt_len % 8 == 0: the 8 keys are in range and in one batch
+        const float bn = bslab[i * 16 + row];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + c * 8 + 4);
+        const int bt = m / p.vt_len, kk = m - bt * p.vt_len;
+        float pe[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (has_pe) {   // transposed positional table [N][period]: the 8 keys are 8 consecutive positions
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pe[e] = (float)t8[e];
-          }
-          f16x8 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = (f16)((lo[e] + bn + pe[e]) * oscale);
-            o[4 + e] = (f16)((hi[e] + bn + pe[4 + e]) * oscale);
-          }
-          *reinterpret_cast<f16x8*>(C + ((int64_t)bt * N + n) * p.vt_ld + kk) = o;
+          for (int e = 0; e < 8; ++e) pe[e] = (float)pev[i][q][e];
         }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (f16)((lo[e] + bn + pe[e]) * oscale);
+          o[4 + e] = (f16)((hi[e] + bn + pe[4 + e]) * oscale);
+        }
+        const unsigned off = m < M ? (unsigned)(((bt * N + n) * (int)p.vt_ld + kk) * 2) : VOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_c, off, 0, 0);
       }
     });
     return;
