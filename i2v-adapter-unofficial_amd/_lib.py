@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # I2V_LIB_PATH selects another build of the same ABI (same-box A/B of two kernels, tools/ab_bench.sh); the in-tree
 # library is never overwritten by tooling
 LIB_PATH = os.environ.get("I2V_LIB_PATH") or os.path.join(_HERE, "libi2v_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
 I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
@@ -56,6 +56,25 @@ class AttnParams(C.Structure):
         ("batch_q", C.c_int32), ("kv_group", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("lq", C.c_int32), ("lk", C.c_int32),
         ("scale", C.c_float), ("accumulate", C.c_int32), ("acc_scale", C.c_float),
+    ]
+
+
+class AttnBwdParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_row_stride", C.c_int64), ("q_batch_stride", C.c_int64),
+        ("qt", C.c_void_p), ("qt_row_stride", C.c_int64), ("qt_batch_stride", C.c_int64),
+        ("k", C.c_void_p), ("k_row_stride", C.c_int64), ("k_batch_stride", C.c_int64),
+        ("kt", C.c_void_p), ("kt_row_stride", C.c_int64), ("kt_batch_stride", C.c_int64),
+        ("v", C.c_void_p), ("v_row_stride", C.c_int64), ("v_batch_stride", C.c_int64),
+        ("dout", C.c_void_p), ("do_row_stride", C.c_int64), ("do_batch_stride", C.c_int64),
+        ("doutt", C.c_void_p), ("dot_row_stride", C.c_int64), ("dot_batch_stride", C.c_int64),
+        ("lse", C.c_void_p), ("delta", C.c_void_p),
+        ("dq", C.c_void_p), ("dq_row_stride", C.c_int64), ("dq_batch_stride", C.c_int64),
+        ("dk", C.c_void_p), ("dk_row_stride", C.c_int64), ("dk_batch_stride", C.c_int64),
+        ("dv", C.c_void_p), ("dv_row_stride", C.c_int64), ("dv_batch_stride", C.c_int64),
+        ("batch_q", C.c_int32), ("kv_group", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+        ("lq", C.c_int32), ("lk", C.c_int32),
+        ("scale", C.c_float),
     ]
 
 
@@ -121,6 +140,15 @@ SIGNATURES = {
     "i2v_gaussian_sample_f32": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_first_frame_prior_f32": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "i2v_attention_lse_f32": (C.c_int, [C.POINTER(AttnParams), _P, _P]),
+    "i2v_attention_bwd_f16": (C.c_int, [C.POINTER(AttnBwdParams), _P]),
+    "i2v_transpose_f16": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_rowdot_heads_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_layernorm_bwd_f16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_float, _P]),
+    "i2v_geglu_bwd_f16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int32, _P]),
+    "i2v_colsum_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
+    "i2v_masked_mse_grad_f16": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
     "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, _P]),
 }

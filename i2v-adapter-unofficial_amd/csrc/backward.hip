@@ -1,0 +1,544 @@
+// Backward kernels of the adapter training step (reference loop src/train_image_to_video.py:839-884, trainable
+// set unet:979-1026 = i2v_adapter.to_q / to_out only): what the backward of one I2VAdapterTransformerBlock needs beside
+// i2v_gemm_f16 (dgrad = the same GEMM over transposed weights, wgrad = the same GEMM over transposed activations):
+//
+//   * flash-attention backward on MFMA, recomputing P from Q, K and the forward's log-sum-exp (never the L x L scores):
+//       dQ   kernel: a wave owns 16 queries, sweeps the keys:   S^T = K Q^T, dP^T = V dO^T (key on the MFMA row, so the
+//                    accumulators ARE the B operand of)           dQ^T += K^T dS^T
+//       dK/dV kernel: a wave owns 16 keys, sweeps the queries of every batch entry that shares them (kv_group: the F
+//                    frames of a clip read the frame-0 K / V, i2v:483-492 -- dK0 / dV0 are summed over the frames here,
+//                    in registers):                              S = Q K^T, dP = dO V^T (query on the MFMA row), then
+//                                                                 dV^T += dO^T P,  dK^T += Q^T dS
+//     two sweeps (7 products instead of 5) buy: no atomics, no cross-workgroup sum, run-to-run identical gradients.
+//     The K^T / Q^T / dO^T operands are channel-major copies ([batch][channel][token], the V^T layout of the forward)
+//     made by i2v_transpose_f16;
+//   * the log-sum-exp of a forward attention (the inference kernel does not keep it), rowsum(dO o O) per head;
+//   * LayerNorm backward (input gradient only: the norms are frozen), GEGLU backward, column sums (bias gradient),
+//     the masked-MSE seed gradient (loss without the first frame, train_image_to_video.py:848-856).
+//
+// MFMA orientation (v_mfma_f32_16x16x32_f16, D = A B): A lane (row = l & 15, k = 8 (l >> 4) + 0..7), B lane
+// (k = 8 (l >> 4) + 0..7, col = l & 15), D lane (row = 4 (l >> 4) + r, col = l & 15).  Rows of a 32-row block are
+// dealt to the two 16-row MFMAs so that D rows 4 g + r of tiles t = 0, 1 are block rows 8 g + 4 t + r: a lane's 8
+// values are block rows 8 g .. 8 g + 7 = one B-operand fragment of the next product, no lane movement (as attention.hip).
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int perm_row(int l15, int t) { return 8 * (l15 >> 2) + 4 * t + (l15 & 3); }
+
+// the fragments of one token row over the (zero-padded) head dim: chunk s holds channels 32 s + 8 g .. + 7
+template <int KS>
+__device__ __forceinline__ void row_frags(f16x8 (&f)[KS], const f16* row_ptr, bool row_ok, int g, int d) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int dd = 32 * s + 8 * g;
+    f[s] = (row_ok && dd < d) ? ld_global_16B(row_ptr + dd) : zero8();
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ f32x4 chain(const f16x8 (&a)[KS], const f16x8 (&b)[KS]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) acc = mfma16x16x32(a[s], b[s], acc);
+  return acc;
+}
+
+__device__ __forceinline__ f16x8 pack8(const float (&lo)[4], const float (&hi)[4]) {
+  f16x8 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    o[r] = (f16)lo[r];
+    o[4 + r] = (f16)hi[r];
+  }
+  return o;
+}
+
+__device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups holding the same column
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------------ log-sum-exp
+// lse[bq][h][q] = log2 sum_j exp2(c s_qj), c = scale log2 e: the statistic the backward recomputes P from.
+template <int KS>
+__global__ __launch_bounds__(256) void attn_lse_kernel(const i2v_attn_params p, const float c, float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, bq = blockIdx.z, bkv = bq / p.kv_group, d = p.head_dim;
+  const int q = blockIdx.x * 64 + wave * 16 + l15;
+  const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
+  const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
+  f16x8 qf[KS];
+  row_frags<KS>(qf, Q + (int64_t)q * p.q_row_stride, q < p.lq, g, d);
+  float m = -INFINITY, l = 0.f;
+  for (int kb = 0; kb < p.lk; kb += 32) {
+    float v[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = kb + perm_row(l15, t);
+      f16x8 kf[KS];
+      row_frags<KS>(kf, Kg + (int64_t)key * p.k_row_stride, key < p.lk, g, d);
+      const f32x4 s = chain<KS>(kf, qf);   // rows = keys kb + 8 g + 4 t + r, column = query l15
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[t][r] = (kb + 8 * g + 4 * t + r < p.lk) ? c * s[r] : -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[0][3])),
+                     fmaxf(fmaxf(v[1][0], v[1][1]), fmaxf(v[1][2], v[1][3])));
+    mx = group_max(mx);
+    const float mn = fmaxf(m, mx);      // finite: every 32-key block holds at least one key < lk
+    float add = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) add += __builtin_amdgcn_exp2f(v[t][r] - mn);
+    l = l * __builtin_amdgcn_exp2f(m - mn) + add;
+    m = mn;
+  }
+  l = group_sum(l);
+  if (g == 0 && q < p.lq) lse[((int64_t)bq * p.heads + h) * p.lq + q] = m + __log2f(l);
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int KS, int DT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const i2v_attn_bwd_params p, const float c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, bq = blockIdx.z, bkv = bq / p.kv_group, d = p.head_dim;
+  const int q = blockIdx.x * 64 + wave * 16 + l15;
+  const bool qok = q < p.lq;
+  const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
+  const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
+  const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
+  const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
+  const f16* KT = reinterpret_cast<const f16*>(p.kt) + (int64_t)bkv * p.kt_batch_stride + (int64_t)h * d * p.kt_row_stride;
+  f16x8 qf[KS], dof[KS];
+  row_frags<KS>(qf, Q + (int64_t)q * p.q_row_stride, qok, g, d);
+  row_frags<KS>(dof, DO + (int64_t)q * p.do_row_stride, qok, g, d);
+  const int64_t stat = ((int64_t)bq * p.heads + h) * p.lq + q;
+  const float lse_q = qok ? p.lse[stat] : 0.f, del_q = qok ? p.delta[stat] : 0.f;
+  f32x4 acc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lk8 = (p.lk + 7) & ~7;     // K^T rows are zero-filled up to the next multiple of 8 keys (i2v_transpose_f16)
+  for (int kb = 0; kb < p.lk; kb += 32) {
+    float ds[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = kb + perm_row(l15, t);
+      f16x8 kf[KS], vf[KS];
+      row_frags<KS>(kf, Kg + (int64_t)key * p.k_row_stride, key < p.lk, g, d);
+      row_frags<KS>(vf, Vg + (int64_t)key * p.v_row_stride, key < p.lk, g, d);
+      const f32x4 s = chain<KS>(kf, qf);     // S^T : rows = keys kb + 8 g + 4 t + r, column = query l15
+      const f32x4 dp = chain<KS>(vf, dof);   // dP^T
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = (kb + 8 * g + 4 * t + r < p.lk) ? __builtin_amdgcn_exp2f(c * s[r] - lse_q) : 0.f;
+        ds[t][r] = pr * (dp[r] - del_q);
+      }
+    }
+    const f16x8 dsb = pack8(ds[0], ds[1]);   // B operand: keys kb + 8 g .. + 7 of query l15
+    const int kcol = kb + 8 * g;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int row = 16 * i + l15;          // channel of the head
+      const f16x8 a = (row < d && kcol < lk8) ? ld_global_16B(KT + (int64_t)row * p.kt_row_stride + kcol) : zero8();
+      acc[i] = mfma16x16x32(a, dsb, acc[i]);   // dQ^T: rows = channels 16 i + 4 g + r, column = query l15
+    }
+  }
+  if (!qok) return;
+  f16* DQ = reinterpret_cast<f16*>(p.dq) + (int64_t)bq * p.dq_batch_stride + (int64_t)q * p.dq_row_stride + h * d;
+#pragma unroll
+  for (int i = 0; i < DT; ++i) {
+    const int dd = 16 * i + 4 * g;
+    if (dd >= d) continue;
+    f16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][r] * p.scale);
+    *reinterpret_cast<f16x4*>(DQ + dd) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <int KS, int DT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_params p, const float c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, bkv = blockIdx.z, d = p.head_dim;
+  const int key = blockIdx.x * 64 + wave * 16 + l15;
+  const bool kok = key < p.lk;
+  const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
+  const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
+  f16x8 kf[KS], vf[KS];
+  row_frags<KS>(kf, Kg + (int64_t)key * p.k_row_stride, kok, g, d);
+  row_frags<KS>(vf, Vg + (int64_t)key * p.v_row_stride, kok, g, d);
+  f32x4 dk[DT], dv[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < p.kv_group; ++f) {           // every batch entry that attends to this K / V
+    const int bq = bkv * p.kv_group + f;
+    const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
+    const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
+    const f16* QT = reinterpret_cast<const f16*>(p.qt) + (int64_t)bq * p.qt_batch_stride + (int64_t)h * d * p.qt_row_stride;
+    const f16* DOT = reinterpret_cast<const f16*>(p.doutt) + (int64_t)bq * p.dot_batch_stride + (int64_t)h * d * p.dot_row_stride;
+    const float* lse = p.lse + ((int64_t)bq * p.heads + h) * p.lq;
+    const float* del = p.delta + ((int64_t)bq * p.heads + h) * p.lq;
+    for (int qb = 0; qb < p.lq; qb += 32) {        // lq % 32 == 0 (checked on the host)
+      float pv[2][4], ds[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qrow = qb + perm_row(l15, t);
+        f16x8 qa[KS], da[KS];
+        row_frags<KS>(qa, Q + (int64_t)qrow * p.q_row_stride, true, g, d);
+        row_frags<KS>(da, DO + (int64_t)qrow * p.do_row_stride, true, g, d);
+        const f32x4 s = chain<KS>(qa, kf);     // S : rows = queries qb + 8 g + 4 t + r, column = key l15
+        const f32x4 dp = chain<KS>(da, vf);    // dP
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse + qb + 8 * g + 4 * t);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del + qb + 8 * g + 4 * t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = kok ? __builtin_amdgcn_exp2f(c * s[r] - l4[r]) : 0.f;
+          pv[t][r] = pr;
+          ds[t][r] = pr * (dp[r] - d4[r]);
+        }
+      }
+      const f16x8 pb = pack8(pv[0], pv[1]), dsb = pack8(ds[0], ds[1]);   // B operands: queries qb + 8 g .. + 7, key l15
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const int row = 16 * i + l15;
+        const f16x8 a1 = row < d ? ld_global_16B(DOT + (int64_t)row * p.dot_row_stride + qb + 8 * g) : zero8();
+        const f16x8 a2 = row < d ? ld_global_16B(QT + (int64_t)row * p.qt_row_stride + qb + 8 * g) : zero8();
+        dv[i] = mfma16x16x32(a1, pb, dv[i]);    // dV^T : rows = channels, column = key l15
+        dk[i] = mfma16x16x32(a2, dsb, dk[i]);   // dK^T
+      }
+    }
+  }
+  if (!kok) return;
+  f16* DK = reinterpret_cast<f16*>(p.dk) + (int64_t)bkv * p.dk_batch_stride + (int64_t)key * p.dk_row_stride + h * d;
+  f16* DV = reinterpret_cast<f16*>(p.dv) + (int64_t)bkv * p.dv_batch_stride + (int64_t)key * p.dv_row_stride + h * d;
+#pragma unroll
+  for (int i = 0; i < DT; ++i) {
+    const int dd = 16 * i + 4 * g;
+    if (dd >= d) continue;
+    f16x4 ok4, ov4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ok4[r] = (f16)(dk[i][r] * p.scale);
+      ov4[r] = (f16)dv[i][r];
+    }
+    *reinterpret_cast<f16x4*>(DK + dd) = ok4;
+    *reinterpret_cast<f16x4*>(DV + dd) = ov4;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// dst[b][c][r] = src[b][r][c]; columns r in [rows, rows8) of dst are zero-filled
+__global__ __launch_bounds__(256) void transpose_kernel(const f16* __restrict__ src, int64_t src_bs, int64_t ld_src,
+                                                        f16* __restrict__ dst, int64_t dst_bs, int64_t ld_dst, int rows,
+                                                        int cols, int rows8) {
+  __shared__ f16 tile[64][66];
+  const int b = blockIdx.z, r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const f16* s = src + (int64_t)b * src_bs;
+  f16* t = dst + (int64_t)b * dst_bs;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, cc = c0 + tx;
+    tile[i][tx] = (r < rows && cc < cols) ? s[(int64_t)r * ld_src + cc] : (f16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int cc = c0 + i, r = r0 + tx;
+    if (cc < cols && r < rows8) t[(int64_t)cc * ld_dst + r] = tile[tx][i];
+  }
+}
+
+// out[(b * heads + h) * L + l] = sum_i a[b][l][h d + i] * bm[b][l][h d + i]
+__global__ __launch_bounds__(256) void rowdot_kernel(const f16* __restrict__ a, int64_t lda, const f16* __restrict__ bm,
+                                                     int64_t ldb, float* __restrict__ out, int64_t rows, int L, int heads,
+                                                     int d) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * heads) return;
+  const int64_t row = idx / heads;
+  const int h = (int)(idx - row * heads);
+  const f16* pa = a + row * lda + h * d;
+  const f16* pb = bm + row * ldb + h * d;
+  float s = 0.f;
+  for (int i = 0; i < d; i += 8) {
+    const f16x8 x = ld_global_16B(pa + i), y = ld_global_16B(pb + i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)y[e];
+  }
+  const int64_t b = row / L, l = row - b * L;
+  out[(b * heads + h) * L + l] = s;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// LayerNorm backward, input gradient only: with xh = (x - mean) rstd and gy = dn o gamma,
+//   dx = rstd (gy - mean(gy) - xh mean(gy o xh))  (+ add: the gradient arriving over the residual path)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const f16* __restrict__ x, int64_t ldx, const f16* __restrict__ dn,
+                                                     int64_t lddn, const f16* __restrict__ gamma, const f16* __restrict__ add,
+                                                     int64_t ldadd, f16* __restrict__ dx, int64_t lddx, int rows, int C,
+                                                     float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f16* xr = x + (int64_t)row * ldx;
+  const f16* dr = dn + (int64_t)row * lddn;
+  const int nvec = C / 8;
+  float s = 0.f;
+  for (int v = lane; v < nvec; v += 64) {
+    const f16x8 a = ld_global_16B(xr + 8 * v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e];
+  }
+  const float mean = wave_sum64(s) / (float)C;
+  float q = 0.f;
+  for (int v = lane; v < nvec; v += 64) {
+    const f16x8 a = ld_global_16B(xr + 8 * v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = (float)a[e] - mean;
+      q += t * t;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum64(q) / (float)C + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (int v = lane; v < nvec; v += 64) {
+    const f16x8 a = ld_global_16B(xr + 8 * v), dd = ld_global_16B(dr + 8 * v), ga = ld_global_16B(gamma + 8 * v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gy = (float)dd[e] * (float)ga[e];
+      s1 += gy;
+      s2 += gy * ((float)a[e] - mean) * rstd;
+    }
+  }
+  s1 = wave_sum64(s1) / (float)C;
+  s2 = wave_sum64(s2) / (float)C;
+  for (int v = lane; v < nvec; v += 64) {
+    const f16x8 a = ld_global_16B(xr + 8 * v), dd = ld_global_16B(dr + 8 * v), ga = ld_global_16B(gamma + 8 * v);
+    f16x8 up = zero8();
+    if (add) up = ld_global_16B(add + (int64_t)row * ldadd + 8 * v);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = ((float)a[e] - mean) * rstd;
+      o[e] = (f16)(rstd * ((float)dd[e] * (float)ga[e] - s1 - xh * s2) + (float)up[e]);
+    }
+    *reinterpret_cast<f16x8*>(dx + (int64_t)row * lddx + 8 * v) = o;
+  }
+}
+
+// GEGLU backward: h [rows][2 inner] interleaved (value_i, gate_i) (the pre-activation of the I2V_EPI_GEGLU GEMM),
+// dy [rows][inner] -> dh[.., 2 i] = dy gelu(g), dh[.., 2 i + 1] = dy a (Phi(g) + g phi(g))
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* __restrict__ hh, int64_t ldh, const f16* __restrict__ dy,
+                                                        int64_t lddy, f16* __restrict__ dh, int64_t lddh, int64_t rows,
+                                                        int inner) {
+  const int nvec = inner / 4;    // 4 outputs = 8 interleaved inputs per thread
+  const int64_t total = rows * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / nvec;
+    const int v = (int)(idx - row * nvec);
+    const f16x8 hv = ld_global_16B(hh + row * ldh + 8 * v);
+    const f16x4 d4 = *reinterpret_cast<const f16x4*>(dy + row * lddy + 4 * v);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = (float)hv[2 * e], gt = (float)hv[2 * e + 1], dd = (float)d4[e];
+      const float phi = 0.5f * (1.0f + erff(gt * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * __expf(-0.5f * gt * gt);
+      o[2 * e] = (f16)(dd * gt * phi);
+      o[2 * e + 1] = (f16)(dd * a * (phi + gt * pdf));
+    }
+    *reinterpret_cast<f16x8*>(dh + row * lddh + 8 * v) = o;
+  }
+}
+
+// out[c] += sum_r x[r][c] (fp32 atomics over row chunks; out is zeroed / accumulated by the caller)
+__global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ x, int64_t ldx, float* __restrict__ out,
+                                                     int64_t rows, int cols, int64_t rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + rl; r < r1; r += 4) s += (float)x[r * ldx + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// g[m][c] = coef (y[m][c] - t[m][c]) for tokens of frames >= 1, 0 for the first frame of every clip
+__global__ __launch_bounds__(256) void mse_grad_kernel(const f16* __restrict__ y, const f16* __restrict__ t,
+                                                       f16* __restrict__ gout, int64_t n_img, int L, int C, int frames,
+                                                       float coef) {
+  const int nvec = C / 8;
+  const int64_t total = n_img * L * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / nvec;
+    const int64_t img = row / L;
+    const bool first = (img % frames) == 0;
+    const f16x8 a = ld_global_16B(y + idx * 8), b = ld_global_16B(t + idx * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = first ? (f16)0.f : (f16)(coef * ((float)a[e] - (float)b[e]));
+    *reinterpret_cast<f16x8*>(gout + idx * 8) = o;
+  }
+}
+
+inline int ew_grid(int64_t n) {
+  const int64_t b = i2v_cdiv(n, 256);
+  return (int)(b < 65535 * 4 ? (b > 0 ? b : 1) : 65535 * 4);
+}
+
+template <int KS, int DT>
+int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
+  const float c = p.scale * LOG2E;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DT>), dim3((unsigned)i2v_cdiv(p.lq, 64), p.heads, p.batch_q), dim3(256), 0, s, p, c);
+  int rc = i2v_check_launch("i2v_attention_bwd_f16(dQ)");
+  if (rc < 0) return rc;
+  if (p.dk != nullptr) {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT>), dim3((unsigned)i2v_cdiv(p.lk, 64), p.heads, p.batch_q / p.kv_group),
+                       dim3(256), 0, s, p, c);
+    rc = i2v_check_launch("i2v_attention_bwd_f16(dK, dV)");
+  }
+  return rc;
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int i2v_attention_lse_f32(const i2v_attn_params* pp, float* lse, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp && lse, "i2v_attention_lse_f32: null argument");
+  const i2v_attn_params& p = *pp;
+  I2V_CHECK_ARG(p.q && p.k, "i2v_attention_lse_f32: null q / k");
+  I2V_CHECK_ARG(p.batch_q > 0 && p.kv_group > 0 && p.batch_q % p.kv_group == 0 && p.heads > 0 && p.lq > 0 && p.lk > 0,
+                "i2v_attention_lse_f32: bad sizes");
+  I2V_CHECK_ARG(p.head_dim > 0 && p.head_dim % 8 == 0 && p.head_dim <= 160, "i2v_attention_lse_f32: head_dim (%d) must be a "
+                "multiple of 8 and <= 160", p.head_dim);
+  I2V_CHECK_ARG(p.q_row_stride % 8 == 0 && p.k_row_stride % 8 == 0 && p.q_batch_stride % 8 == 0 && p.k_batch_stride % 8 == 0 &&
+                    al16(p.q) && al16(p.k), "i2v_attention_lse_f32: q / k strides must be multiples of 8 elements, 16-byte aligned");
+  I2V_CHECK_ARG(p.heads <= 65535 && p.batch_q <= 65535, "i2v_attention_lse_f32: heads / batch_q exceed the grid limits");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)i2v_cdiv(p.lq, 64), p.heads, p.batch_q), block(256);
+  const float c = p.scale * LOG2E;
+  const int ks = (p.head_dim + 31) / 32;
+  if (ks == 1) hipLaunchKernelGGL((attn_lse_kernel<1>), grid, block, 0, s, p, c, lse);
+  else if (ks == 2) hipLaunchKernelGGL((attn_lse_kernel<2>), grid, block, 0, s, p, c, lse);
+  else if (ks == 3) hipLaunchKernelGGL((attn_lse_kernel<3>), grid, block, 0, s, p, c, lse);
+  else if (ks == 4) hipLaunchKernelGGL((attn_lse_kernel<4>), grid, block, 0, s, p, c, lse);
+  else hipLaunchKernelGGL((attn_lse_kernel<5>), grid, block, 0, s, p, c, lse);
+  return i2v_check_launch("i2v_attention_lse_f32");
+}
+
+extern "C" int i2v_attention_bwd_f16(const i2v_attn_bwd_params* pp, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_attention_bwd_f16: null params");
+  const i2v_attn_bwd_params& p = *pp;
+  I2V_CHECK_ARG(p.q && p.k && p.v && p.kt && p.dout && p.lse && p.delta && p.dq, "i2v_attention_bwd_f16: null pointer");
+  I2V_CHECK_ARG(p.batch_q > 0 && p.kv_group > 0 && p.batch_q % p.kv_group == 0 && p.heads > 0 && p.lq > 0 && p.lk > 0,
+                "i2v_attention_bwd_f16: bad sizes");
+  I2V_CHECK_ARG(p.head_dim > 0 && p.head_dim % 8 == 0 && p.head_dim <= 160, "i2v_attention_bwd_f16: head_dim (%d) must be a "
+                "multiple of 8 and <= 160", p.head_dim);
+  I2V_CHECK_ARG(p.heads <= 65535 && p.batch_q <= 65535, "i2v_attention_bwd_f16: heads / batch_q exceed the grid limits");
+  const int lk8 = (p.lk + 7) & ~7;
+  I2V_CHECK_ARG(p.kt_row_stride >= lk8 && p.kt_row_stride % 8 == 0, "i2v_attention_bwd_f16: kt_row_stride must be a multiple "
+                "of 8 and >= lk rounded up to 8 (zero-filled: i2v_transpose_f16)");
+  const int64_t strides[] = {p.q_row_stride, p.q_batch_stride, p.k_row_stride, p.k_batch_stride, p.v_row_stride,
+                             p.v_batch_stride, p.kt_batch_stride, p.do_row_stride, p.do_batch_stride, p.dq_row_stride,
+                             p.dq_batch_stride};
+  for (int64_t st : strides) I2V_CHECK_ARG(st % 8 == 0, "i2v_attention_bwd_f16: strides must be multiples of 8 elements");
+  I2V_CHECK_ARG(al16(p.q) && al16(p.k) && al16(p.v) && al16(p.kt) && al16(p.dout) && al16(p.dq) && al16(p.lse) && al16(p.delta),
+                "i2v_attention_bwd_f16: pointers must be 16-byte aligned");
+  if (p.dk != nullptr) {
+    I2V_CHECK_ARG(p.dv && p.qt && p.doutt, "i2v_attention_bwd_f16: dk needs dv, qt and doutt");
+    I2V_CHECK_ARG(p.lq % 32 == 0, "i2v_attention_bwd_f16: the dK / dV sweep needs lq (%d) %% 32 == 0", p.lq);
+    I2V_CHECK_ARG(p.qt_row_stride >= p.lq && p.qt_row_stride % 8 == 0 && p.dot_row_stride >= p.lq && p.dot_row_stride % 8 == 0 &&
+                      p.qt_batch_stride % 8 == 0 && p.dot_batch_stride % 8 == 0 && p.dk_row_stride % 8 == 0 &&
+                      p.dk_batch_stride % 8 == 0 && p.dv_row_stride % 8 == 0 && p.dv_batch_stride % 8 == 0 && al16(p.qt) &&
+                      al16(p.doutt) && al16(p.dk) && al16(p.dv) && (p.lq % 4 == 0),
+                  "i2v_attention_bwd_f16: Q^T / dO^T / dK / dV strides and alignment");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int d = p.head_dim;
+  if (d <= 32) return launch_bwd<1, 2>(p, s);
+  if (d <= 48) return launch_bwd<2, 3>(p, s);
+  if (d <= 64) return launch_bwd<2, 4>(p, s);
+  if (d <= 80) return launch_bwd<3, 5>(p, s);
+  if (d <= 96) return launch_bwd<3, 6>(p, s);
+  if (d <= 128) return launch_bwd<4, 8>(p, s);
+  return launch_bwd<5, 10>(p, s);
+}
+
+extern "C" int i2v_transpose_f16(const void* src, int64_t src_batch_stride, int64_t ld_src, void* dst,
+                                 int64_t dst_batch_stride, int64_t ld_dst, int32_t batches, int32_t rows, int32_t cols,
+                                 i2v_stream_t stream) {
+  const int rows8 = (rows + 7) & ~7;
+  I2V_CHECK_ARG(src && dst && batches > 0 && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows8 && batches <= 65535,
+                "i2v_transpose_f16: bad arguments (ld_dst must cover rows rounded up to 8)");
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)i2v_cdiv(rows8, 64), (unsigned)i2v_cdiv(cols, 64), batches), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), src_batch_stride, ld_src,
+                     reinterpret_cast<f16*>(dst), dst_batch_stride, ld_dst, rows, cols, rows8);
+  return i2v_check_launch("i2v_transpose_f16");
+}
+
+extern "C" int i2v_rowdot_heads_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows,
+                                    int32_t rows_per_batch, int32_t heads, int32_t head_dim, i2v_stream_t stream) {
+  I2V_CHECK_ARG(a && b && out && rows > 0 && rows_per_batch > 0 && rows % rows_per_batch == 0 && heads > 0 && head_dim > 0 &&
+                    head_dim % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && al16(a) && al16(b),
+                "i2v_rowdot_heads_f32: bad arguments");
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)i2v_cdiv(rows * heads, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(a), lda,
+                     reinterpret_cast<const f16*>(b), ldb, out, rows, rows_per_batch, heads, head_dim);
+  return i2v_check_launch("i2v_rowdot_heads_f32");
+}
+
+extern "C" int i2v_layernorm_bwd_f16(const void* x, int64_t ldx, const void* dn, int64_t lddn, const void* gamma,
+                                     const void* add, int64_t ldadd, void* dx, int64_t lddx, int32_t rows, int32_t C, float eps,
+                                     i2v_stream_t stream) {
+  I2V_CHECK_ARG(x && dn && gamma && dx && rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && lddn % 8 == 0 && lddx % 8 == 0 &&
+                    (!add || ldadd % 8 == 0) && al16(x) && al16(dn) && al16(gamma) && al16(dx) && (!add || al16(add)),
+                "i2v_layernorm_bwd_f16: bad arguments (C and the strides must be multiples of 8, pointers 16-byte aligned)");
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)i2v_cdiv(rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(x), ldx, reinterpret_cast<const f16*>(dn), lddn,
+                     reinterpret_cast<const f16*>(gamma), reinterpret_cast<const f16*>(add), ldadd, reinterpret_cast<f16*>(dx),
+                     lddx, rows, C, eps);
+  return i2v_check_launch("i2v_layernorm_bwd_f16");
+}
+
+extern "C" int i2v_geglu_bwd_f16(const void* h, int64_t ldh, const void* dy, int64_t lddy, void* dh, int64_t lddh, int64_t rows,
+                                 int32_t inner, i2v_stream_t stream) {
+  I2V_CHECK_ARG(h && dy && dh && rows > 0 && inner > 0 && inner % 4 == 0 && ldh % 8 == 0 && lddh % 8 == 0 && lddy % 4 == 0 &&
+                    al16(h) && al16(dh) && (reinterpret_cast<uintptr_t>(dy) & 7) == 0,
+                "i2v_geglu_bwd_f16: bad arguments");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_grid(rows * (inner / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(h), ldh, reinterpret_cast<const f16*>(dy), lddy, reinterpret_cast<f16*>(dh),
+                     lddh, rows, inner);
+  return i2v_check_launch("i2v_geglu_bwd_f16");
+}
+
+extern "C" int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t rows, int32_t cols, i2v_stream_t stream) {
+  I2V_CHECK_ARG(x && out && rows > 0 && cols > 0 && ldx >= cols, "i2v_colsum_f32: bad arguments");
+  const int64_t rpb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)i2v_cdiv(cols, 64), (unsigned)i2v_cdiv(rows, rpb)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(x), ldx, out, rows, cols, rpb);
+  return i2v_check_launch("i2v_colsum_f32");
+}
+
+extern "C" int i2v_masked_mse_grad_f16(const void* y, const void* target, void* grad, int64_t n_img, int32_t tokens,
+                                       int32_t channels, int32_t frames, float coef, i2v_stream_t stream) {
+  I2V_CHECK_ARG(y && target && grad && n_img > 0 && tokens > 0 && channels > 0 && channels % 8 == 0 && frames > 0 &&
+                    n_img % frames == 0 && al16(y) && al16(target) && al16(grad),
+                "i2v_masked_mse_grad_f16: bad arguments");
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(ew_grid(n_img * tokens * (channels / 8))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(y),
+                     reinterpret_cast<const f16*>(target), reinterpret_cast<f16*>(grad), n_img, tokens, channels, frames, coef);
+  return i2v_check_launch("i2v_masked_mse_grad_f16");
+}

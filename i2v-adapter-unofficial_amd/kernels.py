@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (I2V_A_CONV3X3, I2V_A_PLAIN, I2V_EPI_GEGLU, I2V_EPI_GELU, I2V_EPI_NONE, I2V_STORE_ROWMAJOR,
-                   I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T, AttnParams, GemmParams, GnParams,
+                   I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T, AttnBwdParams, AttnParams, GemmParams, GnParams,
                    HipLibraryError, LnParams, TAttnParams)
 
 f16 = torch.float16
@@ -602,3 +602,153 @@ def ddim_cfg_step(latents, noise_pred, coef, step_index, guidance_scale, cfg_cop
                                      _p(step_index), float(guidance_scale), b, f, c, h * w, cfg_copies, _stream()),
                "i2v_ddim_cfg_step")
     return latents
+
+
+# ---------------------------------------------------------------------------------------------- backward (SURVEY 8 f4)
+def transpose_tokens(x, batch_len, out=None):
+    """[B * L, C] token-major -> [B, C, pad8(L)] channel-major (zero-filled pad): the K^T / Q^T / dO^T operands of the
+    attention backward and the operands of a weight gradient (i2v_transpose_f16).  x may be a column slice."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    rows, c = x.shape
+    if rows % batch_len != 0:
+        raise ValueError(f"{rows} rows do not split into batches of {batch_len}")
+    b, lp = rows // batch_len, pad8(batch_len)
+    if out is None:
+        out = torch.empty((b, c, lp), dtype=f16, device=x.device)
+    _req(out, "out")
+    if tuple(out.shape) != (b, c, lp) or not out.is_contiguous():
+        raise ValueError(f"out must be contiguous [{b}, {c}, {lp}]")
+    _lib.check(lib.i2v_transpose_f16(_p(x), batch_len * ldx, ldx, _p(out), c * lp, lp, b, batch_len, c, _stream()),
+               "i2v_transpose_f16")
+    return out
+
+
+def attention_lse(q, k, *, batch_q, lq, lk, heads, head_dim, kv_group=1, scale=None):
+    """fp32 [batch_q, heads, lq] log2-sum-exp of the forward attention over (q, k) (i2v_attention_lse_f32)."""
+    lib = _lib.load()
+    q, ldq = _mat(q, "q")
+    k, ldk = _mat(k, "k")
+    Cc, bkv = heads * head_dim, batch_q // kv_group
+    if q.shape[0] != batch_q * lq or q.shape[1] < Cc or k.shape[0] != bkv * lk or k.shape[1] < Cc:
+        raise ValueError(f"q {tuple(q.shape)} / k {tuple(k.shape)} do not match batch_q {batch_q}, lq {lq}, lk {lk}")
+    lse = torch.empty((batch_q, heads, lq), dtype=torch.float32, device=q.device)
+    p = AttnParams()
+    p.q, p.q_row_stride, p.q_batch_stride = _p(q), ldq, lq * ldq
+    p.k, p.k_row_stride, p.k_batch_stride = _p(k), ldk, lk * ldk
+    p.batch_q, p.kv_group, p.heads, p.head_dim, p.lq, p.lk = batch_q, kv_group, heads, head_dim, lq, lk
+    p.scale = float(head_dim) ** -0.5 if scale is None else scale
+    _lib.check(lib.i2v_attention_lse_f32(C.byref(p), _p(lse), _stream()), "i2v_attention_lse_f32")
+    return lse
+
+
+def rowdot_heads(a, b, *, rows_per_batch, heads, head_dim):
+    """fp32 [batches, heads, rows_per_batch]: sum over each head's channels of a * b (delta = rowsum(dO o O))."""
+    lib = _lib.load()
+    a, lda = _mat(a, "a")
+    b, ldb = _mat(b, "b")
+    rows = a.shape[0]
+    if b.shape[0] != rows or rows % rows_per_batch != 0 or min(a.shape[1], b.shape[1]) < heads * head_dim:
+        raise ValueError("rowdot_heads: shape mismatch")
+    out = torch.empty((rows // rows_per_batch, heads, rows_per_batch), dtype=torch.float32, device=a.device)
+    _lib.check(lib.i2v_rowdot_heads_f32(_p(a), lda, _p(b), ldb, _p(out), rows, rows_per_batch, heads, head_dim, _stream()),
+               "i2v_rowdot_heads_f32")
+    return out
+
+
+def attention_bwd(q, k, v, o, dout, *, batch_q, lq, lk, heads, head_dim, kv_group=1, scale=None, need_dkv=True):
+    """Gradients of softmax(scale q k^T) v with respect to q (and k, v when need_dkv): token-major fp16 matrices in, the
+    channel-major operand copies, the log-sum-exp and delta are made here.  Returns (dq, dk, dv); dk / dv [batch_kv * lk, C]
+    are summed over the kv_group batch entries that share k / v (the frames of a clip for the cross-frame attention)."""
+    lib = _lib.load()
+    q, ldq = _mat(q, "q")
+    k, ldk = _mat(k, "k")
+    v, ldv = _mat(v, "v")
+    o, _ = _mat(o, "o")
+    dout, ldo = _mat(dout, "dout")
+    Cc, bkv = heads * head_dim, batch_q // kv_group
+    sc = float(head_dim) ** -0.5 if scale is None else scale
+    lse = attention_lse(q, k, batch_q=batch_q, lq=lq, lk=lk, heads=heads, head_dim=head_dim, kv_group=kv_group, scale=sc)
+    delta = rowdot_heads(dout, o, rows_per_batch=lq, heads=heads, head_dim=head_dim)
+    kt = transpose_tokens(k[:, :Cc], lk)
+    dq = torch.empty((batch_q * lq, Cc), dtype=f16, device=q.device)
+    p = AttnBwdParams()
+    p.q, p.q_row_stride, p.q_batch_stride = _p(q), ldq, lq * ldq
+    p.k, p.k_row_stride, p.k_batch_stride = _p(k), ldk, lk * ldk
+    p.v, p.v_row_stride, p.v_batch_stride = _p(v), ldv, lk * ldv
+    p.kt, p.kt_row_stride, p.kt_batch_stride = _p(kt), kt.shape[2], Cc * kt.shape[2]
+    p.dout, p.do_row_stride, p.do_batch_stride = _p(dout), ldo, lq * ldo
+    p.lse, p.delta = _p(lse), _p(delta)
+    p.dq, p.dq_row_stride, p.dq_batch_stride = _p(dq), Cc, lq * Cc
+    dk = dv = qt = dot = None
+    if need_dkv:
+        qt, dot = transpose_tokens(q[:, :Cc], lq), transpose_tokens(dout[:, :Cc], lq)
+        dk = torch.empty((bkv * lk, Cc), dtype=f16, device=q.device)
+        dv = torch.empty((bkv * lk, Cc), dtype=f16, device=q.device)
+        p.qt, p.qt_row_stride, p.qt_batch_stride = _p(qt), qt.shape[2], Cc * qt.shape[2]
+        p.doutt, p.dot_row_stride, p.dot_batch_stride = _p(dot), dot.shape[2], Cc * dot.shape[2]
+        p.dk, p.dk_row_stride, p.dk_batch_stride = _p(dk), Cc, lk * Cc
+        p.dv, p.dv_row_stride, p.dv_batch_stride = _p(dv), Cc, lk * Cc
+    p.batch_q, p.kv_group, p.heads, p.head_dim, p.lq, p.lk = batch_q, kv_group, heads, head_dim, lq, lk
+    p.scale = sc
+    _lib.check(lib.i2v_attention_bwd_f16(C.byref(p), _stream()), "i2v_attention_bwd_f16")
+    return dq, dk, dv
+
+
+def layernorm_bwd(x, dn, gamma, eps, add=None):
+    """input gradient of LayerNorm (frozen affine): dx = LN'(x)[dn o gamma] (+ add, the residual path's gradient)."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    dn, lddn = _mat(dn, "dn")
+    _req(gamma, "gamma")
+    rows, c = x.shape
+    if tuple(dn.shape) != (rows, c) or gamma.numel() != c:
+        raise ValueError("layernorm_bwd: shape mismatch")
+    lda = 0
+    if add is not None:
+        add, lda = _mat(add, "add")
+        if tuple(add.shape) != (rows, c):
+            raise ValueError("layernorm_bwd: add shape mismatch")
+    dx = torch.empty((rows, c), dtype=f16, device=x.device)
+    _lib.check(lib.i2v_layernorm_bwd_f16(_p(x), ldx, _p(dn), lddn, _p(gamma.contiguous()), _p(add), lda, _p(dx), c, rows, c,
+                                         float(eps), _stream()), "i2v_layernorm_bwd_f16")
+    return dx
+
+
+def geglu_bwd(h, dy):
+    """h [rows, 2 inner] interleaved (value, gate) pre-activation, dy [rows, inner] -> dh [rows, 2 inner] (same order)."""
+    lib = _lib.load()
+    h, ldh = _mat(h, "h")
+    dy, lddy = _mat(dy, "dy")
+    rows, two_inner = h.shape
+    if dy.shape[0] != rows or dy.shape[1] * 2 != two_inner:
+        raise ValueError("geglu_bwd: shape mismatch")
+    dh = torch.empty((rows, two_inner), dtype=f16, device=h.device)
+    _lib.check(lib.i2v_geglu_bwd_f16(_p(h), ldh, _p(dy), lddy, _p(dh), two_inner, rows, two_inner // 2, _stream()),
+               "i2v_geglu_bwd_f16")
+    return dh
+
+
+def colsum(x, out=None):
+    """fp32 [cols] += sum over the rows of fp16 x (bias gradient)."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    if out is None:
+        out = torch.zeros((x.shape[1],), dtype=torch.float32, device=x.device)
+    _req(out, "out", dtype=torch.float32)
+    _lib.check(lib.i2v_colsum_f32(_p(x), ldx, _p(out), x.shape[0], x.shape[1], _stream()), "i2v_colsum_f32")
+    return out
+
+
+def masked_mse_grad(y, target, frames, coef):
+    """seed gradient of the training loss (train_image_to_video.py:848-856): coef * (y - target) on the tokens of every
+    frame but the first of each clip, 0 there.  y, target fp16 [n_img, tokens, C] contiguous."""
+    lib = _lib.load()
+    _req(y, "y")
+    _req(target, "target")
+    if y.dim() != 3 or y.shape != target.shape or not y.is_contiguous() or not target.is_contiguous():
+        raise ValueError("masked_mse_grad: y / target must be equal-shape contiguous [n_img, tokens, C]")
+    g = torch.empty_like(y)
+    _lib.check(lib.i2v_masked_mse_grad_f16(_p(y), _p(target), _p(g), y.shape[0], y.shape[1], y.shape[2], frames, float(coef),
+                                           _stream()), "i2v_masked_mse_grad_f16")
+    return g

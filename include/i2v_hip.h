@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 4
+#define I2V_ABI_VERSION 5
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -308,6 +308,75 @@ int i2v_first_frame_prior_f32(const float* cond, const float* mask_uniform, cons
  * eps / out fp32 [n, c, hw]. */
 int i2v_gaussian_sample_f32(const float* moments, const float* eps, float* out, int32_t n, int32_t c, int32_t hw,
                             i2v_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward kernels of the adapter training step.  The reference trains only
+ * i2v_adapter.to_q / to_out (unet:979-1026) through the whole frozen UNet with torch autograd
+ * (src/train_image_to_video.py:839-884: forward with enable_cross_frame_attn, MSE without the first frame :848-856,
+ * backward, clip, step); these entry points replace the aten backward kernels that autograd dispatches for one
+ * I2VAdapterTransformerBlock (i2v:420-565): SDPA backward, native_layer_norm_backward, the GEGLU chunk / gelu backward,
+ * bias-gradient sums, mse_loss backward.  Linear dgrad / wgrad are i2v_gemm_f16 over transposed weights / activations.
+ * Gradients are fp16 (scaled by the caller's loss scale) except the fp32 statistics and the fp32 bias gradient.
+ * ------------------------------------------------------------------------------------------------ */
+/* lse[bq][h][l] = log2 sum_j exp2(scale * log2(e) * Q[bq, l, h, :] . K[bq / kv_group, j, h, :]), fp32
+ * [batch_q, heads, lq]: the softmax statistic of the forward attention described by p (p->vt, p->o, accumulate are
+ * ignored).  The backward recomputes P from it instead of storing the lq x lk scores. */
+int i2v_attention_lse_f32(const i2v_attn_params* p, float* lse, i2v_stream_t stream);
+
+/* Flash-attention backward (aten _scaled_dot_product_*_attention_backward behind i2v:468-473, 483-492, 527-532):
+ *   P = exp2(scale log2e Q K^T - lse),  dP = dO V^T,  dS = P o (dP - delta),  delta[bq][h][l] = sum_i dO o O
+ *   dQ = scale dS K          (one sweep over the keys per 16-query wave)
+ *   dK = scale dS^T Q,  dV = P^T dO  summed over the kv_group batch entries that share K / V (the F frames of a clip for
+ *                        the cross-frame adapter attention: dK0 / dV0), one sweep over the queries per 16-key wave.
+ * q, k, v, dout, dq, dk, dv are token-major [batch][token][heads * head_dim] views (row / batch strides in elements);
+ * qt, kt, doutt are channel-major copies [batch][heads * head_dim][token] (i2v_transpose_f16; rows zero-filled up to the
+ * next multiple of 8 tokens).  dk = NULL skips the dK / dV sweep (frozen context K / V of the text cross-attention); qt,
+ * doutt, dv are then unused.  That sweep needs lq % 32 == 0; the dQ sweep takes any lq, lk.  No atomics: gradients are
+ * run-to-run identical. */
+typedef struct i2v_attn_bwd_params {
+  const void* q;     int64_t q_row_stride, q_batch_stride;
+  const void* qt;    int64_t qt_row_stride, qt_batch_stride;
+  const void* k;     int64_t k_row_stride, k_batch_stride;
+  const void* kt;    int64_t kt_row_stride, kt_batch_stride;
+  const void* v;     int64_t v_row_stride, v_batch_stride;
+  const void* dout;  int64_t do_row_stride, do_batch_stride;
+  const void* doutt; int64_t dot_row_stride, dot_batch_stride;
+  const float* lse;   /* [batch_q, heads, lq] from i2v_attention_lse_f32 */
+  const float* delta; /* [batch_q, heads, lq] from i2v_rowdot_heads_f32(dO, O) */
+  void* dq;          int64_t dq_row_stride, dq_batch_stride;
+  void* dk;          int64_t dk_row_stride, dk_batch_stride;
+  void* dv;          int64_t dv_row_stride, dv_batch_stride;
+  int32_t batch_q, kv_group, heads, head_dim, lq, lk;
+  float scale;
+} i2v_attn_bwd_params;
+int i2v_attention_bwd_f16(const i2v_attn_bwd_params* p, i2v_stream_t stream);
+
+/* dst[b][c][r] = src[b][r][c] for r < rows, c < cols (fp16; strides in elements); dst columns [rows, rows rounded up to 8)
+ * are zero-filled (ld_dst must cover them).  Channel-major copies of token-major activations: the K^T / Q^T / dO^T
+ * operands of i2v_attention_bwd_f16 and the operands of a weight gradient dW = dY^T X as i2v_gemm_f16(a = dY^T, w = X^T). */
+int i2v_transpose_f16(const void* src, int64_t src_batch_stride, int64_t ld_src, void* dst, int64_t dst_batch_stride,
+                      int64_t ld_dst, int32_t batches, int32_t rows, int32_t cols, i2v_stream_t stream);
+/* out[(b * heads + h) * rows_per_batch + l] = sum_i a[b * rows_per_batch + l][h * head_dim + i] * b[..][..], fp32:
+ * delta = rowsum(dO o O) per head. */
+int i2v_rowdot_heads_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows,
+                         int32_t rows_per_batch, int32_t heads, int32_t head_dim, i2v_stream_t stream);
+/* LayerNorm backward, input gradient only (the norms are frozen; native_layer_norm_backward behind i2v:445, 514, 539):
+ * dx[r] = rstd (gy - mean(gy) - xh mean(gy o xh)) + add[r], gy = dn o gamma, xh = (x - mean) rstd; add (the gradient
+ * arriving over the residual path) may be NULL. */
+int i2v_layernorm_bwd_f16(const void* x, int64_t ldx, const void* dn, int64_t lddn, const void* gamma, const void* add,
+                          int64_t ldadd, void* dx, int64_t lddx, int32_t rows, int32_t C, float eps, i2v_stream_t stream);
+/* GEGLU backward (i2v:554): h [rows, 2 inner] is the pre-activation in the interleaved (value_i, gate_i) column order of
+ * I2V_EPI_GEGLU, dy [rows, inner] -> dh[.., 2i] = dy gelu(gate), dh[.., 2i + 1] = dy value gelu'(gate). */
+int i2v_geglu_bwd_f16(const void* h, int64_t ldh, const void* dy, int64_t lddy, void* dh, int64_t lddh, int64_t rows,
+                      int32_t inner, i2v_stream_t stream);
+/* out[c] += sum_r x[r][c], fp32 (the bias gradient of a Linear; the caller zeroes out before the first call). */
+int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t rows, int32_t cols, i2v_stream_t stream);
+/* Seed gradient of the training loss (train_image_to_video.py:848-856: MSE summed over every frame but the first of each
+ * clip, divided by the number of unmasked elements): grad[img][l][c] = coef (y - target) for img % frames != 0, else 0;
+ * coef = 2 * loss_scale / count is the caller's.  y, target, grad fp16 [n_img, tokens, channels]. */
+int i2v_masked_mse_grad_f16(const void* y, const void* target, void* grad, int64_t n_img, int32_t tokens, int32_t channels,
+                            int32_t frames, float coef, i2v_stream_t stream);
 
 #ifdef __cplusplus
 }
