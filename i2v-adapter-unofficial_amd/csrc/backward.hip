@@ -186,31 +186,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_pa
     const f16* DOT = reinterpret_cast<const f16*>(p.doutt) + (int64_t)bq * p.dot_batch_stride + (int64_t)h * d * p.dot_row_stride;
     const float* lse = p.lse + ((int64_t)bq * p.heads + h) * p.lq;
     const float* del = p.delta + ((int64_t)bq * p.heads + h) * p.lq;
-    for (int qb = 0; qb < p.lq; qb += 32) {        // lq % 32 == 0 (checked on the host)
+    const int lq8 = (p.lq + 7) & ~7;                // Q^T / dO^T rows are zero-filled up to the next multiple of 8 queries
+    for (int qb = 0; qb < p.lq; qb += 32) {
       float pv[2][4], ds[2][4];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int qrow = qb + perm_row(l15, t);
         f16x8 qa[KS], da[KS];
-        row_frags<KS>(qa, Q + (int64_t)qrow * p.q_row_stride, true, g, d);
-        row_frags<KS>(da, DO + (int64_t)qrow * p.do_row_stride, true, g, d);
+        row_frags<KS>(qa, Q + (int64_t)qrow * p.q_row_stride, qrow < p.lq, g, d);
+        row_frags<KS>(da, DO + (int64_t)qrow * p.do_row_stride, qrow < p.lq, g, d);
         const f32x4 s = chain<KS>(qa, kf);     // S : rows = queries qb + 8 g + 4 t + r, column = key l15
         const f32x4 dp = chain<KS>(da, vf);    // dP
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse + qb + 8 * g + 4 * t);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del + qb + 8 * g + 4 * t);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = kok ? __builtin_amdgcn_exp2f(c * s[r] - l4[r]) : 0.f;
+          const int qi = qb + 8 * g + 4 * t + r;
+          const bool ok = kok && qi < p.lq;      // (short sequences: the frames of one pixel in the motion modules)
+          const float pr = ok ? __builtin_amdgcn_exp2f(c * s[r] - lse[qi < p.lq ? qi : 0]) : 0.f;
           pv[t][r] = pr;
-          ds[t][r] = pr * (dp[r] - d4[r]);
+          ds[t][r] = ok ? pr * (dp[r] - del[qi < p.lq ? qi : 0]) : 0.f;
         }
       }
       const f16x8 pb = pack8(pv[0], pv[1]), dsb = pack8(ds[0], ds[1]);   // B operands: queries qb + 8 g .. + 7, key l15
+      const int qcol = qb + 8 * g;
 #pragma unroll
       for (int i = 0; i < DT; ++i) {
         const int row = 16 * i + l15;
-        const f16x8 a1 = row < d ? ld_global_16B(DOT + (int64_t)row * p.dot_row_stride + qb + 8 * g) : zero8();
-        const f16x8 a2 = row < d ? ld_global_16B(QT + (int64_t)row * p.qt_row_stride + qb + 8 * g) : zero8();
+        const bool in = row < d && qcol < lq8;
+        const f16x8 a1 = in ? ld_global_16B(DOT + (int64_t)row * p.dot_row_stride + qcol) : zero8();
+        const f16x8 a2 = in ? ld_global_16B(QT + (int64_t)row * p.qt_row_stride + qcol) : zero8();
         dv[i] = mfma16x16x32(a1, pb, dv[i]);    // dV^T : rows = channels, column = key l15
         dk[i] = mfma16x16x32(a2, dsb, dk[i]);   // dK^T
       }
@@ -393,6 +396,86 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const f16* __restrict__ y
   }
 }
 
+// out = a + b (gradients meeting at a skip connection / a residual branch)
+__global__ __launch_bounds__(256) void add_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ out,
+                                                  int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const f16x8 x = ld_global_16B(a + 8 * i), y = ld_global_16B(b + 8 * i);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)x[e] + (float)y[e]);
+    *reinterpret_cast<f16x8*>(out + 8 * i) = o;
+  }
+}
+
+// rows (b, f, p) <-> (b, p, f): to_pixel_major = 1 reads row (b f + f') hw + p and writes row (b hw + p) F + f'
+__global__ __launch_bounds__(256) void permute_rows_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int64_t batches,
+                                                           int frames, int hw, int C, int to_pixel_major) {
+  const int nvec = C / 8;
+  const int64_t total = batches * frames * hw * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int v = (int)(idx % nvec);
+    const int64_t row = idx / nvec;                       // destination row
+    const int64_t per = (int64_t)frames * hw, b = row / per, rem = row - b * per;
+    int64_t srow;
+    if (to_pixel_major) {
+      const int64_t p = rem / frames, f = rem - p * frames;
+      srow = b * per + f * hw + p;
+    } else {
+      const int64_t f = rem / hw, p = rem - f * hw;
+      srow = b * per + p * frames + f;
+    }
+    *reinterpret_cast<f16x8*>(dst + row * C + 8 * v) = ld_global_16B(src + srow * C + 8 * v);
+  }
+}
+
+// dst [n, 2h, 2w, C]: dst[2y][2x] = src[y][x], zero elsewhere (the input-gradient of a stride-2 convolution is the
+// stride-1 convolution of this with the flipped, transposed weights)
+__global__ __launch_bounds__(256) void zero_insert_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int64_t n, int h,
+                                                          int w, int C) {
+  const int nvec = C / 8;
+  const int64_t total = n * (2 * h) * (2 * w) * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int v = (int)(idx % nvec);
+    int64_t r = idx / nvec;
+    const int xx = (int)(r % (2 * w));
+    r /= 2 * w;
+    const int yy = (int)(r % (2 * h));
+    const int64_t img = r / (2 * h);
+    f16x8 o = zero8();
+    if (((xx | yy) & 1) == 0) o = ld_global_16B(src + ((img * h + (yy >> 1)) * w + (xx >> 1)) * C + 8 * v);
+    *reinterpret_cast<f16x8*>(dst + idx * 8) = o;
+  }
+}
+
+// dst [n, h, w, C] = sum of the 2 x 2 blocks of src [n, 2h, 2w, C] (input-gradient of the nearest-2x upsampling)
+__global__ __launch_bounds__(256) void sum_pool_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int64_t n, int h, int w,
+                                                       int C) {
+  const int nvec = C / 8;
+  const int64_t total = n * h * w * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int v = (int)(idx % nvec);
+    int64_t r = idx / nvec;
+    const int xx = (int)(r % w);
+    r /= w;
+    const int yy = (int)(r % h);
+    const int64_t img = r / h;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const f16x8 t = ld_global_16B(src + ((img * 2 * h + 2 * yy + dy) * (2 * w) + 2 * xx + dx) * C + 8 * v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)t[e];
+      }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)acc[e];
+    *reinterpret_cast<f16x8*>(dst + idx * 8) = o;
+  }
+}
+
 inline int ew_grid(int64_t n) {
   const int64_t b = i2v_cdiv(n, 256);
   return (int)(b < 65535 * 4 ? (b > 0 ? b : 1) : 65535 * 4);
@@ -459,11 +542,11 @@ extern "C" int i2v_attention_bwd_f16(const i2v_attn_bwd_params* pp, i2v_stream_t
                 "i2v_attention_bwd_f16: pointers must be 16-byte aligned");
   if (p.dk != nullptr) {
     I2V_CHECK_ARG(p.dv && p.qt && p.doutt, "i2v_attention_bwd_f16: dk needs dv, qt and doutt");
-    I2V_CHECK_ARG(p.lq % 32 == 0, "i2v_attention_bwd_f16: the dK / dV sweep needs lq (%d) %% 32 == 0", p.lq);
-    I2V_CHECK_ARG(p.qt_row_stride >= p.lq && p.qt_row_stride % 8 == 0 && p.dot_row_stride >= p.lq && p.dot_row_stride % 8 == 0 &&
+    const int lq8 = (p.lq + 7) & ~7;
+    I2V_CHECK_ARG(p.qt_row_stride >= lq8 && p.qt_row_stride % 8 == 0 && p.dot_row_stride >= lq8 && p.dot_row_stride % 8 == 0 &&
                       p.qt_batch_stride % 8 == 0 && p.dot_batch_stride % 8 == 0 && p.dk_row_stride % 8 == 0 &&
                       p.dk_batch_stride % 8 == 0 && p.dv_row_stride % 8 == 0 && p.dv_batch_stride % 8 == 0 && al16(p.qt) &&
-                      al16(p.doutt) && al16(p.dk) && al16(p.dv) && (p.lq % 4 == 0),
+                      al16(p.doutt) && al16(p.dk) && al16(p.dv),
                   "i2v_attention_bwd_f16: Q^T / dO^T / dK / dV strides and alignment");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -541,4 +624,41 @@ extern "C" int i2v_masked_mse_grad_f16(const void* y, const void* target, void* 
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(y),
                      reinterpret_cast<const f16*>(target), reinterpret_cast<f16*>(grad), n_img, tokens, channels, frames, coef);
   return i2v_check_launch("i2v_masked_mse_grad_f16");
+}
+
+extern "C" int i2v_add_f16(const void* a, const void* b, void* out, int64_t n, i2v_stream_t stream) {
+  I2V_CHECK_ARG(a && b && out && n > 0 && n % 8 == 0 && al16(a) && al16(b) && al16(out), "i2v_add_f16: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(a), reinterpret_cast<const f16*>(b), reinterpret_cast<f16*>(out), n / 8);
+  return i2v_check_launch("i2v_add_f16");
+}
+
+extern "C" int i2v_permute_rows_f16(const void* src, void* dst, int64_t batches, int32_t frames, int32_t hw, int32_t channels,
+                                    int32_t to_pixel_major, i2v_stream_t stream) {
+  I2V_CHECK_ARG(src && dst && src != dst && batches > 0 && frames > 0 && hw > 0 && channels > 0 && channels % 8 == 0 &&
+                    al16(src) && al16(dst), "i2v_permute_rows_f16: bad arguments");
+  hipLaunchKernelGGL(permute_rows_kernel, dim3(ew_grid(batches * frames * hw * (channels / 8))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), reinterpret_cast<f16*>(dst),
+                     batches, frames, hw, channels, to_pixel_major);
+  return i2v_check_launch("i2v_permute_rows_f16");
+}
+
+extern "C" int i2v_zero_insert2x_f16(const void* src, void* dst, int64_t n_img, int32_t h, int32_t w, int32_t channels,
+                                     i2v_stream_t stream) {
+  I2V_CHECK_ARG(src && dst && n_img > 0 && h > 0 && w > 0 && channels > 0 && channels % 8 == 0 && al16(src) && al16(dst),
+                "i2v_zero_insert2x_f16: bad arguments");
+  hipLaunchKernelGGL(zero_insert_kernel, dim3(ew_grid(n_img * 4 * h * w * (channels / 8))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), reinterpret_cast<f16*>(dst), n_img, h,
+                     w, channels);
+  return i2v_check_launch("i2v_zero_insert2x_f16");
+}
+
+extern "C" int i2v_sum_pool2x_f16(const void* src, void* dst, int64_t n_img, int32_t h, int32_t w, int32_t channels,
+                                  i2v_stream_t stream) {
+  I2V_CHECK_ARG(src && dst && n_img > 0 && h > 0 && w > 0 && channels > 0 && channels % 8 == 0 && al16(src) && al16(dst),
+                "i2v_sum_pool2x_f16: bad arguments");
+  hipLaunchKernelGGL(sum_pool_kernel, dim3(ew_grid(n_img * h * w * (channels / 8))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), reinterpret_cast<f16*>(dst), n_img, h,
+                     w, channels);
+  return i2v_check_launch("i2v_sum_pool2x_f16");
 }

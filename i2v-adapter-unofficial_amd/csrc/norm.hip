@@ -204,6 +204,179 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   }
 }
 
+// ---------------------------------------------------------------------------------------------- GroupNorm backward
+// Input gradient of y = silu?(xh gamma + beta), xh = (x - mu) rstd over a statistics group of n elements (the norms are
+// frozen in the adapter training step): with dz = dy silu'(z), g = dz gamma, S1 = sum g, S2 = sum g xh,
+//   dx = rstd (g - S1 / n - xh S2 / n) = dz P_c + x Q + R,   P_c = gamma_c rstd, Q = -rstd^2 S2 / n, R = -rstd S1 / n - mu Q.
+// pass 1 (this kernel): per (image, row-chunk, channel) sums A = sum dz and B = sum dz (x - k), k = the channel's value in
+// the chunk's first row (the same shift as the forward statistics: sum dz (x - mu) = B + (k - mu) A has no cancellation
+// against a large channel mean); z = x a + b from the forward's per-(image, channel) coefficients.
+__device__ __forceinline__ float silu_grad(float z) {
+  const float sg = 1.0f / (1.0f + __expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
+                                                             int c2, const f16* __restrict__ dy, const float* __restrict__ coef,
+                                                             int hw, int rpc, int silu, float* __restrict__ partial) {
+  __shared__ float red[256 * 16];
+  const int C = c1 + c2, nvec = C / 8;
+  const int chunk = blockIdx.x, img = blockIdx.y, nchunk = gridDim.x;
+  const int row_begin = chunk * rpc, row_end = min(hw, row_begin + rpc);
+  const int tid = threadIdx.x;
+  const int cols_per_pass = nvec < 256 ? nvec : 256;
+  const int rows_par = 256 / cols_per_pass;
+  const int col_lane = tid % cols_per_pass, row_lane = tid / cols_per_pass;
+  const bool active = row_lane < rows_par;
+  const int nv1 = c1 / 8;
+  for (int col0 = 0; col0 < nvec; col0 += cols_per_pass) {
+    const int col = col0 + col_lane;
+    float sa[8], sb[8], kshift[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sa[e] = sb[e] = kshift[e] = 0.f;
+    if (active && col < nvec) {
+      const f16* base;
+      int64_t ld;
+      int coff;
+      if (col < nv1) {
+        base = x1 + (int64_t)img * hw * c1;
+        ld = c1;
+        coff = col * 8;
+      } else {
+        base = x2 + (int64_t)img * hw * c2;
+        ld = c2;
+        coff = (col - nv1) * 8;
+      }
+      const f16x8 k8 = ld_global_16B(base + (int64_t)row_begin * ld + coff);
+      float ca[8], cb[8];
+      const float4* cf = reinterpret_cast<const float4*>(coef + ((int64_t)img * C + col * 8) * 2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 ab = cf[e];
+        ca[2 * e] = ab.x;
+        cb[2 * e] = ab.y;
+        ca[2 * e + 1] = ab.z;
+        cb[2 * e + 1] = ab.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kshift[e] = (float)k8[e];
+      for (int r = row_begin + row_lane; r < row_end; r += rows_par) {
+        const f16x8 v = ld_global_16B(base + (int64_t)r * ld + coff);
+        const f16x8 g = ld_global_16B(dy + ((int64_t)img * hw + r) * C + col * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = (float)v[e];
+          float dz = (float)g[e];
+          if (silu) dz *= silu_grad(xv * ca[e] + cb[e]);
+          sa[e] += dz;
+          sb[e] += dz * (xv - kshift[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[tid * 16 + e] = sa[e];
+      red[tid * 16 + 8 + e] = sb[e];
+    }
+    __syncthreads();
+    if (row_lane == 0 && col < nvec) {
+      for (int rl = 1; rl < rows_par; ++rl) {
+        const int o = (rl * cols_per_pass + col_lane) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sa[e] += red[o + e];
+          sb[e] += red[o + 8 + e];
+        }
+      }
+      float* dst = partial + (((int64_t)img * nchunk + chunk) * C + col * 8) * 3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dst[3 * e] = sa[e];
+        dst[3 * e + 1] = sb[e];
+        dst[3 * e + 2] = kshift[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: one workgroup per (statistics group, channel group): mean / rstd again from the forward partials (Chan merge, as
+// gn_finalize_kernel), S1, S2 from the backward partials, then (P, Q, R) per (image, channel)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ fpart, const float* __restrict__ bpart,
+                                                              int nchunk, int C, int groups, int fps, int hw, int rpc, float eps,
+                                                              const f16* __restrict__ gamma, float* __restrict__ bcoef) {
+  __shared__ float red[4];
+  const int sg = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C / groups;
+  const int total = fps * nchunk * cpg;
+  const float cnt = (float)fps * (float)hw * (float)cpg;
+  float s = 0.f;
+  for (int i = lane; i < total; i += 256) {
+    const int c = i % cpg, t = i / cpg;
+    const int ch = t % nchunk, f = t / nchunk;
+    const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc);
+    s += n_i * fpart[((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 2];
+  }
+  const float mean = block_sum_256(s, red) / cnt;
+  float m2 = 0.f;
+  for (int i = lane; i < total; i += 256) {
+    const int c = i % cpg, t = i / cpg;
+    const int ch = t % nchunk, f = t / nchunk;
+    const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc);
+    const float2 v = *reinterpret_cast<const float2*>(fpart + ((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 2);
+    const float dm = v.x - mean;
+    m2 += v.y + n_i * dm * dm;
+  }
+  const float rstd = rsqrtf(block_sum_256(m2, red) / cnt + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < total; i += 256) {
+    const int c = i % cpg, t = i / cpg;
+    const int ch = t % nchunk, f = t / nchunk;
+    const float* b3 = bpart + ((((int64_t)(sg * fps + f)) * nchunk + ch) * C + grp * cpg + c) * 3;
+    const float ga = (float)gamma[grp * cpg + c];
+    s1 += ga * b3[0];
+    s2 += ga * (b3[1] + (b3[2] - mean) * b3[0]);
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red) * rstd;
+  const float q = -rstd * rstd * s2 / cnt, r = -rstd * s1 / cnt - mean * q;
+  for (int i = lane; i < fps * cpg; i += 256) {
+    const int c = grp * cpg + i % cpg, f = i / cpg;
+    float* dst = bcoef + ((int64_t)(sg * fps + f) * C + c) * 3;
+    dst[0] = (float)gamma[c] * rstd;
+    dst[1] = q;
+    dst[2] = r;
+  }
+}
+
+// pass 3: dx = dz P + x Q + R, split back onto the two sources of a channel-concatenated input
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2, int c2,
+                                                           const f16* __restrict__ dy, const float* __restrict__ coef,
+                                                           const float* __restrict__ bcoef, f16* __restrict__ dx1,
+                                                           f16* __restrict__ dx2, int n_img, int hw, int silu) {
+  const int C = c1 + c2, nvec = C / 8, nv1 = c1 / 8;
+  const int64_t total = (int64_t)n_img * hw * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int col = (int)(idx % nvec);
+    const int64_t rowg = idx / nvec;
+    const int img = (int)(rowg / hw);
+    const bool second = col >= nv1;
+    const int64_t off = second ? rowg * c2 + (col - nv1) * 8 : rowg * c1 + col * 8;
+    const f16x8 v = ld_global_16B((second ? x2 : x1) + off);
+    const f16x8 g = ld_global_16B(dy + rowg * C + col * 8);
+    const float* cf = coef + ((int64_t)img * C + col * 8) * 2;
+    const float* bc = bcoef + ((int64_t)img * C + col * 8) * 3;
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xv = (float)v[e];
+      float dz = (float)g[e];
+      if (silu) dz *= silu_grad(xv * cf[2 * e] + cf[2 * e + 1]);
+      o[e] = (f16)(dz * bc[3 * e] + xv * bc[3 * e + 1] + bc[3 * e + 2]);
+    }
+    *reinterpret_cast<f16x8*>((second ? dx2 : dx1) + off) = o;
+  }
+}
+
 // One-launch GroupNorm for the small levels (8 x 8 ... 32 x 32): a workgroup owns a whole (statistics group, block of
 // GB channel groups) slab -- fps * hw rows x GB * cpg channels, <= 64 KiB of fp16 -- reads it ONCE into LDS, takes the
 // exact two-pass statistics there (mean, then sum of squared deviations: no partials, no merge), applies scale / shift
@@ -539,6 +712,49 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, x1, p.c1, x2, p.c2, coef,
                      reinterpret_cast<f16*>(p.y), p.n_img, p.hw, p.silu, p.out_perm, p.frames);
   return i2v_check_launch("i2v_groupnorm_f16");
+}
+
+
+extern "C" int64_t i2v_groupnorm_bwd_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels) {
+  const int64_t nchunk = i2v_cdiv(hw, gn_rows_per_chunk(n_img, hw));
+  return ((int64_t)n_img * nchunk * channels * 5 + (int64_t)n_img * channels * 5) * (int64_t)sizeof(float);
+}
+
+extern "C" int i2v_groupnorm_bwd_f16(const i2v_gn_params* pp, const void* dy, void* dx, void* dx2, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_groupnorm_bwd_f16: null params");
+  const i2v_gn_params& p = *pp;
+  const int C = p.c1 + p.c2;
+  I2V_CHECK_ARG(p.x && p.gamma && p.beta && p.workspace && dy && dx, "i2v_groupnorm_bwd_f16: null pointer");
+  I2V_CHECK_ARG(p.n_img > 0 && p.hw > 0 && p.c1 > 0 && p.c2 >= 0, "i2v_groupnorm_bwd_f16: bad sizes");
+  I2V_CHECK_ARG((p.c2 == 0) == (p.x2 == nullptr) && (p.c2 == 0) == (dx2 == nullptr), "i2v_groupnorm_bwd_f16: x2 / dx2 / c2 mismatch");
+  I2V_CHECK_ARG(p.c1 % 8 == 0 && p.c2 % 8 == 0 && p.groups > 0 && C % p.groups == 0, "i2v_groupnorm_bwd_f16: channel counts");
+  I2V_CHECK_ARG(p.frames_per_stat > 0 && p.n_img % p.frames_per_stat == 0 && !p.out_perm,
+                "i2v_groupnorm_bwd_f16: frames_per_stat must divide n_img; out_perm is not supported");
+  I2V_CHECK_ARG(al16(p.x) && (!p.x2 || al16(p.x2)) && al16(dy) && al16(dx) && (!dx2 || al16(dx2)) && al16(p.workspace) &&
+                    al16(p.gamma) && al16(p.beta), "i2v_groupnorm_bwd_f16: pointers must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rpc = gn_rows_per_chunk(p.n_img, p.hw);
+  const int nchunk = (int)i2v_cdiv(p.hw, rpc);
+  float* fpart = reinterpret_cast<float*>(p.workspace);
+  float* coef = fpart + (int64_t)p.n_img * nchunk * C * 2;
+  float* bpart = coef + (int64_t)p.n_img * C * 2;
+  float* bcoef = bpart + (int64_t)p.n_img * nchunk * C * 3;
+  const f16* x1 = reinterpret_cast<const f16*>(p.x);
+  const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+  const f16* g = reinterpret_cast<const f16*>(p.gamma);
+  // the forward statistics again (the inference forward keeps none), then the three backward passes
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, fpart);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, fpart, nchunk, C,
+                     p.groups, p.frames_per_stat, p.hw, rpc, p.eps, g, reinterpret_cast<const f16*>(p.beta), coef);
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2,
+                     reinterpret_cast<const f16*>(dy), coef, p.hw, rpc, p.silu, bpart);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, fpart, bpart, nchunk,
+                     C, p.groups, p.frames_per_stat, p.hw, rpc, p.eps, g, bcoef);
+  const int64_t total = (int64_t)p.n_img * p.hw * (C / 8);
+  const int blocks = (int)(i2v_cdiv(total, 256) < 4096 ? i2v_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x1, p.c1, x2, p.c2, reinterpret_cast<const f16*>(dy),
+                     coef, bcoef, reinterpret_cast<f16*>(dx), reinterpret_cast<f16*>(dx2), p.n_img, p.hw, p.silu);
+  return i2v_check_launch("i2v_groupnorm_bwd_f16");
 }
 
 extern "C" int i2v_layernorm_f16(const i2v_ln_params* pp, i2v_stream_t stream) {

@@ -752,3 +752,82 @@ def masked_mse_grad(y, target, frames, coef):
     _lib.check(lib.i2v_masked_mse_grad_f16(_p(y), _p(target), _p(g), y.shape[0], y.shape[1], y.shape[2], frames, float(coef),
                                            _stream()), "i2v_masked_mse_grad_f16")
     return g
+
+
+def groupnorm_bwd(x, dy, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_stat=1):
+    """input gradient of groupnorm(x [, x2], ...): dy [N, H, W, C1 + C2] -> dx [N, H, W, C1] (, dx2 [N, H, W, C2])."""
+    lib = _lib.load()
+    _req(x, "x")
+    _req(dy, "dy")
+    if x.dim() != 4 or not x.is_contiguous() or not dy.is_contiguous():
+        raise ValueError("x / dy must be contiguous [N, H, W, C]")
+    n, h, w, c1 = x.shape
+    c2 = 0
+    if x2 is not None:
+        _req(x2, "x2")
+        if x2.dim() != 4 or not x2.is_contiguous() or x2.shape[:3] != x.shape[:3]:
+            raise ValueError("x2 must be contiguous [N, H, W, C2] with the same N, H, W as x")
+        c2 = x2.shape[3]
+    Cc = c1 + c2
+    if tuple(dy.shape) != (n, h, w, Cc) or gamma.numel() != Cc or beta.numel() != Cc:
+        raise ValueError("groupnorm_bwd: shape mismatch")
+    ws = torch.empty((lib.i2v_groupnorm_bwd_workspace_bytes(n, h * w, Cc) + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    p = GnParams()
+    p.x, p.c1, p.x2, p.c2 = _p(x), c1, _p(x2), c2
+    p.gamma, p.beta = _p(_req(gamma, "gamma").contiguous()), _p(_req(beta, "beta").contiguous())
+    p.n_img, p.hw, p.groups, p.frames_per_stat = n, h * w, groups, frames_per_stat
+    p.eps, p.silu = eps, 1 if silu else 0
+    p.workspace = _p(ws)
+    _lib.check(lib.i2v_groupnorm_bwd_f16(C.byref(p), _p(dy), _p(dx), _p(dx2), _stream()), "i2v_groupnorm_bwd_f16")
+    return (dx, dx2) if x2 is not None else dx
+
+
+def add(a, b, out=None):
+    """a + b (fp16, same shape, contiguous)."""
+    lib = _lib.load()
+    _req(a, "a")
+    _req(b, "b")
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous() or a.numel() % 8 != 0:
+        raise ValueError("add: equal-shape contiguous tensors with a multiple of 8 elements expected")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(lib.i2v_add_f16(_p(a), _p(b), _p(out), a.numel(), _stream()), "i2v_add_f16")
+    return out
+
+
+def permute_rows(x, batches, frames, hw, to_pixel_major):
+    """[batches * frames * hw, C] rows (b, f, p) -> (b, p, f) (to_pixel_major) or back."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    if x.shape[0] != batches * frames * hw or ldx != x.shape[1]:
+        raise ValueError("permute_rows: contiguous [batches * frames * hw, C] expected")
+    y = torch.empty_like(x)
+    _lib.check(lib.i2v_permute_rows_f16(_p(x), _p(y), batches, frames, hw, x.shape[1], 1 if to_pixel_major else 0, _stream()),
+               "i2v_permute_rows_f16")
+    return y
+
+
+def zero_insert2x(x):
+    """[N, H, W, C] -> [N, 2H, 2W, C] with x at the even positions and zeros elsewhere."""
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("zero_insert2x: contiguous [N, H, W, C] expected")
+    n, h, w, c = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, c), dtype=f16, device=x.device)
+    _lib.check(lib.i2v_zero_insert2x_f16(_p(x), _p(y), n, h, w, c, _stream()), "i2v_zero_insert2x_f16")
+    return y
+
+
+def sum_pool2x(x):
+    """[N, 2H, 2W, C] -> [N, H, W, C]: sums of the 2 x 2 blocks."""
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 4 or not x.is_contiguous() or x.shape[1] % 2 or x.shape[2] % 2:
+        raise ValueError("sum_pool2x: contiguous [N, 2H, 2W, C] expected")
+    n, h2, w2, c = x.shape
+    y = torch.empty((n, h2 // 2, w2 // 2, c), dtype=f16, device=x.device)
+    _lib.check(lib.i2v_sum_pool2x_f16(_p(x), _p(y), n, h2 // 2, w2 // 2, c, _stream()), "i2v_sum_pool2x_f16")
+    return y

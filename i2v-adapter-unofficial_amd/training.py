@@ -152,3 +152,190 @@ class AdapterBlockTrainer:
         inv = 1.0 / float(loss_scale)
         return {"hidden_states": g0, "i2v_adapter.to_q.weight": d_wq * inv, "i2v_adapter.to_out.0.weight": d_wout * inv,
                 "i2v_adapter.to_out.0.bias": d_bout * inv}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The frozen layers around the adapter blocks: input gradients only (no parameter of theirs trains, unet:979-1026), each
+# from the library's kernels: conv dgrad = the conv kernel over the flipped, transposed weights; GroupNorm(+SiLU) backward;
+# temporal attention backward = i2v_attention_bwd_f16 with batch = pixels, sequence = frames.
+from ._lib import I2V_STORE_ROWPERM  # noqa: E402
+from .blocks import pack_conv3x3  # noqa: E402
+
+
+def conv_dgrad_weight(weight, cout_pad=None):
+    """packed weights of the input-gradient convolution: W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]."""
+    return pack_conv3x3(weight.detach().transpose(0, 1).flip(2, 3), cin_pad=cout_pad)
+
+
+def _t(w):
+    return w16(w.detach().t())
+
+
+class ResnetTrainer:
+    """ResnetBlock2D: out = conv2(silu(GN2(conv1(silu(GN1(x))) + temb))) + shortcut(x)."""
+
+    def __init__(self, resnet):
+        self.m = resnet
+        if resnet.output_scale_factor != 1.0:
+            raise NotImplementedError("output_scale_factor = 1 on the hot path")
+
+    @torch.no_grad()
+    def forward(self, x, temb_rows, x2=None):
+        m, p = self.m, self.m.packed()
+        n, hh, ww, c1 = x.shape
+        a1 = K.groupnorm(x, p["g1"], p["b1"], m.groups, m.eps, x2=x2, silu=True)
+        rpv = (n // temb_rows.shape[0]) * hh * ww
+        h1 = K.conv3x3(a1, p["w1"], p["cb1"], rowvec=temb_rows, rows_per_vec=rpv)
+        a2 = K.groupnorm(h1, p["g2"], p["b2"], m.groups, m.eps, silu=True)
+        s = x
+        if m.conv_shortcut is not None:
+            a2d = None if x2 is None else x2.view(-1, x2.shape[3])
+            s = K.gemm(x.view(-1, c1), p["ws"], p["bs"], a2=a2d).view(n, hh, ww, m.out_channels)
+        self.saved = (x, x2, h1)
+        return K.conv3x3(a2, p["w2"], p["cb2"], residual=s)
+
+    @torch.no_grad()
+    def backward(self, g):
+        m, p = self.m, self.m.packed()
+        x, x2, h1 = self.saved
+        n, hh, ww, c1 = x.shape
+        d_a2 = K.conv3x3(g, conv_dgrad_weight(m.conv2.weight))
+        d_h1 = K.groupnorm_bwd(h1, d_a2, p["g2"], p["b2"], m.groups, m.eps, silu=True)
+        d_a1 = K.conv3x3(d_h1, conv_dgrad_weight(m.conv1.weight))
+        res = K.groupnorm_bwd(x, d_a1, p["g1"], p["b1"], m.groups, m.eps, x2=x2, silu=True)
+        dx, dx2 = res if x2 is not None else (res, None)
+        g2d = g.view(-1, m.out_channels)
+        if m.conv_shortcut is not None:
+            wst = _t(m.conv_shortcut.weight.reshape(m.out_channels, m.in_channels))          # [Cin, Cout]
+            dx = K.gemm(g2d, wst[:c1].contiguous(), residual=dx.view(-1, c1)).view(n, hh, ww, c1)
+            if x2 is not None:
+                c2 = x2.shape[3]
+                dx2 = K.gemm(g2d, wst[c1:].contiguous(), residual=dx2.view(-1, c2)).view(n, hh, ww, c2)
+        else:
+            dx = K.add(dx, g)
+        return dx, dx2
+
+
+class Transformer2DTrainer:
+    """I2VAdapterTransformer2DModel (i2v:184-354): GroupNorm -> proj_in -> block -> proj_out + residual."""
+
+    def __init__(self, t2d):
+        if len(t2d.transformer_blocks) != 1 or t2d.use_linear_projection:
+            raise NotImplementedError("one transformer block per Transformer2D, 1x1-conv projections (SD-1.5)")
+        self.m = t2d
+        self.block = AdapterBlockTrainer(t2d.transformer_blocks[0])
+
+    @torch.no_grad()
+    def forward(self, x, num_frames, ctx_text):
+        m, p = self.m, self.m.packed()
+        n, hh, ww, c = x.shape
+        nrm = K.groupnorm(x, p["g"], p["b"], m.groups, 1e-6)
+        t = K.gemm(nrm.view(-1, c), p["wi"], p["bi"])
+        t = self.block.forward(t, n, hh * ww, num_frames, ctx_text)
+        self.saved = x
+        return K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c)).view(n, hh, ww, c)
+
+    @torch.no_grad()
+    def backward(self, g, loss_scale):
+        m, p = self.m, self.m.packed()
+        x = self.saved
+        n, hh, ww, c = x.shape
+        dt = K.gemm(g.view(-1, c), _t(p["wo"]))
+        grads = self.block.backward(dt, loss_scale=loss_scale)
+        dn = K.gemm(grads.pop("hidden_states"), _t(p["wi"])).view(n, hh, ww, c)
+        dx = K.groupnorm_bwd(x, dn, p["g"], p["b"], m.groups, 1e-6)
+        return K.add(dx, g), grads
+
+
+class MotionModuleTrainer:
+    """TransformerTemporalModel: clip-wide GroupNorm -> proj_in -> [LN + PE -> self-attention over the frames of
+    a pixel -> + residual] x 2 -> LN -> GEGLU FF -> proj_out -> + residual, on rows in (batch, pixel, frame) order."""
+
+    def __init__(self, mm):
+        if len(mm.transformer_blocks) != 1:
+            raise NotImplementedError("one temporal block per motion module (AnimateDiff v1.5)")
+        self.m = mm
+
+    @torch.no_grad()
+    def forward(self, x, num_frames):
+        m, p = self.m, self.m.packed()
+        blk = m.transformer_blocks[0]
+        q = blk.packed()
+        n, hh, ww, c = x.shape
+        hw, clips, F = hh * ww, n // num_frames, num_frames
+        n_pixels = clips * hw
+        nrm = K.groupnorm(x, p["g"], p["b"], m.groups, 1e-6, frames_per_stat=F)
+        t = K.gemm(K.permute_rows(nrm.view(-1, c), clips, F, hw, True), p["wi"], p["bi"])
+        stages = []
+        for i in (1, 2):
+            nl = K.layernorm(t, q[f"g{i}"], q[f"b{i}"], blk.eps, pe=q["pe"], pe_period=F)
+            qk = K.gemm(nl, q[f"wqk{i}"])
+            v = K.gemm(nl, q[f"wv{i}"])
+            o = K.temporal_attention(qk[:, :c], qk[:, c:], K.transpose_tokens(v, F), n_pixels=n_pixels, frames=F,
+                                     heads=blk.heads, head_dim=blk.dim_head, scale=blk.dim_head ** -0.5)
+            stages.append((t, qk, v, o))
+            t = K.gemm(o, q[f"wo{i}"], q[f"bo{i}"], residual=t)
+        ff = blk.ff.packed()
+        n3 = K.layernorm(t, q["g3"], q["b3"], blk.eps)
+        h = K.gemm(n3, ff["w1"], ff["b1"])
+        y = K.gemm(n3, ff["w1"], ff["b1"], epilogue=I2V_EPI_GEGLU)
+        t3 = K.gemm(y, ff["w2"], ff["b2"], residual=t)
+        self.saved = (x, stages, t, h)
+        return K.gemm(t3, p["wo"], p["bo"], residual=x.view(-1, c), store=I2V_STORE_ROWPERM, frames=F, hw=hw).view(n, hh, ww, c)
+
+    @torch.no_grad()
+    def backward(self, g, num_frames):
+        m, p = self.m, self.m.packed()
+        blk = m.transformer_blocks[0]
+        q, ff = blk.packed(), blk.ff.packed()
+        x, stages, t2, h = self.saved
+        n, hh, ww, c = x.shape
+        hw, clips, F = hh * ww, n // num_frames, num_frames
+        n_pixels = clips * hw
+        gp = K.permute_rows(g.view(-1, c), clips, F, hw, True)
+        dt = K.gemm(gp, _t(p["wo"]))                                                  # dL/dt3
+        dy = K.gemm(dt, _t(ff["w2"]))
+        dn3 = K.gemm(K.geglu_bwd(h, dy), w16(ff["w1"].t()))
+        dt = K.layernorm_bwd(t2, dn3, q["g3"], blk.eps, add=dt)
+        for i in (2, 1):
+            t_in, qk, v, o = stages[i - 1]
+            do = K.gemm(dt, _t(q[f"wo{i}"]))
+            dq, dk, dv = K.attention_bwd(qk[:, :c], qk[:, c:], v, o, do, batch_q=n_pixels, lq=F, lk=F, heads=blk.heads,
+                                         head_dim=blk.dim_head, scale=blk.dim_head ** -0.5)
+            dnl = K.gemm(dq, w16(q[f"wqk{i}"].t()), a2=dk)                            # [dq | dk] [Wq ; Wk]
+            dnl = K.gemm(dv, _t(q[f"wv{i}"]), residual=dnl, out=dnl)
+            dt = K.layernorm_bwd(t_in, dnl, q[f"g{i}"], blk.eps, add=dt)
+        dnp = K.gemm(dt, _t(p["wi"]))
+        dn = K.permute_rows(dnp, clips, F, hw, False).view(n, hh, ww, c)
+        dx = K.groupnorm_bwd(x, dn, p["g"], p["b"], m.groups, 1e-6, frames_per_stat=F)
+        return K.add(dx, g)
+
+
+class DownsampleTrainer:
+    def __init__(self, d):
+        if d.padding != 1:
+            raise NotImplementedError("Downsample2D(padding=1) on the UNet path")
+        self.m = d
+
+    @torch.no_grad()
+    def forward(self, x):
+        p = self.m.packed()
+        return K.conv3x3(x, p["w"], p["b"], stride=2)
+
+    @torch.no_grad()
+    def backward(self, g):
+        return K.conv3x3(K.zero_insert2x(g), conv_dgrad_weight(self.m.conv.weight))
+
+
+class UpsampleTrainer:
+    def __init__(self, u):
+        self.m = u
+
+    @torch.no_grad()
+    def forward(self, x):
+        p = self.m.packed()
+        return K.conv3x3(x, p["w"], p["b"], upsample=True)
+
+    @torch.no_grad()
+    def backward(self, g):
+        return K.sum_pool2x(K.conv3x3(g, conv_dgrad_weight(self.m.conv.weight)))

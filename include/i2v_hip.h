@@ -332,8 +332,8 @@ int i2v_attention_lse_f32(const i2v_attn_params* p, float* lse, i2v_stream_t str
  * q, k, v, dout, dq, dk, dv are token-major [batch][token][heads * head_dim] views (row / batch strides in elements);
  * qt, kt, doutt are channel-major copies [batch][heads * head_dim][token] (i2v_transpose_f16; rows zero-filled up to the
  * next multiple of 8 tokens).  dk = NULL skips the dK / dV sweep (frozen context K / V of the text cross-attention); qt,
- * doutt, dv are then unused.  That sweep needs lq % 32 == 0; the dQ sweep takes any lq, lk.  No atomics: gradients are
- * run-to-run identical. */
+ * doutt, dv are then unused.  Any lq, lk (short sequences -- the <= 32 frames of one pixel in the motion modules, batch =
+ * pixels -- run with most of a 32-row block masked).  No atomics: gradients are run-to-run identical. */
 typedef struct i2v_attn_bwd_params {
   const void* q;     int64_t q_row_stride, q_batch_stride;
   const void* qt;    int64_t qt_row_stride, qt_batch_stride;
@@ -377,6 +377,25 @@ int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t rows, int32_t
  * coef = 2 * loss_scale / count is the caller's.  y, target, grad fp16 [n_img, tokens, channels]. */
 int i2v_masked_mse_grad_f16(const void* y, const void* target, void* grad, int64_t n_img, int32_t tokens, int32_t channels,
                             int32_t frames, float coef, i2v_stream_t stream);
+/* GroupNorm (+SiLU) backward, input gradient only (native_group_norm_backward + silu_backward behind ResnetBlock2D norm1 /
+ * norm2, Transformer2D norm, the motion modules' clip-wide norm and conv_norm_out; the norms are frozen): p describes the
+ * FORWARD call (x [, x2], gamma, beta, n_img, hw, groups, frames_per_stat, eps, silu; y and out_perm unused), dy is the
+ * gradient of its output [n_img, hw, c1 + c2]; dx [n_img, hw, c1] (and dx2 [.., c2] for a channel-concatenated input).
+ * The forward statistics are recomputed (the inference forward keeps none).  workspace: fp32,
+ * i2v_groupnorm_bwd_workspace_bytes(...) bytes. */
+int64_t i2v_groupnorm_bwd_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels);
+int i2v_groupnorm_bwd_f16(const i2v_gn_params* p, const void* dy, void* dx, void* dx2, i2v_stream_t stream);
+/* out = a + b over n fp16 elements (n % 8 == 0): gradients meeting at a skip connection (unet:478) or a residual branch. */
+int i2v_add_f16(const void* a, const void* b, void* out, int64_t n, i2v_stream_t stream);
+/* row permutation (batch, frame, pixel) <-> (batch, pixel, frame) of [batches * frames * hw, channels] fp16 (the motion
+ * modules run in pixel-major row order; to_pixel_major = 1: dst row (b hw + p) F + f = src row (b F + f) hw + p). */
+int i2v_permute_rows_f16(const void* src, void* dst, int64_t batches, int32_t frames, int32_t hw, int32_t channels,
+                         int32_t to_pixel_major, i2v_stream_t stream);
+/* dst [n, 2h, 2w, C]: dst[2y][2x] = src[y][x], zero elsewhere: the input gradient of Downsample2D's stride-2 convolution
+ * (unet:250-259) is the stride-1 convolution of this tensor with the flipped, transposed weights. */
+int i2v_zero_insert2x_f16(const void* src, void* dst, int64_t n_img, int32_t h, int32_t w, int32_t channels, i2v_stream_t stream);
+/* dst [n, h, w, C] = sums of the 2 x 2 blocks of src [n, 2h, 2w, C]: input gradient of Upsample2D's nearest-2x (unet:431-432). */
+int i2v_sum_pool2x_f16(const void* src, void* dst, int64_t n_img, int32_t h, int32_t w, int32_t channels, i2v_stream_t stream);
 
 #ifdef __cplusplus
 }

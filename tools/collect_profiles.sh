@@ -7,11 +7,15 @@
 #   <tag>_kernel_stats.txt        rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2`
 #   <tag>_pmc_summary.txt         per-kernel PMC table (tools/pmc_step.sh)
 #   <tag>_traffic.json            bytes below L2 per launch by kernel class (tools/pmc_traffic.sh)
+#   <tag>_ceilings.json           measured ceilings of THIS chip: stream copy / read, MFMA-saturating loops (tools/ceilings.hip,
+#                                 built beforehand in the container: hipcc --offload-arch=gfx950 -O3 tools/ceilings.hip -o
+#                                 tools/build/ceilings); bench.py reads profiles/<tag>_ceilings.json for frac_of_measured
 set -e
 cd "${GRAFT_REPO_ROOT:?}"
 mkdir -p gpurun_out
 tag=${1:-r2}
 export TMPDIR=/tmp
+if [ -x tools/build/ceilings ]; then tools/build/ceilings > gpurun_out/${tag}_ceilings.json 2> gpurun_out/${tag}_ceilings.err; fi
 python bench.py --shapes gpurun_out/${tag}_step_shapes.txt > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 : > gpurun_out/${tag}_bench_configs.jsonl
 python bench.py --frames 8 --size 256 --no-cpu-baseline 2>/dev/null >> gpurun_out/${tag}_bench_configs.jsonl
