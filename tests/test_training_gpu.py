@@ -154,3 +154,139 @@ def test_adapter_block_backward_vs_autograd(dev, dim, heads, L, frames, clips):
     compare(grads["i2v_adapter.to_out.0.bias"], train[2].grad, rel=GRAD_REL_TOL, name=f"d loss / d i2v_adapter.to_out.0.bias (C={dim})")
     again = tr.backward(seed.view(-1, dim), loss_scale=loss_scale)
     assert all(torch.equal(grads[k], again[k]) for k in grads if k != "i2v_adapter.to_out.0.bias")   # (bias: fp32 atomics)
+
+
+# ---------------------------------------------------------------------------------------------- the frozen layers around
+def _nchw_to_tok(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _pair(oracle_cls, hip_cls, dev, seed, *args, jitter=True, **kwargs):
+    torch.manual_seed(seed)
+    o = oracle_cls(*args, **kwargs)
+    if jitter:
+        with torch.no_grad():
+            for mod in o.modules():
+                if isinstance(mod, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
+                    mod.weight.add_(0.1 * torch.randn_like(mod.weight))
+                    mod.bias.add_(0.1 * torch.randn_like(mod.bias))
+    o = round_fp16_(o).eval()
+    m = hip_cls(*args, **kwargs)
+    m.load_state_dict(o.state_dict())
+    for prm in o.parameters():
+        prm.requires_grad_(False)
+    return o, m.to(device=dev, dtype=torch.float16).eval()
+
+
+@pytest.mark.parametrize("c1,c2,hw,fps,silu", [(64, 0, 16, 1, True), (320, 0, 32, 1, False), (64, 32, 8, 1, True), (64, 0, 8, 4, False)])
+def test_groupnorm_backward(dev, c1, c2, hw, fps, silu):
+    """spatial and clip-wide statistics, SiLU fused, channel-concatenated input (the up blocks' skip, unet:478)."""
+    K = pkg().kernels
+    g = torch.Generator().manual_seed(c1 + c2 + hw)
+    n, C, groups = 8, c1 + c2, 16
+    x = (h(torch.randn(n, C, hw, hw, generator=g)) * 1.5 + 3.0 * torch.randn(1, C, 1, 1, generator=g)).half().float().requires_grad_()
+    gamma, beta = h(1 + 0.2 * torch.randn(C, generator=g)), h(0.2 * torch.randn(C, generator=g))
+    dy = h(torch.randn(n, C, hw, hw, generator=g))
+    xin = x.view(n // fps, fps, C, hw, hw).permute(0, 2, 1, 3, 4) if fps > 1 else x
+    y = torch.nn.functional.group_norm(xin, groups, gamma, beta, 1e-5)
+    if fps > 1:
+        y = y.permute(0, 2, 1, 3, 4).reshape(n, C, hw, hw)
+    (torch.nn.functional.silu(y) if silu else y).backward(dy)
+    xt = _nchw_to_tok(x.detach()).half().to(dev)
+    kw = dict(silu=silu, frames_per_stat=fps)
+    if c2:
+        dx1, dx2 = K.groupnorm_bwd(xt[..., :c1].contiguous(), _nchw_to_tok(dy).half().to(dev), gamma.half().to(dev),
+                                   beta.half().to(dev), groups, 1e-5, x2=xt[..., c1:].contiguous(), **kw)
+        got = torch.cat([dx1, dx2], dim=3)
+    else:
+        got = K.groupnorm_bwd(xt, _nchw_to_tok(dy).half().to(dev), gamma.half().to(dev), beta.half().to(dev), groups, 1e-5, **kw)
+    compare(got, _nchw_to_tok(x.grad), rel=GRAD_REL_TOL, name=f"GroupNorm backward C={c1}+{c2} fps={fps} silu={silu}")
+
+
+@pytest.mark.parametrize("cin,cout,skip", [(64, 64, 0), (64, 128, 0), (96, 64, 32)])
+def test_resnet_backward(dev, cin, cout, skip):
+    from oracle.blocks import ResnetBlock2D as O
+    from i2v_adapter_unofficial_amd.training import ResnetTrainer
+    o, m = _pair(O, pkg().blocks.ResnetBlock2D, dev, 21, cin, cout, temb_channels=128, eps=1e-5, groups=16)
+    g = torch.Generator().manual_seed(22)
+    n, hw = 4, 16
+    x = h(torch.randn(n, cin, hw, hw, generator=g)).requires_grad_()
+    temb = h(torch.randn(2, 128, generator=g))
+    dy = h(torch.randn(n, cout, hw, hw, generator=g))
+    out = o(x, temb.repeat_interleave(2, dim=0))
+    out.backward(dy)
+    K = pkg().kernels
+    tr = ResnetTrainer(m)
+    p = m.packed()
+    rows = K.gemm(K.silu(temb.half().to(dev)), p["wt"], p["bt"])
+    xt = _nchw_to_tok(x.detach()).half().to(dev)
+    x1, x2 = (xt[..., :cin - skip].contiguous(), xt[..., cin - skip:].contiguous()) if skip else (xt, None)
+    y = tr.forward(x1, rows, x2=x2)
+    compare(y, _nchw_to_tok(out), rel=3e-3, name="resnet training forward")
+    dx, dx2 = tr.backward(_nchw_to_tok(dy).half().to(dev))
+    got = torch.cat([dx, dx2], dim=3) if skip else dx
+    compare(got, _nchw_to_tok(x.grad), rel=GRAD_REL_TOL, name=f"ResnetBlock2D backward {cin}->{cout} skip={skip}")
+
+
+def test_samplers_backward(dev):
+    from oracle.blocks import Downsample2D as OD, Upsample2D as OU
+    from i2v_adapter_unofficial_amd.training import DownsampleTrainer, UpsampleTrainer
+    g = torch.Generator().manual_seed(31)
+    for ocls, hcls, tcls, scale in ((OD, pkg().blocks.Downsample2D, DownsampleTrainer, 0.5), (OU, pkg().blocks.Upsample2D, UpsampleTrainer, 2)):
+        o, m = _pair(ocls, hcls, dev, 32, 64)
+        x = h(torch.randn(3, 64, 16, 16, generator=g)).requires_grad_()
+        out = o(x)
+        dy = h(torch.randn(out.shape, generator=g))
+        out.backward(dy)
+        tr = tcls(m)
+        y = tr.forward(_nchw_to_tok(x.detach()).half().to(dev))
+        compare(y, _nchw_to_tok(out), rel=3e-3, name=f"{ocls.__name__} forward")
+        compare(tr.backward(_nchw_to_tok(dy).half().to(dev)), _nchw_to_tok(x.grad), rel=GRAD_REL_TOL, name=f"{ocls.__name__} backward")
+
+
+@pytest.mark.parametrize("frames", [4, 16])
+def test_motion_module_backward(dev, frames):
+    from oracle.blocks import TransformerTemporalModel as O
+    from i2v_adapter_unofficial_amd.training import MotionModuleTrainer
+    kw = dict(num_attention_heads=4, attention_head_dim=16, in_channels=64, norm_num_groups=16, attention_bias=False,
+              activation_fn="geglu", positional_embeddings="sinusoidal", num_positional_embeddings=32)
+    o, m = _pair(O, pkg().blocks.TransformerTemporalModel, dev, 41, **kw)
+    g = torch.Generator().manual_seed(42)
+    n, hw = 2 * frames, 8
+    x = h(torch.randn(n, 64, hw, hw, generator=g)).requires_grad_()
+    dy = h(torch.randn(n, 64, hw, hw, generator=g))
+    out = o(x, num_frames=frames)[0]
+    out.backward(dy)
+    tr = MotionModuleTrainer(m)
+    y = tr.forward(_nchw_to_tok(x.detach()).half().to(dev), frames)
+    compare(y, _nchw_to_tok(out), rel=3e-3, name="motion module training forward")
+    compare(tr.backward(_nchw_to_tok(dy).half().to(dev), frames), _nchw_to_tok(x.grad), rel=GRAD_REL_TOL,
+            name=f"TransformerTemporalModel backward F={frames}")
+
+
+def test_transformer2d_backward(dev):
+    from oracle.i2v_adapter import I2VAdapterTransformer2DModel as O
+    from i2v_adapter_unofficial_amd.training import Transformer2DTrainer
+    o, m = _pair(O, pkg().I2VAdapterTransformer2DModel, dev, 51, 4, 16, in_channels=64, num_layers=1, cross_attention_dim=48,
+                 norm_num_groups=16)
+    randomize_adapter_out_(o)
+    m.load_state_dict(o.state_dict())
+    m = m.to(device=dev, dtype=torch.float16)
+    ad = o.transformer_blocks[0].i2v_adapter
+    train = [ad.to_q.weight, ad.to_out[0].weight, ad.to_out[0].bias]
+    for prm in train:
+        prm.requires_grad_(True)
+    g = torch.Generator().manual_seed(52)
+    frames, n, hw = 4, 8, 8
+    x = h(torch.randn(n, 64, hw, hw, generator=g)).requires_grad_()
+    ctx = h(torch.randn(n, 7, 48, generator=g))
+    dy = h(torch.randn(n, 64, hw, hw, generator=g))
+    out = o(x, enable_cross_frame_attn=True, encoder_hidden_states=ctx, num_frames=frames, return_dict=False)[0]
+    out.backward(dy)
+    tr = Transformer2DTrainer(m)
+    y = tr.forward(_nchw_to_tok(x.detach()).half().to(dev), frames, ctx.half().to(dev))
+    compare(y, _nchw_to_tok(out), rel=3e-3, name="Transformer2D training forward")
+    dx, grads = tr.backward(_nchw_to_tok(dy).half().to(dev), loss_scale=1.0)
+    compare(dx, _nchw_to_tok(x.grad), rel=GRAD_REL_TOL, name="Transformer2D backward: d / d input")
+    for key, ref in zip(("i2v_adapter.to_q.weight", "i2v_adapter.to_out.0.weight", "i2v_adapter.to_out.0.bias"), train):
+        compare(grads[key], ref.grad, rel=GRAD_REL_TOL, name=f"Transformer2D backward: {key}")
