@@ -155,6 +155,9 @@ SIGNATURES = {
     "i2v_permute_rows_f16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_zero_insert2x_f16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_sum_pool2x_f16": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "i2v_sumsq_f32": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "i2v_adamw_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                C.c_float, _P, C.c_float, _P]),
     "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, _P]),
 }

@@ -476,6 +476,41 @@ __global__ __launch_bounds__(256) void sum_pool_kernel(const f16* __restrict__ s
   }
 }
 
+// out[0] += sum x^2 (global gradient norm for clip_grad_norm_, train_image_to_video.py:878-879)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.AdamW (decoupled weight decay) over one flat fp32 bucket; grad_coef folds 1 / loss_scale, the data-parallel
+// mean and the clip coefficient: g = grad * min(1, max_norm / (*norm_sq)^0.5 / ...) is applied by the caller through it,
+// except the clip, which reads the DEVICE value *norm_sq (no host round trip): g *= min(1, max_norm / (sqrt(norm_sq) grad_coef'))
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2, float grad_coef,
+                                                    const float* __restrict__ norm_sq, float max_norm) {
+  float coef = grad_coef;
+  if (norm_sq != nullptr && max_norm > 0.f) {
+    const float total = sqrtf(*norm_sq) * grad_coef;          // norm of the un-scaled, averaged gradient
+    coef *= fminf(1.0f, max_norm / (total + 1e-6f));           // clip_grad_norm_'s coefficient
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g = grad[i] * coef;
+    float p = param[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * g;
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    p -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    param[i] = p;
+  }
+}
+
 inline int ew_grid(int64_t n) {
   const int64_t b = i2v_cdiv(n, 256);
   return (int)(b < 65535 * 4 ? (b > 0 ? b : 1) : 65535 * 4);
@@ -661,4 +696,22 @@ extern "C" int i2v_sum_pool2x_f16(const void* src, void* dst, int64_t n_img, int
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), reinterpret_cast<f16*>(dst), n_img, h,
                      w, channels);
   return i2v_check_launch("i2v_sum_pool2x_f16");
+}
+
+extern "C" int i2v_sumsq_f32(const float* x, int64_t n, float* out, i2v_stream_t stream) {
+  I2V_CHECK_ARG(x && out && n > 0, "i2v_sumsq_f32: bad arguments");
+  const int64_t b = i2v_cdiv(n, 256);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(b < 1024 ? b : 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, out);
+  return i2v_check_launch("i2v_sumsq_f32");
+}
+
+extern "C" int i2v_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, float grad_coef, const float* norm_sq,
+                             float max_norm, i2v_stream_t stream) {
+  I2V_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "i2v_adamw_f32: bad arguments");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  const int64_t b = i2v_cdiv(n, 256);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(b < 4096 ? b : 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param,
+                     grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_coef, norm_sq, max_norm);
+  return i2v_check_launch("i2v_adamw_f32");
 }

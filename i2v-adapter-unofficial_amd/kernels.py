@@ -831,3 +831,29 @@ def sum_pool2x(x):
     y = torch.empty((n, h2 // 2, w2 // 2, c), dtype=f16, device=x.device)
     _lib.check(lib.i2v_sum_pool2x_f16(_p(x), _p(y), n, h2 // 2, w2 // 2, c, _stream()), "i2v_sum_pool2x_f16")
     return y
+
+
+def sumsq(x, out=None):
+    """fp32 [1] += sum of squares of a flat fp32 tensor (the global gradient norm)."""
+    lib = _lib.load()
+    _req(x, "x", dtype=torch.float32)
+    if not x.is_contiguous():
+        raise ValueError("sumsq: contiguous tensor expected")
+    if out is None:
+        out = torch.zeros((1,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.i2v_sumsq_f32(_p(x), x.numel(), _p(out), _stream()), "i2v_sumsq_f32")
+    return out
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr, betas, eps, weight_decay, step, grad_coef=1.0, norm_sq=None,
+               max_norm=0.0):
+    """in-place AdamW update of a flat fp32 bucket (i2v_adamw_f32)."""
+    lib = _lib.load()
+    for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, name, dtype=torch.float32)
+        if not t.is_contiguous() or t.numel() != param.numel():
+            raise ValueError(f"adamw_step: {name} must be contiguous with {param.numel()} elements")
+    _lib.check(lib.i2v_adamw_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
+                                 float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_coef), _p(norm_sq),
+                                 float(max_norm), _stream()), "i2v_adamw_f32")
+    return param

@@ -19,8 +19,9 @@ summed over the clip's frames inside the kernel), LayerNorm / GEGLU backward, bi
 fp16 under the caller's loss scale (as the reference's fp16 mixed precision scales its loss); parameter gradients come back
 un-scaled in fp32.  There is no CPU fallback.
 
-Not here yet (the rest of f4): conv / GroupNorm / motion-module backward, the other blocks' chaining, the optimiser and the
-RCCL all-reduce of the adapter gradients (~100 MB per step).
+Below the block: the backward of the frozen layers around it (ResnetBlock2D, Transformer2D, the motion modules, the
+samplers), `UNetAdapterTrainer` (the whole forward + backward of the reference's training step for the adapter parameters)
+and `AdapterOptimizer` (clip + AdamW over flat fp32 buckets, ONE all-reduce of the adapter gradients over RCCL per step).
 """
 import torch
 
@@ -339,3 +340,193 @@ class UpsampleTrainer:
     @torch.no_grad()
     def backward(self, g):
         return K.sum_pool2x(K.conv3x3(g, conv_dgrad_weight(self.m.conv.weight)))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The whole training step of the reference loop (src/train_image_to_video.py:839-884) for the adapter parameters.
+class UNetAdapterTrainer:
+    """forward(...) = UNetMotionCrossFrameAttnModel.forward with enable_cross_frame_attn=True (unet:1289-1451) in the un-fused
+    training form, keeping every layer's input; backward(target, ...) = the loss without the first frame
+    (train_image_to_video.py:848-856) seeded at the prediction and walked back through every frozen layer, collecting
+    d loss / d {i2v_adapter.to_q.weight, to_out.0.weight, to_out.0.bias} of all spatial blocks (unet:979-1026) as un-scaled
+    fp32 tensors keyed by their state-dict names."""
+
+    def __init__(self, unet):
+        from .blocks import DownBlockMotion, UpBlockMotion  # noqa: F401  (attention-free blocks: resnet -> motion)
+        self.unet = unet
+        names = {m: n for n, m in unet.named_modules()}
+        self.tape_layout = []          # (kind, trainer, extra) in forward order; built once, replayed per step
+        self._mk = dict(resnet=ResnetTrainer, t2d=Transformer2DTrainer, motion=MotionModuleTrainer, down=DownsampleTrainer,
+                        up=UpsampleTrainer)
+        self._names = names
+        self._trainers = {}
+        if unet.encoder_hid_proj is not None:
+            raise NotImplementedError("IP-Adapter image tokens in the training step are not implemented yet")
+
+    def _tr(self, kind, module):
+        t = self._trainers.get(module)
+        if t is None:
+            t = self._trainers[module] = self._mk[kind](module)
+        return t
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states):
+        """sample (B, F, C, H, W) on the GPU; returns the prediction as tokens fp16 [B * F, H, W, 8] (4 channels + zeros)."""
+        u = self.unet
+        b, F, c, hh, ww = sample.shape
+        p = u.packed()
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
+        t = t.to(device=sample.device, dtype=torch.float32).reshape(-1).expand(b).contiguous()
+        temb_act = K.silu(u._embed_time(t))
+        ctx = encoder_hidden_states.to(f16).contiguous()
+        rows = lambda r: K.gemm(temb_act, r.packed()["wt"], r.packed()["bt"])
+        tape, res, res_ids = [], [], []
+        x = K.conv3x3(K.nchw_to_tokens(sample.reshape(b * F, c, hh, ww), p["cin_pad"]), p["w_in"], p["b_in"])
+        push = lambda v: (tape.append(("push", None, len(res_ids))), res.append(v), res_ids.append(len(res_ids)))
+
+        def layer(x, resnet, attn, motion, skip=None, skip_id=None):
+            r = self._tr("resnet", resnet)
+            x = r.forward(x, rows(resnet), x2=skip)
+            tape.append(("resnet", r, skip_id))
+            if attn is not None:
+                a = self._tr("t2d", attn)
+                x = a.forward(x, F, ctx)
+                tape.append(("t2d", a, self._names[attn]))
+            if motion is not None:
+                mm = self._tr("motion", motion)
+                x = mm.forward(x, F)
+                tape.append(("motion", mm, None))
+            return x
+
+        push(x)
+        for blk in u.down_blocks:
+            attns = getattr(blk, "attentions", [None] * len(blk.resnets))
+            for resnet, attn, motion in zip(blk.resnets, attns, blk.motion_modules):
+                x = layer(x, resnet, attn, motion)
+                push(x)
+            if blk.downsamplers is not None:
+                for d in blk.downsamplers:
+                    tr = self._tr("down", d)
+                    x = tr.forward(x)
+                    tape.append(("down", tr, None))
+                push(x)
+        mid = u.mid_block
+        x = layer(x, mid.resnets[0], None, None)
+        for attn, resnet, motion in zip(mid.attentions, mid.resnets[1:], mid.motion_modules):
+            a = self._tr("t2d", attn)
+            x = a.forward(x, F, ctx)
+            tape.append(("t2d", a, self._names[attn]))
+            mm = self._tr("motion", motion)
+            x = mm.forward(x, F)
+            tape.append(("motion", mm, None))
+            x = layer(x, resnet, None, None)
+        for blk in u.up_blocks:
+            attns = getattr(blk, "attentions", [None] * len(blk.resnets))
+            for resnet, attn, motion in zip(blk.resnets, attns, blk.motion_modules):
+                skip, sid = res.pop(), res_ids.pop()
+                x = layer(x, resnet, attn, motion, skip=skip, skip_id=sid)
+            if blk.upsamplers is not None:
+                for up in blk.upsamplers:
+                    tr = self._tr("up", up)
+                    x = tr.forward(x)
+                    tape.append(("up", tr, None))
+        a = K.groupnorm(x, p["g_out"], p["be_out"], u.config.norm_num_groups, u.config.norm_eps, silu=True)
+        w_out = torch.zeros((8,) + tuple(u.conv_out.weight.shape[1:]), dtype=u.conv_out.weight.dtype, device=x.device)
+        w_out[: u.conv_out.weight.shape[0]] = u.conv_out.weight.detach()
+        b_out = torch.zeros((8,), dtype=f16, device=x.device)
+        b_out[: u.conv_out.bias.shape[0]] = u.conv_out.bias.detach().to(f16)
+        y = K.conv3x3(a, pack_conv3x3(w_out), b_out)
+        self.saved = dict(tape=tape, x_last=x, y=y, F=F, w_out=w_out)
+        return y
+
+    @torch.no_grad()
+    def backward(self, target, loss_scale=2.0 ** 12):
+        """target (B, F, C, H, W) (the noise, train_image_to_video.py:830-831).  Returns (loss, {name: fp32 gradient})."""
+        u, s = self.unet, self.saved
+        p = u.packed()
+        y, F = s["y"], s["F"]
+        n, hh, ww, _ = y.shape
+        b, c = n // F, target.shape[2]
+        tgt = K.nchw_to_tokens(target.to(device=y.device, dtype=torch.float32).reshape(n, c, hh, ww).contiguous(), 8)
+        count = float(b * (F - 1) * c * hh * ww)
+        seed = K.masked_mse_grad(y.view(n, hh * ww, 8), tgt.view(n, hh * ww, 8), F, 2.0 * loss_scale / count)
+        # loss = sum (coef (y - t))^2 / (coef^2 count): the row sums on the GPU, their total is plumbing
+        per_row = K.rowdot_heads(seed.view(-1, 8), seed.view(-1, 8), rows_per_batch=hh * ww, heads=1, head_dim=8)
+        loss = per_row.sum() * (count / (2.0 * loss_scale) ** 2)
+        g = K.conv3x3(seed.view(n, hh, ww, 8), conv_dgrad_weight(s["w_out"], cout_pad=8))
+        g = K.groupnorm_bwd(s["x_last"], g, p["g_out"], p["be_out"], u.config.norm_num_groups, u.config.norm_eps, silu=True)
+        grads, dskip = {}, {}
+        tape = s["tape"]
+        first_t2d = min(i for i, op in enumerate(tape) if op[0] == "t2d")
+        for i in range(len(tape) - 1, first_t2d - 1, -1):          # nothing trains in front of the first transformer
+            kind, tr, extra = tape[i]
+            if kind == "push":
+                if extra in dskip:
+                    g = K.add(g, dskip.pop(extra))
+            elif kind == "resnet":
+                g, dx2 = tr.backward(g)
+                if extra is not None:
+                    dskip[extra] = dx2
+            elif kind == "t2d":
+                g, pg = tr.backward(g, loss_scale)
+                for k, v in pg.items():
+                    grads[f"{extra}.transformer_blocks.0.{k}"] = v
+            elif kind == "motion":
+                g = tr.backward(g, F)
+            else:
+                g = tr.backward(g)
+        self.saved = None
+        return loss, grads
+
+
+class AdapterOptimizer:
+    """AdamW + clip_grad_norm_ on the adapter parameters (train_image_to_video.py:716-724, 876-882), data-parallel:
+    fp32 master copies, gradients and both moments live in FLAT buckets in state-dict order; `step(grads)` copies the
+    gradients into the bucket, sums it over the ranks with ONE all-reduce (RCCL over xGMI under backend "nccl"; the mean is
+    folded into the update's gradient coefficient), takes the global norm and applies the update with two kernels, then
+    writes the fp16 parameters back.  No per-parameter launches, no host round trip for the clip coefficient."""
+
+    def __init__(self, unet, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, process_group=None):
+        self.unet, self.group = unet, process_group
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.names = [n for n, _ in unet.named_parameters()
+                      if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n]                   # unet:1001-1006
+        params = dict(unet.named_parameters())
+        self.params = [params[n] for n in self.names]
+        self.offsets, off = {}, 0
+        for n, prm in zip(self.names, self.params):
+            self.offsets[n] = (off, prm.numel())
+            off += prm.numel()
+        dev = self.params[0].device
+        self.master = torch.cat([prm.detach().float().reshape(-1) for prm in self.params]).contiguous()
+        self.grad = torch.zeros_like(self.master)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.master), torch.zeros_like(self.master)
+        self.norm_sq = torch.zeros((1,), dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    def fill_gradients(self, grads):
+        for n in self.names:
+            off, cnt = self.offsets[n]
+            self.grad[off: off + cnt].copy_(grads[n].reshape(-1))
+
+    def reduce_gradients(self):
+        """sum the bucket over the data-parallel ranks; returns the divisor that turns the sum into the mean."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+            return dist.get_world_size(self.group)
+        return 1
+
+    @torch.no_grad()
+    def step(self, grads):
+        self.fill_gradients(grads)
+        world = self.reduce_gradients()
+        self.step_count += 1
+        self.norm_sq.zero_()
+        K.sumsq(self.grad, out=self.norm_sq)
+        K.adamw_step(self.master, self.grad, self.exp_avg, self.exp_avg_sq, lr=self.lr, betas=self.betas, eps=self.eps,
+                     weight_decay=self.wd, step=self.step_count, grad_coef=1.0 / world, norm_sq=self.norm_sq,
+                     max_norm=self.max_norm)
+        for n, prm in zip(self.names, self.params):
+            off, cnt = self.offsets[n]
+            prm.data.copy_(self.master[off: off + cnt].view_as(prm))

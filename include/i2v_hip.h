@@ -396,6 +396,16 @@ int i2v_permute_rows_f16(const void* src, void* dst, int64_t batches, int32_t fr
 int i2v_zero_insert2x_f16(const void* src, void* dst, int64_t n_img, int32_t h, int32_t w, int32_t channels, i2v_stream_t stream);
 /* dst [n, h, w, C] = sums of the 2 x 2 blocks of src [n, 2h, 2w, C]: input gradient of Upsample2D's nearest-2x (unet:431-432). */
 int i2v_sum_pool2x_f16(const void* src, void* dst, int64_t n_img, int32_t h, int32_t w, int32_t channels, i2v_stream_t stream);
+/* Optimiser step of the adapter parameters (train_image_to_video.py:876-882: clip_grad_norm_, AdamW.step) over ONE flat fp32
+ * bucket (the same bucket the RCCL all-reduce sums): i2v_sumsq_f32 adds sum x^2 into *out (zeroed by the caller);
+ * i2v_adamw_f32 is torch.optim.AdamW's update (decoupled weight decay, bias correction with `step` >= 1) on
+ * g = grad * grad_coef * min(1, max_norm / (sqrt(*norm_sq) * grad_coef + 1e-6)): grad_coef folds 1 / loss_scale and the
+ * data-parallel mean, the clip coefficient is read from device memory (no host round trip); norm_sq = NULL or
+ * max_norm <= 0: no clipping. */
+int i2v_sumsq_f32(const float* x, int64_t n, float* out, i2v_stream_t stream);
+int i2v_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, float grad_coef, const float* norm_sq,
+                  float max_norm, i2v_stream_t stream);
 
 #ifdef __cplusplus
 }

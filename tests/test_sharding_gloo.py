@@ -99,3 +99,50 @@ def test_plan_groups_matches_shard_range():
         assert len(g) == 2 and all(len(x) == 4 for x in g)
         seen += [i for x in g for i in x]
     assert seen == list(range(64))
+
+
+# ------------------------------------------------------------------------------------------------ adapter-gradient all-reduce
+def _grad_worker(rank, world, port, q):
+    """the data-parallel half of the training step (the only per-step collective of the reference is
+    DDP's all-reduce of the adapter gradients): every rank fills the flat fp32 bucket with ITS gradients, one all-reduce
+    sums it, the update uses the mean.  On CPU only the host logic runs (the clip + AdamW kernels need the GPU)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from i2v_adapter_unofficial_amd.i2v_adapter import I2VAdapterTransformerBlock
+    from i2v_adapter_unofficial_amd.training import AdapterOptimizer
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([I2VAdapterTransformerBlock(32, 4, 8, cross_attention_dim=16) for _ in range(2)])
+    torch.manual_seed(0)
+    opt = AdapterOptimizer(Holder())
+    g = torch.Generator().manual_seed(10 + rank)
+    grads = {n: torch.randn(p.shape, generator=g) for n, p in zip(opt.names, opt.params)}
+    opt.fill_gradients(grads)
+    mine = opt.grad.clone()
+    div = opt.reduce_gradients()
+    q.put((rank, opt.names, mine, opt.grad.clone(), div, opt.master.numel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_adapter_gradient_allreduce_world_size_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, names0, mine0, red0, div0, n0), (_, names1, mine1, red1, div1, n1) = res
+    assert names0 == names1 and len(names0) == 2 * 3 and all(".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n for n in names0)
+    assert n0 == n1 == 2 * (32 * 32 + 32 * 32 + 32)            # to_q.weight, to_out.0.weight, to_out.0.bias per block
+    assert div0 == div1 == 2
+    assert not torch.equal(mine0, mine1)
+    assert torch.equal(red0, red1) and torch.allclose(red0, mine0 + mine1)

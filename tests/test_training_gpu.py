@@ -290,3 +290,78 @@ def test_transformer2d_backward(dev):
     compare(dx, _nchw_to_tok(x.grad), rel=GRAD_REL_TOL, name="Transformer2D backward: d / d input")
     for key, ref in zip(("i2v_adapter.to_q.weight", "i2v_adapter.to_out.0.weight", "i2v_adapter.to_out.0.bias"), train):
         compare(grads[key], ref.grad, rel=GRAD_REL_TOL, name=f"Transformer2D backward: {key}")
+
+
+# ---------------------------------------------------------------------------------------------- the whole training step
+def test_unet_training_step_vs_autograd(dev):
+    """The reference's step (train_image_to_video.py:839-884) on the reduced UNet (SD-1.5 topology, narrow channels): forward
+    with enable_cross_frame_attn=True, loss = MSE without the first frame, backward through every layer -- the gradient of
+    ALL 16 x 3 trainable adapter tensors (unet:979-1026) and the loss against torch autograd on the fp32 oracle UNet."""
+    from tests.parity import hip_unet_from_oracle, host_threads, oracle_small_unet, small_unet_inputs
+    from i2v_adapter_unofficial_amd.training import UNetAdapterTrainer
+    host_threads()
+    ou = oracle_small_unet(seed=77)
+    hu = hip_unet_from_oracle(ou, dev)
+    for prm in ou.parameters():
+        prm.requires_grad_(False)
+    ou.freeze_unet_params() if hasattr(ou, "freeze_unet_params") else None
+    train = {n: prm for n, prm in ou.named_parameters() if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n}
+    for prm in train.values():
+        prm.requires_grad_(True)
+    assert len(train) == 16 * 3
+    inp = small_unet_inputs(b=2, f=4, hw=16)
+    t = torch.tensor([481, 481])
+    g = torch.Generator().manual_seed(78)
+    target = h(torch.randn(inp["sample"].shape, generator=g))
+    pred = ou(inp["sample"], t, True, inp["ctx"]).sample
+    mask = torch.ones_like(pred)
+    mask[:, 0] = 0
+    loss = ((pred.float() - target) ** 2 * mask).sum() / mask.sum()
+    loss.backward()
+
+    tr = UNetAdapterTrainer(hu)
+    y = tr.forward(inp["sample"].half().to(dev), t.to(dev), inp["ctx"].half().to(dev))
+    got_pred = y[..., :4].float().cpu().permute(0, 3, 1, 2).reshape(pred.shape)
+    compare(got_pred, pred, rel=6e-3, name="training forward of the reduced UNet")
+    got_loss, grads = tr.backward(target.to(dev), loss_scale=2.0 ** 12)
+    assert abs(got_loss.item() - loss.item()) <= 5e-3 * abs(loss.item()), (got_loss.item(), loss.item())
+    assert set(grads) == set(train)
+    worst = 0.0
+    for name, prm in train.items():
+        err, scale = compare(grads[name], prm.grad, rel=2e-2, name=f"UNet step: d loss / d {name}")
+        worst = max(worst, err / scale)
+    print(f"UNet training step: loss {got_loss.item():.6f} vs {loss.item():.6f}, worst gradient error {worst:.2e} of max")
+
+
+def test_adamw_clip_matches_torch(dev):
+    """AdapterOptimizer (flat fp32 buckets, clip + AdamW in two kernels) against torch.optim.AdamW + clip_grad_norm_ on
+    the same parameters / gradients for three steps (train_image_to_video.py:716-724, 876-882 defaults)."""
+    from i2v_adapter_unofficial_amd.training import AdapterOptimizer
+    p = pkg()
+    m = p.I2VAdapterTransformerBlock(64, 4, 16, cross_attention_dim=32)
+
+    class Holder(torch.nn.Module):
+        def __init__(self, blk):
+            super().__init__()
+            self.encoder_hid_proj = None
+            self.blocks = torch.nn.ModuleList([blk])
+    hold = Holder(m).to(dev).half()
+    ref_params = [torch.nn.Parameter(prm.detach().float().cpu().clone()) for n, prm in hold.named_parameters()
+                  if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n]
+    ref_opt = torch.optim.AdamW(ref_params, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    opt = AdapterOptimizer(hold, lr=1e-3, max_grad_norm=1.0)
+    assert len(opt.names) == 3 == len(ref_params)
+    g = torch.Generator().manual_seed(1)
+    for step in range(3):
+        grads = {n: torch.randn(prm.shape, generator=g) * (3.0 if step == 0 else 0.01) for n, prm in zip(opt.names, ref_params)}
+        for prm, n in zip(ref_params, opt.names):
+            prm.grad = grads[n].clone()
+        torch.nn.utils.clip_grad_norm_(ref_params, 1.0)
+        ref_opt.step()
+        opt.step({n: v.to(dev) for n, v in grads.items()})
+    for n, prm in zip(opt.names, ref_params):
+        off, cnt = opt.offsets[n]
+        compare(opt.master[off: off + cnt].view_as(prm), prm, rel=1e-5, name=f"AdamW master {n}")
+    got = dict(hold.named_parameters())
+    for n, prm in zip(opt.names, ref_params):
+        assert torch.equal(got[n].detach().cpu(), prm.detach().half())
