@@ -232,6 +232,9 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
 
     // ---- S^T = K Q^T
     f32x4 sacc[NKT][QT];
+#ifdef I2V_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int krow = 32 * (kt >> 1) + 8 * (l15 >> 2) + 4 * (kt & 1) + (l15 & 3);
@@ -243,6 +246,9 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
       }
     }
 
+#ifdef I2V_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- online softmax with deferred max (per query column; keys over registers and the 4 lane groups)
     const int key_base = t * KVT;
     const bool first = t == 0;
@@ -309,6 +315,9 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
     }
 
     // ---- O^T += V^T P^T   (with SPARE, row `d` of V^T is all ones: O^T[d][q] accumulates the row sum)
+#ifdef I2V_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int s2 = 0; s2 < NS2; ++s2)
 #pragma unroll
@@ -318,6 +327,9 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
         for (int j = 0; j < QT; ++j) o[i][j] = mfma16x16x32(vf, pf[j][s2], o[i][j]);
       }
 
+#ifdef I2V_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (more) {
       if (partial && t + 2 == ntiles) mask_tail_v(t + 1);
       commit((t + 1) & 1);   // the other stage was last read in iteration t - 1 (closed by its barrier)

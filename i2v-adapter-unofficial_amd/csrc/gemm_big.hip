@@ -410,12 +410,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
   // D = W_frag * A_frag: lane owns 4 consecutive n of one row m.  For the transposed V^T store the operands are
   // swapped (D = A_frag * W_frag): lane owns 4 consecutive m (keys) of one channel n = an 8-byte run of a V^T row.
   auto mma = [&](const f16x8 (&wf)[NI], const f16x8 (&af)[MI]) {
+#ifdef I2V_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j)
         acc[i][j] = (STORE == I2V_STORE_VT_T) ? mfma16x16x32(af[j], wf[i], acc[i][j])
                                               : mfma16x16x32(wf[i], af[j], acc[i][j]);
+#ifdef I2V_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // LNF: row sums of x and x^2 from the A fragments.  A wave's MI row blocks are shared by the four N-waves that read
