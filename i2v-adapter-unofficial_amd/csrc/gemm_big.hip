@@ -1188,10 +1188,16 @@ int i2v_gemm_big_unsplit_ok(const i2v_gemm_params& p, int vec4) {
   return plan == 256 || plan == 128;
 }
 
+int i2v_gemm_alt_try(const i2v_gemm_params& p, hipStream_t s);   // gemm_alt.hip: short-K problems, alternating wave groups
+
 int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   int splits = 0, kps = 0;
   const int plan = big_plan(p, vec4, &splits, &kps);
   const int bn = big_bn(p);
+  if (bn == BIG_BN && (plan == 256 || plan == 128)) {
+    const int rc = i2v_gemm_alt_try(p, s);
+    if (rc != 0) return rc;
+  }
   if (bn == 256 && plan == 256) return launch_big_conv_bn<256, 256>(p, s);
   if (bn == 256 && plan == 128) return launch_big_conv_bn<128, 256>(p, s);
   if (bn == 128 && plan == 256) return launch_big_conv_bn<256, 128>(p, s);

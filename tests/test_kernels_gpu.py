@@ -708,3 +708,16 @@ def test_gemm_4wave_two_workgroups_per_cu_variant(dev):
                        env=dict(os.environ, I2V_GEMM_4W="1"), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_gemm_alternating_groups_opt_in_child_process(dev):
+    """I2V_GEMM_ALT=2 (read once per process) sends the short-K GEMM flavours to the alternating-groups kernel (gemm_alt.hip:
+    one wave group in the K loop of a 128-row tile while the other runs the previous tile's epilogue; measured slower, kept
+    as a switch): tools/alt_ab.py checks every flavour against a torch fp32 reference in a child process."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "alt_ab.py")], cwd=root, env=dict(os.environ, I2V_GEMM_ALT="2"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    errs = [float(m) for m in re.findall(r"rel err ([0-9.e+-]+)", r.stdout)]
+    assert len(errs) == 11 and max(errs) < 2e-3 and "finite False" not in r.stdout, r.stdout
