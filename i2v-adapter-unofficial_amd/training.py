@@ -49,8 +49,6 @@ class AdapterBlockTrainer:
     def __init__(self, block):
         if block.attn2 is None:
             raise NotImplementedError("the spatial block of the hot path has a text cross-attention")
-        if block.attn2.ip_num_tokens:
-            raise NotImplementedError("IP-Adapter image tokens in the training step are not implemented yet")
         self.block = block
         self._saved = None
 
@@ -69,6 +67,8 @@ class AdapterBlockTrainer:
             w_q2=w16(a2.to_q.weight), w_k2=w16(a2.to_k.weight), w_v2=w16(a2.to_v.weight),
             w_o2=w16(a2.to_out[0].weight), b_o2=w16(a2.to_out[0].bias),
             w1=w1, b1=b1, w2=w16(ff.net[2].weight), b2=w16(ff.net[2].bias),
+            w_k_ip=w16(a2.to_k_ip.weight) if a2.ip_num_tokens else None,
+            w_v_ip=w16(a2.to_v_ip.weight) if a2.ip_num_tokens else None,
             # dgrad operands: dX = dY W  ==  gemm(dY, w = W^T)
             w2_t=t(ff.net[2].weight), w1_t=w16(w1.t()), w_o2_t=t(a2.to_out[0].weight), w_q2_t=t(a2.to_q.weight),
             w_o1_t=t(a1.to_out[0].weight), w_oa_t=t(ad.to_out[0].weight),
@@ -77,8 +77,9 @@ class AdapterBlockTrainer:
             w_kva_t=w16(torch.cat([ad.to_k.weight.t(), ad.to_v.weight.t()], dim=1)))      # [dk0 | dv0] -> dn1[frame 0]
 
     @torch.no_grad()
-    def forward(self, x, n_img, L, num_frames, ctx_text):
-        """x [n_img * L, C] fp16 tokens, ctx_text [Bc, Lt, Dc] fp16; returns x3 [n_img * L, C]."""
+    def forward(self, x, n_img, L, num_frames, ctx_text, ctx_ip=None):
+        """x [n_img * L, C] fp16 tokens, ctx_text [Bc, Lt, Dc] (+ ctx_ip [Bc, 4, Dc]: the IP-Adapter image tokens, frozen
+        decoupled cross-attention of unet:1263-1279) fp16; returns x3 [n_img * L, C]."""
         b = self.block
         if n_img % num_frames != 0:
             raise ValueError(f"Batch size {n_img} must be divisible by the number of frames {num_frames}.")   # i2v:479-481
@@ -105,13 +106,28 @@ class AdapterBlockTrainer:
         group2 = n_img // bc
         o2 = K.attention(q2, kc, K.transpose_tokens(vc, lt), batch_q=n_img, lq=L, lk=lt, heads=heads, head_dim=d,
                          kv_group=group2)
+        ip = None
+        if ctx_ip is not None and b.attn2.ip_num_tokens:
+            li = ctx_ip.shape[1]
+            ip2d = ctx_ip.reshape(-1, dc).to(f16).contiguous()
+            kip, vip = K.gemm(ip2d, w["w_k_ip"]), K.gemm(ip2d, w["w_v_ip"])
+            vipt = K.transpose_tokens(vip, li)
+            kw = dict(batch_q=n_img, lq=L, lk=li, heads=heads, head_dim=d, kv_group=group2)
+            o_ip = K.attention(q2, kip, vipt, **kw)                                   # kept alone: its backward needs it
+            o_sum = torch.empty_like(o2)
+            K.copy3d(o2.view(1, -1, c), o_sum.view(1, -1, c))
+            K.attention(q2, kip, vipt, out=o_sum, accumulate=True, acc_scale=float(b.attn2.ip_scale), **kw)
+            ip = dict(k=kip, v=vip, o=o_ip, li=li, scale=float(b.attn2.ip_scale))
+            o2_text, o2 = o2, o_sum
+        else:
+            o2_text = o2
         x2 = K.gemm(o2, w["w_o2"], w["b_o2"], residual=x1)
         n3 = K.layernorm(x2, w["g3"], w["be3"], b.eps)
         h = K.gemm(n3, w["w1"], w["b1"])                                             # pre-activation, (value, gate) interleaved
         y = K.gemm(n3, w["w1"], w["b1"], epilogue=I2V_EPI_GEGLU)
         x3 = K.gemm(y, w["w2"], w["b2"], residual=x2)
         self._saved = dict(w=w, x=x, n1=n1, q1=q1, k1=k1, qa=qa, v1=v1, o1=o1, k0=k0, v0=v0, oa=oa, x1=x1, q2=q2, kc=kc,
-                           vc=vc, o2=o2, x2=x2, h=h, n_img=n_img, L=L, F=num_frames, lt=lt, group2=group2)
+                           vc=vc, o2=o2_text, ip=ip, x2=x2, h=h, n_img=n_img, L=L, F=num_frames, lt=lt, group2=group2)
         return x3
 
     @torch.no_grad()
@@ -133,7 +149,13 @@ class AdapterBlockTrainer:
         do2 = K.gemm(g2, w["w_o2_t"])
         dq2, _, _ = K.attention_bwd(s["q2"], s["kc"], s["vc"], s["o2"], do2, batch_q=n_img, lq=L, lk=s["lt"], heads=heads,
                                     head_dim=d, kv_group=s["group2"], need_dkv=False)
-        dn2 = K.gemm(dq2, w["w_q2_t"])
+        if s["ip"] is not None:       # + ip_scale * softmax(q K_ip^T) V_ip: the same query, frozen K / V; dq is linear in dO
+            ipb = s["ip"]
+            dq_ip, _, _ = K.attention_bwd(s["q2"], ipb["k"], ipb["v"], ipb["o"], do2, batch_q=n_img, lq=L, lk=ipb["li"],
+                                          heads=heads, head_dim=d, kv_group=s["group2"], need_dkv=False)
+            dn2 = K.gemm(dq2, w["w_q2_t"], residual=K.gemm(dq_ip, w["w_q2_t"], out_scale=ipb["scale"]))
+        else:
+            dn2 = K.gemm(dq2, w["w_q2_t"])
         g1 = K.layernorm_bwd(s["x1"], dn2, w["g2"], b.eps, add=g2)                    # dL/dx1
         # self-attention + cross-frame adapter attention (i2v:444-501)
         do1, doa = K.gemm(g1, w["w_o1_t"]), K.gemm(g1, w["w_oa_t"])
@@ -227,12 +249,12 @@ class Transformer2DTrainer:
         self.block = AdapterBlockTrainer(t2d.transformer_blocks[0])
 
     @torch.no_grad()
-    def forward(self, x, num_frames, ctx_text):
+    def forward(self, x, num_frames, ctx_text, ctx_ip=None):
         m, p = self.m, self.m.packed()
         n, hh, ww, c = x.shape
         nrm = K.groupnorm(x, p["g"], p["b"], m.groups, 1e-6)
         t = K.gemm(nrm.view(-1, c), p["wi"], p["bi"])
-        t = self.block.forward(t, n, hh * ww, num_frames, ctx_text)
+        t = self.block.forward(t, n, hh * ww, num_frames, ctx_text, ctx_ip)
         self.saved = x
         return K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c)).view(n, hh, ww, c)
 
@@ -360,8 +382,6 @@ class UNetAdapterTrainer:
                         up=UpsampleTrainer)
         self._names = names
         self._trainers = {}
-        if unet.encoder_hid_proj is not None:
-            raise NotImplementedError("IP-Adapter image tokens in the training step are not implemented yet")
 
     def _tr(self, kind, module):
         t = self._trainers.get(module)
@@ -370,8 +390,10 @@ class UNetAdapterTrainer:
         return t
 
     @torch.no_grad()
-    def forward(self, sample, timestep, encoder_hidden_states):
-        """sample (B, F, C, H, W) on the GPU; returns the prediction as tokens fp16 [B * F, H, W, 8] (4 channels + zeros)."""
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
+        """sample (B, F, C, H, W) on the GPU; added_cond_kwargs={"image_embeds": ...} when the IP-Adapter is installed (the
+        reference's training step passes them, train_image_to_video.py:843); returns the prediction as tokens fp16
+        [B * F, H, W, 8] (4 channels + zeros)."""
         u = self.unet
         b, F, c, hh, ww = sample.shape
         p = u.packed()
@@ -379,6 +401,7 @@ class UNetAdapterTrainer:
         t = t.to(device=sample.device, dtype=torch.float32).reshape(-1).expand(b).contiguous()
         temb_act = K.silu(u._embed_time(t))
         ctx = encoder_hidden_states.to(f16).contiguous()
+        ctx_ip = u._project_image_embeds(added_cond_kwargs)                      # unet:1346-1352 (frozen ImageProjection)
         rows = lambda r: K.gemm(temb_act, r.packed()["wt"], r.packed()["bt"])
         tape, res, res_ids = [], [], []
         x = K.conv3x3(K.nchw_to_tokens(sample.reshape(b * F, c, hh, ww), p["cin_pad"]), p["w_in"], p["b_in"])
@@ -390,7 +413,7 @@ class UNetAdapterTrainer:
             tape.append(("resnet", r, skip_id))
             if attn is not None:
                 a = self._tr("t2d", attn)
-                x = a.forward(x, F, ctx)
+                x = a.forward(x, F, ctx, ctx_ip)
                 tape.append(("t2d", a, self._names[attn]))
             if motion is not None:
                 mm = self._tr("motion", motion)
@@ -414,7 +437,7 @@ class UNetAdapterTrainer:
         x = layer(x, mid.resnets[0], None, None)
         for attn, resnet, motion in zip(mid.attentions, mid.resnets[1:], mid.motion_modules):
             a = self._tr("t2d", attn)
-            x = a.forward(x, F, ctx)
+            x = a.forward(x, F, ctx, ctx_ip)
             tape.append(("t2d", a, self._names[attn]))
             mm = self._tr("motion", motion)
             x = mm.forward(x, F)

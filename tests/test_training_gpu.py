@@ -293,15 +293,17 @@ def test_transformer2d_backward(dev):
 
 
 # ---------------------------------------------------------------------------------------------- the whole training step
-def test_unet_training_step_vs_autograd(dev):
+@pytest.mark.parametrize("ip", [False, True])
+def test_unet_training_step_vs_autograd(dev, ip):
     """The reference's step (train_image_to_video.py:839-884) on the reduced UNet (SD-1.5 topology, narrow channels): forward
     with enable_cross_frame_attn=True, loss = MSE without the first frame, backward through every layer -- the gradient of
     ALL 16 x 3 trainable adapter tensors (unet:979-1026) and the loss against torch autograd on the fp32 oracle UNet."""
     from tests.parity import hip_unet_from_oracle, host_threads, oracle_small_unet, small_unet_inputs
     from i2v_adapter_unofficial_amd.training import UNetAdapterTrainer
     host_threads()
-    ou = oracle_small_unet(seed=77)
-    hu = hip_unet_from_oracle(ou, dev)
+    from tests.parity import small_ip_state_dict
+    ou = oracle_small_unet(seed=77, ip=ip)
+    hu = hip_unet_from_oracle(ou, dev, ip_state_dict=small_ip_state_dict(ou) if ip else None)
     for prm in ou.parameters():
         prm.requires_grad_(False)
     ou.freeze_unet_params() if hasattr(ou, "freeze_unet_params") else None
@@ -313,14 +315,16 @@ def test_unet_training_step_vs_autograd(dev):
     t = torch.tensor([481, 481])
     g = torch.Generator().manual_seed(78)
     target = h(torch.randn(inp["sample"].shape, generator=g))
-    pred = ou(inp["sample"], t, True, inp["ctx"]).sample
+    added = {"image_embeds": inp["image_embeds"]} if ip else None
+    added_d = {"image_embeds": inp["image_embeds"].half().to(dev)} if ip else None
+    pred = ou(inp["sample"], t, True, inp["ctx"], added_cond_kwargs=added).sample
     mask = torch.ones_like(pred)
     mask[:, 0] = 0
     loss = ((pred.float() - target) ** 2 * mask).sum() / mask.sum()
     loss.backward()
 
     tr = UNetAdapterTrainer(hu)
-    y = tr.forward(inp["sample"].half().to(dev), t.to(dev), inp["ctx"].half().to(dev))
+    y = tr.forward(inp["sample"].half().to(dev), t.to(dev), inp["ctx"].half().to(dev), added_cond_kwargs=added_d)
     got_pred = y[..., :4].float().cpu().permute(0, 3, 1, 2).reshape(pred.shape)
     compare(got_pred, pred, rel=6e-3, name="training forward of the reduced UNet")
     got_loss, grads = tr.backward(target.to(dev), loss_scale=2.0 ** 12)
