@@ -105,79 +105,102 @@ __global__ __launch_bounds__(256) void attn_lse_kernel(const i2v_attn_params p, 
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-template <int KS, int DT>
+// U = 16-row tiles per wave (1 or 2): the K / V / K^T fragments a key block needs are fetched once and used for both of a
+// wave's query tiles (the fragments come straight from L2: no LDS staging yet, so loads per FLOP are what there is to save)
+template <int KS, int DT, int U>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const i2v_attn_bwd_params p, const float c) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
   const int h = blockIdx.y, bq = blockIdx.z, bkv = bq / p.kv_group, d = p.head_dim;
-  const int q = blockIdx.x * 64 + wave * 16 + l15;
-  const bool qok = q < p.lq;
+  const int q0 = blockIdx.x * (64 * U) + wave * (16 * U);
   const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
   const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
   const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
   const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
   const f16* KT = reinterpret_cast<const f16*>(p.kt) + (int64_t)bkv * p.kt_batch_stride + (int64_t)h * d * p.kt_row_stride;
-  f16x8 qf[KS], dof[KS];
-  row_frags<KS>(qf, Q + (int64_t)q * p.q_row_stride, qok, g, d);
-  row_frags<KS>(dof, DO + (int64_t)q * p.do_row_stride, qok, g, d);
-  const int64_t stat = ((int64_t)bq * p.heads + h) * p.lq + q;
-  const float lse_q = qok ? p.lse[stat] : 0.f, del_q = qok ? p.delta[stat] : 0.f;
-  f32x4 acc[DT];
+  f16x8 qf[U][KS], dof[U][KS];
+  float lse_q[U], del_q[U];
+  f32x4 acc[U][DT];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < U; ++u) {
+    const int q = q0 + 16 * u + l15;
+    const bool qok = q < p.lq;
+    row_frags<KS>(qf[u], Q + (int64_t)q * p.q_row_stride, qok, g, d);
+    row_frags<KS>(dof[u], DO + (int64_t)q * p.do_row_stride, qok, g, d);
+    const int64_t stat = ((int64_t)bq * p.heads + h) * p.lq + (qok ? q : 0);
+    lse_q[u] = qok ? p.lse[stat] : 0.f;
+    del_q[u] = qok ? p.delta[stat] : 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) acc[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int lk8 = (p.lk + 7) & ~7;     // K^T rows are zero-filled up to the next multiple of 8 keys (i2v_transpose_f16)
   for (int kb = 0; kb < p.lk; kb += 32) {
-    float ds[2][4];
+    float ds[U][2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int key = kb + perm_row(l15, t);
       f16x8 kf[KS], vf[KS];
       row_frags<KS>(kf, Kg + (int64_t)key * p.k_row_stride, key < p.lk, g, d);
       row_frags<KS>(vf, Vg + (int64_t)key * p.v_row_stride, key < p.lk, g, d);
-      const f32x4 s = chain<KS>(kf, qf);     // S^T : rows = keys kb + 8 g + 4 t + r, column = query l15
-      const f32x4 dp = chain<KS>(vf, dof);   // dP^T
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pr = (kb + 8 * g + 4 * t + r < p.lk) ? __builtin_amdgcn_exp2f(c * s[r] - lse_q) : 0.f;
-        ds[t][r] = pr * (dp[r] - del_q);
+      for (int u = 0; u < U; ++u) {
+        const f32x4 s = chain<KS>(kf, qf[u]);     // S^T : rows = keys kb + 8 g + 4 t + r, column = query l15
+        const f32x4 dp = chain<KS>(vf, dof[u]);   // dP^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = (kb + 8 * g + 4 * t + r < p.lk) ? __builtin_amdgcn_exp2f(c * s[r] - lse_q[u]) : 0.f;
+          ds[u][t][r] = pr * (dp[r] - del_q[u]);
+        }
       }
     }
-    const f16x8 dsb = pack8(ds[0], ds[1]);   // B operand: keys kb + 8 g .. + 7 of query l15
+    f16x8 dsb[U];                                  // B operands: keys kb + 8 g .. + 7 of query l15
+#pragma unroll
+    for (int u = 0; u < U; ++u) dsb[u] = pack8(ds[u][0], ds[u][1]);
     const int kcol = kb + 8 * g;
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
       const int row = 16 * i + l15;          // channel of the head
       const f16x8 a = (row < d && kcol < lk8) ? ld_global_16B(KT + (int64_t)row * p.kt_row_stride + kcol) : zero8();
-      acc[i] = mfma16x16x32(a, dsb, acc[i]);   // dQ^T: rows = channels 16 i + 4 g + r, column = query l15
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u][i] = mfma16x16x32(a, dsb[u], acc[u][i]);   // dQ^T: rows = channels, column = query
     }
   }
-  if (!qok) return;
-  f16* DQ = reinterpret_cast<f16*>(p.dq) + (int64_t)bq * p.dq_batch_stride + (int64_t)q * p.dq_row_stride + h * d;
 #pragma unroll
-  for (int i = 0; i < DT; ++i) {
-    const int dd = 16 * i + 4 * g;
-    if (dd >= d) continue;
-    f16x4 o;
+  for (int u = 0; u < U; ++u) {
+    const int q = q0 + 16 * u + l15;
+    if (q >= p.lq) continue;
+    f16* DQ = reinterpret_cast<f16*>(p.dq) + (int64_t)bq * p.dq_batch_stride + (int64_t)q * p.dq_row_stride + h * d;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][r] * p.scale);
-    *reinterpret_cast<f16x4*>(DQ + dd) = o;
+    for (int i = 0; i < DT; ++i) {
+      const int dd = 16 * i + 4 * g;
+      if (dd >= d) continue;
+      f16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[u][i][r] * p.scale);
+      *reinterpret_cast<f16x4*>(DQ + dd) = o;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int KS, int DT>
+template <int KS, int DT, int U>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_params p, const float c) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
   const int h = blockIdx.y, bkv = blockIdx.z, d = p.head_dim;
-  const int key = blockIdx.x * 64 + wave * 16 + l15;
-  const bool kok = key < p.lk;
+  const int key0 = blockIdx.x * (64 * U) + wave * (16 * U);
   const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
   const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
-  f16x8 kf[KS], vf[KS];
-  row_frags<KS>(kf, Kg + (int64_t)key * p.k_row_stride, kok, g, d);
-  row_frags<KS>(vf, Vg + (int64_t)key * p.v_row_stride, kok, g, d);
-  f32x4 dk[DT], dv[DT];
+  f16x8 kf[U][KS], vf[U][KS];
+  f32x4 dk[U][DT], dv[U][DT];
+  bool kok[U];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < U; ++u) {
+    const int key = key0 + 16 * u + l15;
+    kok[u] = key < p.lk;
+    row_frags<KS>(kf[u], Kg + (int64_t)key * p.k_row_stride, kok[u], g, d);
+    row_frags<KS>(vf[u], Vg + (int64_t)key * p.v_row_stride, kok[u], g, d);
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dk[u][i] = dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int f = 0; f < p.kv_group; ++f) {           // every batch entry that attends to this K / V
     const int bq = bkv * p.kv_group + f;
     const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
@@ -188,25 +211,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_pa
     const float* del = p.delta + ((int64_t)bq * p.heads + h) * p.lq;
     const int lq8 = (p.lq + 7) & ~7;                // Q^T / dO^T rows are zero-filled up to the next multiple of 8 queries
     for (int qb = 0; qb < p.lq; qb += 32) {
-      float pv[2][4], ds[2][4];
+      float pv[U][2][4], ds[U][2][4];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int qrow = qb + perm_row(l15, t);
         f16x8 qa[KS], da[KS];
         row_frags<KS>(qa, Q + (int64_t)qrow * p.q_row_stride, qrow < p.lq, g, d);
         row_frags<KS>(da, DO + (int64_t)qrow * p.do_row_stride, qrow < p.lq, g, d);
-        const f32x4 s = chain<KS>(qa, kf);     // S : rows = queries qb + 8 g + 4 t + r, column = key l15
-        const f32x4 dp = chain<KS>(da, vf);    // dP
+        float l4[4], d4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qi = qb + 8 * g + 4 * t + r;
-          const bool ok = kok && qi < p.lq;      // (short sequences: the frames of one pixel in the motion modules)
-          const float pr = ok ? __builtin_amdgcn_exp2f(c * s[r] - lse[qi < p.lq ? qi : 0]) : 0.f;
-          pv[t][r] = pr;
-          ds[t][r] = ok ? pr * (dp[r] - del[qi < p.lq ? qi : 0]) : 0.f;
+          l4[r] = lse[qi < p.lq ? qi : 0];
+          d4[r] = del[qi < p.lq ? qi : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const f32x4 s = chain<KS>(qa, kf[u]);     // S : rows = queries qb + 8 g + 4 t + r, column = key l15
+          const f32x4 dp = chain<KS>(da, vf[u]);    // dP
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = kok[u] && (qb + 8 * g + 4 * t + r < p.lq);   // (short sequences: the frames of one pixel)
+            const float pr = ok ? __builtin_amdgcn_exp2f(c * s[r] - l4[r]) : 0.f;
+            pv[u][t][r] = pr;
+            ds[u][t][r] = ok ? pr * (dp[r] - d4[r]) : 0.f;
+          }
         }
       }
-      const f16x8 pb = pack8(pv[0], pv[1]), dsb = pack8(ds[0], ds[1]);   // B operands: queries qb + 8 g .. + 7, key l15
+      f16x8 pb[U], dsb[U];                          // B operands: queries qb + 8 g .. + 7, key l15
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        pb[u] = pack8(pv[u][0], pv[u][1]);
+        dsb[u] = pack8(ds[u][0], ds[u][1]);
+      }
       const int qcol = qb + 8 * g;
 #pragma unroll
       for (int i = 0; i < DT; ++i) {
@@ -214,26 +251,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_pa
         const bool in = row < d && qcol < lq8;
         const f16x8 a1 = in ? ld_global_16B(DOT + (int64_t)row * p.dot_row_stride + qcol) : zero8();
         const f16x8 a2 = in ? ld_global_16B(QT + (int64_t)row * p.qt_row_stride + qcol) : zero8();
-        dv[i] = mfma16x16x32(a1, pb, dv[i]);    // dV^T : rows = channels, column = key l15
-        dk[i] = mfma16x16x32(a2, dsb, dk[i]);   // dK^T
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          dv[u][i] = mfma16x16x32(a1, pb[u], dv[u][i]);    // dV^T : rows = channels, column = key l15
+          dk[u][i] = mfma16x16x32(a2, dsb[u], dk[u][i]);   // dK^T
+        }
       }
     }
   }
-  if (!kok) return;
-  f16* DK = reinterpret_cast<f16*>(p.dk) + (int64_t)bkv * p.dk_batch_stride + (int64_t)key * p.dk_row_stride + h * d;
-  f16* DV = reinterpret_cast<f16*>(p.dv) + (int64_t)bkv * p.dv_batch_stride + (int64_t)key * p.dv_row_stride + h * d;
 #pragma unroll
-  for (int i = 0; i < DT; ++i) {
-    const int dd = 16 * i + 4 * g;
-    if (dd >= d) continue;
-    f16x4 ok4, ov4;
+  for (int u = 0; u < U; ++u) {
+    if (!kok[u]) continue;
+    const int key = key0 + 16 * u + l15;
+    f16* DK = reinterpret_cast<f16*>(p.dk) + (int64_t)bkv * p.dk_batch_stride + (int64_t)key * p.dk_row_stride + h * d;
+    f16* DV = reinterpret_cast<f16*>(p.dv) + (int64_t)bkv * p.dv_batch_stride + (int64_t)key * p.dv_row_stride + h * d;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ok4[r] = (f16)(dk[i][r] * p.scale);
-      ov4[r] = (f16)dv[i][r];
+    for (int i = 0; i < DT; ++i) {
+      const int dd = 16 * i + 4 * g;
+      if (dd >= d) continue;
+      f16x4 ok4, ov4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ok4[r] = (f16)(dk[u][i][r] * p.scale);
+        ov4[r] = (f16)dv[u][i][r];
+      }
+      *reinterpret_cast<f16x4*>(DK + dd) = ok4;
+      *reinterpret_cast<f16x4*>(DV + dd) = ov4;
     }
-    *reinterpret_cast<f16x4*>(DK + dd) = ok4;
-    *reinterpret_cast<f16x4*>(DV + dd) = ov4;
   }
 }
 
@@ -519,12 +563,17 @@ inline int ew_grid(int64_t n) {
 template <int KS, int DT>
 int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
   const float c = p.scale * LOG2E;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DT>), dim3((unsigned)i2v_cdiv(p.lq, 64), p.heads, p.batch_q), dim3(256), 0, s, p, c);
+  // two 16-row tiles per wave where the sequence is long enough to still fill the chip (halves the fragment loads per FLOP)
+  const bool two_q = p.lq >= 512 && DT <= 6, two_k = p.lk >= 512 && DT <= 6;
+  const dim3 gq((unsigned)i2v_cdiv(p.lq, two_q ? 128 : 64), p.heads, p.batch_q);
+  if (two_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DT, 2>), gq, dim3(256), 0, s, p, c);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DT, 1>), gq, dim3(256), 0, s, p, c);
   int rc = i2v_check_launch("i2v_attention_bwd_f16(dQ)");
   if (rc < 0) return rc;
   if (p.dk != nullptr) {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT>), dim3((unsigned)i2v_cdiv(p.lk, 64), p.heads, p.batch_q / p.kv_group),
-                       dim3(256), 0, s, p, c);
+    const dim3 gk((unsigned)i2v_cdiv(p.lk, two_k ? 128 : 64), p.heads, p.batch_q / p.kv_group);
+    if (two_k) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 1>), gk, dim3(256), 0, s, p, c);
     rc = i2v_check_launch("i2v_attention_bwd_f16(dK, dV)");
   }
   return rc;

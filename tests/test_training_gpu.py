@@ -25,10 +25,12 @@ def h(t):
 
 
 @pytest.mark.parametrize("d,lq,lk,group,need_dkv", [(40, 256, 256, 1, True), (40, 128, 128, 4, True), (80, 64, 64, 2, True),
-                                                    (160, 64, 64, 1, True), (40, 96, 77, 2, False), (64, 32, 160, 1, True)])
+                                                    (160, 64, 64, 1, True), (40, 96, 77, 2, False), (64, 32, 160, 1, True),
+                                                    (40, 512, 640, 1, True), (80, 576, 512, 2, True)])
 def test_attention_backward_vs_autograd(dev, d, lq, lk, group, need_dkv):
     """dQ, dK, dV of softmax(q k^T / sqrt d) v against autograd; kv_group > 1 = several query batches share one K / V (the
-    cross-frame attention: dK / dV are the sums over the group); lk = 77 is the text context (dQ only, masked tail)."""
+    cross-frame attention: dK / dV are the sums over the group); lk = 77 is the text context (dQ only, masked tail);
+    sequences >= 512 take the two-tiles-per-wave forms of both sweeps."""
     K = pkg().kernels
     heads, bkv = 2, 2
     bq, C = bkv * group, heads * d
