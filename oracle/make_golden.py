@@ -243,13 +243,49 @@ def oracle_goldens():
         print("oracle", k, tuple(v.shape))
 
 
+def ref_gradient_goldens():
+    """Gradients of reference-authored code (round 3, pins the training step's backward -- SURVEY 8 f4 -- to something other
+    than this repo's own oracle): torch autograd through the reference's `BasicTransformerBlock`
+    (src/modules/attention.py:64-77: x = attn1(LN1(x)) + x; x = attn2(LN2(x), ctx) + x) on the weights and inputs of the
+    committed ref_transformer_block_* fixtures (re-created from the same seeds and checked against their `y`), for a given
+    output gradient dy: d / d x (LayerNorm backward, both attention backwards, the Linear dgrads, the residual paths) and the
+    parameter gradients of attn1.to_out (a weight gradient dY^T X and a bias column sum, at the position where the I2V
+    adapter's to_out adds, i2v:494).  Only dy and the gradients are stored."""
+    from safetensors.torch import load_file
+    sys.path.insert(0, REFERENCE)
+    from src.modules.attention import BasicTransformerBlock
+    for name, (c, dctx, d, heads, batch, tokens, lctx) in {
+            "d40": (320, 768, 40, 8, 2, 96, 77), "d8": (64, 96, 8, 8, 3, 40, 7)}.items():
+        torch.manual_seed(1000 + c)
+        blk = BasicTransformerBlock(c, dctx, head_dim=d, num_heads=heads).eval()
+        with torch.no_grad():
+            for n, p in blk.named_parameters():
+                if "norm" in n:
+                    p.add_(0.2 * torch.randn(p.shape))
+                p.copy_(h(p))
+        g = torch.Generator().manual_seed(23)
+        x, ctx = h(torch.randn(batch, tokens, c, generator=g)), h(torch.randn(batch, lctx, dctx, generator=g))
+        x.requires_grad_()
+        dy = h(torch.randn(batch, tokens, c, generator=torch.Generator().manual_seed(31)))
+        y = blk(x, ctx)
+        old = load_file(os.path.join(OUT, f"ref_transformer_block_{name}.safetensors"))
+        assert torch.equal(y.detach(), old["y"]) and torch.equal(x.detach(), old["x"]), "not the committed fixture's block"
+        y.backward(dy)
+        t = {"dy": dy, "dx": x.grad.detach(), "d_attn1_to_out_weight": blk.attn1.to_out[0].weight.grad.detach(),
+             "d_attn1_to_out_bias": blk.attn1.to_out[0].bias.grad.detach()}
+        save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(OUT, f"ref_grads_transformer_block_{name}.safetensors"),
+                  metadata=dict(heads=str(heads), head_dim=str(d)))
+        print("wrote ref_grads_transformer_block_" + name, tuple(x.grad.shape))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if os.path.isdir(REFERENCE):
         if "--only-new" not in sys.argv:
             ref_attention_goldens()
             ref_block_goldens()
-        ref_temporal_and_resblock_goldens()
+            ref_temporal_and_resblock_goldens()
+        ref_gradient_goldens()
     else:
         print("reference not present: keeping the committed ref_attention_* fixtures")
     if "--only-new" not in sys.argv:

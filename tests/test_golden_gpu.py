@@ -167,3 +167,40 @@ def test_hip_block_vs_committed_oracle_outputs(dev):
     compare(y, gold["block_y_cross_frame"], name="block_y_cross_frame")
     y = m(x.to(dev), enable_cross_frame_attn=False, encoder_hidden_states=ctx.to(dev))
     compare(y, gold["block_y_plain"], name="block_y_plain")
+
+
+@pytest.mark.parametrize("name", ["d40", "d8"])
+def test_hip_block_backward_vs_reference_autograd(dev, name):
+    """The training step's block backward (training.AdapterBlockTrainer: LayerNorm backward, MFMA attention backward, Linear
+    dgrad / wgrad, bias sums) against torch autograd through the REFERENCE-AUTHORED BasicTransformerBlock
+    (src/modules/attention.py:64-77; tests/golden/ref_grads_transformer_block_*: weights and inputs of the forward fixture,
+    an output gradient dy, d / d x and the gradients of attn1.to_out).  The HIP block reproduces that block with its
+    feed-forward off and its adapter = a copy of attn1's q / k / v with a ZERO to_out and one frame per clip (the cross-frame
+    attention is then attn1 itself and contributes nothing forward): its input gradient must equal the reference's, and the
+    gradients it reports for i2v_adapter.to_out must equal the reference's for attn1.to_out (same dY, same attention output)."""
+    import i2v_adapter_unofficial_amd as pkg
+    from i2v_adapter_unofficial_amd.training import AdapterBlockTrainer
+    from tests.test_oracle import load_ref_block_into
+    fwd_path = os.path.join(GOLD, f"ref_transformer_block_{name}.safetensors")
+    t, gr = load_file(fwd_path), load_file(os.path.join(GOLD, f"ref_grads_transformer_block_{name}.safetensors"))
+    with safe_open(fwd_path, framework="pt") as f:
+        meta = f.metadata()
+    heads, d = int(meta["heads"]), int(meta["head_dim"])
+    c = heads * d
+    torch.manual_seed(0)
+    blk = load_ref_block_into(pkg.I2VAdapterTransformerBlock(c, heads, d, cross_attention_dim=t["ctx"].shape[-1]), t)
+    with torch.no_grad():
+        blk.i2v_adapter.to_q.weight.copy_(blk.attn1.to_q.weight)
+        blk.i2v_adapter.to_k.weight.copy_(blk.attn1.to_k.weight)
+        blk.i2v_adapter.to_v.weight.copy_(blk.attn1.to_v.weight)
+        blk.i2v_adapter.to_out[0].weight.zero_()
+        blk.i2v_adapter.to_out[0].bias.zero_()
+    blk = blk.to(dev).half().eval()
+    n_img, L, _ = t["x"].shape
+    tr = AdapterBlockTrainer(blk)
+    y = tr.forward(t["x"].half().to(dev).view(-1, c), n_img, L, 1, t["ctx"].half().to(dev))
+    compare(y.view(n_img, L, c), t["y"], rel=1.5e-3, name=f"training forward vs reference block {name}")
+    grads = tr.backward(gr["dy"].half().to(dev).view(-1, c), loss_scale=1.0)
+    compare(grads["hidden_states"].view(n_img, L, c), gr["dx"], rel=1.8e-3, name=f"d / d x vs reference autograd {name}")
+    compare(grads["i2v_adapter.to_out.0.weight"], gr["d_attn1_to_out_weight"], rel=1.5e-3, name=f"to_out weight gradient vs reference {name}")
+    compare(grads["i2v_adapter.to_out.0.bias"], gr["d_attn1_to_out_bias"], rel=1e-3, name=f"to_out bias gradient vs reference {name}")
