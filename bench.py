@@ -256,6 +256,62 @@ def launch_ranks(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
+def train_bench(args, model, ip, rank, world, dev):
+    """`--train`: the reference's training step (src/train_image_to_video.py:839-884) for the adapter parameters, one clip
+    per rank per step (data parallel: the gradient bucket is summed with ONE RCCL all-reduce per step), W + K steps timed
+    as the inference bench times its steps.  Prints one JSON line with the contract's fields; the metric is NOT BASELINE's."""
+    import torch.distributed as dist
+    from i2v_adapter_unofficial_amd.training import AdapterOptimizer, UNetAdapterTrainer
+    F, lat = args.frames, args.size // 8
+    g = torch.Generator().manual_seed(100 + rank)                   # every rank trains on its own clip
+    x = torch.randn(1, F, 4, lat, lat, generator=g).half().to(dev)
+    noise = torch.randn(1, F, 4, lat, lat, generator=g).to(dev)
+    ctx = torch.randn(1, 77, 768, generator=g).half().to(dev)
+    added = {"image_embeds": torch.randn(1, 1024, generator=g).half().to(dev)} if ip else None
+    t = torch.tensor([481], device=dev)
+    trainer, opt = UNetAdapterTrainer(model), AdapterOptimizer(model, lr=1e-5)
+
+    def step():
+        trainer.forward(x, t, ctx, added_cond_kwargs=added)
+        loss, grads = trainer.backward(noise, loss_scale=2.0 ** 12)
+        opt.step(grads)
+        return loss
+    for _ in range(max(1, args.warmup)):
+        loss0 = step()
+    sync = torch.cuda.synchronize
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    el = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    if rank == 0:
+        n_train = opt.master.numel()
+        print(json.dumps({
+            "metric": f"adapter training steps/sec @ {F}fx{args.size}x{args.size} SD1.5+I2V-Adapter (one clip per GPU per step)",
+            "value": world * args.steps / elapsed, "unit": "clip-steps/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ranks_in_rccl_group": (dist.get_world_size() if world > 1 else 1), "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": ("adapter training step of src/train_image_to_video.py:839-884 (forward, MSE without the "
+                                    "first frame, backward through the frozen UNet, all-reduce of the adapter gradients, "
+                                    f"clip + AdamW), SD-1.5 width, {F}f x {args.size}x{args.size}, IP {'on' if ip else 'off'}, one clip "
+                                    "per rank; NOT the BASELINE metric"),
+                       "trainable_parameters": n_train, "allreduce_bytes_per_step": 4 * n_train if world > 1 else 0,
+                       "loss_first": float(loss0), "loss_last": float(loss), "finite": bool(torch.isfinite(loss).item())},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def source_stamp():
     """hash of the kernel sources the running library was built from (csrc/*.hip, *.h, include/i2v_hip.h): recorded next
     to PMC traffic figures so that a figure measured on another binary is never attached to this one"""
@@ -287,6 +343,9 @@ def main():
                     help="the K-step timed window is repeated this many times (each bracketed by barrier + synchronize); "
                          "the line reports the MEDIAN window, and min / max as `window_ms_per_step`")
     ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (median)")
+    ap.add_argument("--train", action="store_true",
+                    help="time the ADAPTER TRAINING STEP instead (SURVEY 8 f4: forward + backward + one all-reduce of the "
+                         "adapter gradients + clip + AdamW; one clip per rank per step) -- not the BASELINE metric")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-rank plumbing on a box WITHOUT GPUs: launcher, rendezvous, gloo group, flat "
                          "weight broadcast, pair sharding, timed loop with a stub step, MAX all-reduce, JSON line "
@@ -327,6 +386,8 @@ def main():
         if rank == 0:
             print(f"# broadcast {nbytes / 1e9:.2f} GB of weights over RCCL", file=sys.stderr)
     t_built = time.time()
+    if args.train:
+        return train_bench(args, model, ip, rank, world, dev)
 
     # ---- this rank's samples (static block partition, no per-step collective)
     F, h_lat, B = args.frames, args.size // 8, args.batch
