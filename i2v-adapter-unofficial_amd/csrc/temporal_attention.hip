@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void tattn_kernel(const i2v_tattn_params p, co
 // whole rows) and V^T block ([C][vt_ld], contiguous) are copied to LDS with 16 bytes per lane over whole rows, the
 // waves take their heads' fragments from LDS (row strides padded so the 16 rows of a fragment read start on distinct
 // bank groups), and O goes back through LDS for whole-row 16-byte stores.
-template <int DQK, int DPV>
+template <int DQK, int DPV, int PF>
 __global__ __launch_bounds__(256) void tattn_lds_kernel(const i2v_tattn_params p, const float scale_log2) {
   constexpr int KSTEPS = DQK / 32, DT = DPV / 16;
   extern __shared__ __attribute__((aligned(16))) f16 tsm[];
@@ -149,17 +149,43 @@ __global__ __launch_bounds__(256) void tattn_lds_kernel(const i2v_tattn_params p
   const f16* __restrict__ Vb = reinterpret_cast<const f16*>(p.vt);
   f16* __restrict__ Ob = reinterpret_cast<f16*>(p.o);
 
+  // The NEXT pixel's q / k / V^T chunks are fetched into registers while this pixel is computed and stored (one pixel's
+  // phases -- load, compute, store -- used to run in series per workgroup: 3.4 TB/s); PF = chunks per thread and operand,
+  // sized by the host for this shape (F * C / 8 and C * vt_ld / 8 over 256 threads).
+  f16x8 rq[PF], rk[PF], rv[PF];
+  auto fetch = [&](int pix) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int t = tid + 256 * i;
+      rq[i] = rk[i] = rv[i] = zero8();
+      if (t < F * cpr) {
+        const int f = t / cpr, c = t - f * cpr;
+        rq[i] = ld_global_16B(Qb + ((int64_t)pix * F + f) * p.q_row_stride + c * 8);
+        rk[i] = ld_global_16B(Kb + ((int64_t)pix * F + f) * p.k_row_stride + c * 8);
+      }
+      if (t < C * vpr) rv[i] = ld_global_16B(Vb + ((int64_t)pix * C + t / vpr) * p.vt_ld + (t % vpr) * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int t = tid + 256 * i;
+      if (t < F * cpr) {
+        const int f = t / cpr, c = t - f * cpr;
+        *reinterpret_cast<f16x8*>(sq + f * RS + c * 8) = rq[i];
+        *reinterpret_cast<f16x8*>(sk + f * RS + c * 8) = rk[i];
+      }
+      if (t < C * vpr) *reinterpret_cast<f16x8*>(sv + (t / vpr) * VS + (t % vpr) * 8) = rv[i];
+    }
+  };
+  if ((int)blockIdx.x < p.n_pixels) {
+    fetch(blockIdx.x);
+    commit();
+  }
+  __syncthreads();
   for (int pix = blockIdx.x; pix < p.n_pixels; pix += gridDim.x) {
-    for (int t = tid; t < F * cpr; t += 256) {
-      const int f = t / cpr, c = t - f * cpr;
-      *reinterpret_cast<f16x8*>(sq + f * RS + c * 8) = ld_global_16B(Qb + ((int64_t)pix * F + f) * p.q_row_stride + c * 8);
-      *reinterpret_cast<f16x8*>(sk + f * RS + c * 8) = ld_global_16B(Kb + ((int64_t)pix * F + f) * p.k_row_stride + c * 8);
-    }
-    for (int t = tid; t < C * vpr; t += 256) {
-      const int ch = t / vpr, c = t - ch * vpr;
-      *reinterpret_cast<f16x8*>(sv + ch * VS + c * 8) = ld_global_16B(Vb + ((int64_t)pix * C + ch) * p.vt_ld + c * 8);
-    }
-    __syncthreads();
+    const int next = pix + (int)gridDim.x;
+    if (next < p.n_pixels) fetch(next);
 
     for (int h = wave; h < p.heads; h += 4) {
       f32x4 sacc[2];
@@ -223,13 +249,14 @@ __global__ __launch_bounds__(256) void tattn_lds_kernel(const i2v_tattn_params p
         }
       }
     }
-    __syncthreads();
+    __syncthreads();      // every wave has read this pixel's q / k / V^T and written its part of `so`
     for (int t = tid; t < F * cpr; t += 256) {
       const int f = t / cpr, c = t - f * cpr;
       *reinterpret_cast<f16x8*>(Ob + ((int64_t)pix * F + f) * p.o_row_stride + c * 8) =
           *reinterpret_cast<const f16x8*>(so + f * RS + c * 8);
     }
-    // the next iteration's first barrier orders these reads of `so` before its writes
+    if (next < p.n_pixels) commit();
+    __syncthreads();      // the next pixel's operands are in LDS; `so` has been read
   }
 }
 
@@ -243,7 +270,15 @@ int launch_t(const i2v_tattn_params& p, hipStream_t s) {
   if (!lds_off && p.frames <= 16 && lds <= 64 * 1024 && p.o_row_stride % 8 == 0 &&
       (reinterpret_cast<uintptr_t>(p.o) & 15) == 0) {
     int64_t blocks = p.n_pixels < 256 * 8 ? p.n_pixels : 256 * 8;
-    hipLaunchKernelGGL((tattn_lds_kernel<DQK, DPV>), dim3((unsigned)blocks), dim3(256), lds, s, p, scale_log2);
+    const int chunks = (C / 8) * (p.frames > p.vt_ld ? p.frames : p.vt_ld);   // max(F * C / 8, C * vt_ld / 8)
+    if (chunks <= 256)
+      hipLaunchKernelGGL((tattn_lds_kernel<DQK, DPV, 1>), dim3((unsigned)blocks), dim3(256), lds, s, p, scale_log2);
+    else if (chunks <= 512)
+      hipLaunchKernelGGL((tattn_lds_kernel<DQK, DPV, 2>), dim3((unsigned)blocks), dim3(256), lds, s, p, scale_log2);
+    else if (chunks <= 768)
+      hipLaunchKernelGGL((tattn_lds_kernel<DQK, DPV, 3>), dim3((unsigned)blocks), dim3(256), lds, s, p, scale_log2);
+    else
+      hipLaunchKernelGGL((tattn_lds_kernel<DQK, DPV, 4>), dim3((unsigned)blocks), dim3(256), lds, s, p, scale_log2);
     return i2v_check_launch("i2v_temporal_attention_f16");
   }
   const int64_t items64 = (int64_t)p.n_pixels * p.heads;
