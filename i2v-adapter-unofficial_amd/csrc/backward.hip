@@ -20,6 +20,8 @@
 // (k = 8 (l >> 4) + 0..7, col = l & 15), D lane (row = 4 (l >> 4) + r, col = l & 15).  Rows of a 32-row block are
 // dealt to the two 16-row MFMAs so that D rows 4 g + r of tiles t = 0, 1 are block rows 8 g + 4 t + r: a lane's 8
 // values are block rows 8 g .. 8 g + 7 = one B-operand fragment of the next product, no lane movement (as attention.hip).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -258,6 +260,171 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_pa
         }
       }
     }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (!kok[u]) continue;
+    const int key = key0 + 16 * u + l15;
+    f16* DK = reinterpret_cast<f16*>(p.dk) + (int64_t)bkv * p.dk_batch_stride + (int64_t)key * p.dk_row_stride + h * d;
+    f16* DV = reinterpret_cast<f16*>(p.dv) + (int64_t)bkv * p.dv_batch_stride + (int64_t)key * p.dv_row_stride + h * d;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int dd = 16 * i + 4 * g;
+      if (dd >= d) continue;
+      f16x4 ok4, ov4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ok4[r] = (f16)(dk[u][i][r] * p.scale);
+        ov4[r] = (f16)dv[u][i][r];
+      }
+      *reinterpret_cast<f16x4*>(DK + dd) = ok4;
+      *reinterpret_cast<f16x4*>(DV + dd) = ov4;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV, LDS-staged
+// The same sweep with the query-side operands of a 32-query block (Q, dO rows; Q^T, dO^T rows; lse, delta) staged ONCE per
+// workgroup in LDS (two stages, the next block's chunks in flight in registers under the current block's MFMAs) instead of
+// fetched from L2 by each of the four waves: a quarter of the L2 traffic, and no load round trip inside an iteration.
+template <int KS, int DT, int U>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bwd_params p, const float c) {
+  constexpr int RS = KS * 32 + 8;                    // LDS row stride of the Q / dO tiles (halfs)
+  constexpr int TS = 32 + 8;                         // ... of the Q^T / dO^T tiles
+  constexpr int QCH = 32 * KS * 4;                   // 16-byte chunks of a [32][KS * 32] tile
+  constexpr int TCH = DT * 16 * 4;                   // ... of a [DT * 16][32] tile
+  constexpr int NQ = (QCH + 255) / 256, NT = (TCH + 255) / 256;
+  constexpr int STAGE_H = 2 * 32 * RS + 2 * DT * 16 * TS;     // halfs per stage (+ 64 floats of lse / delta)
+  __shared__ __attribute__((aligned(16))) f16 lds[2 * (STAGE_H + 128)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, bkv = blockIdx.z, d = p.head_dim;
+  const int key0 = blockIdx.x * (64 * U) + wave * (16 * U);
+  const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
+  const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
+  f16x8 kf[U][KS], vf[U][KS];
+  f32x4 dk[U][DT], dv[U][DT];
+  bool kok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int key = key0 + 16 * u + l15;
+    kok[u] = key < p.lk;
+    row_frags<KS>(kf[u], Kg + (int64_t)key * p.k_row_stride, kok[u], g, d);
+    row_frags<KS>(vf[u], Vg + (int64_t)key * p.v_row_stride, kok[u], g, d);
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dk[u][i] = dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nqb = (p.lq + 31) / 32, nit = p.kv_group * nqb;
+  const int lq8 = (p.lq + 7) & ~7;
+  f16x8 rq[NQ], rdo[NQ], rqt[NT], rdot[NT];
+  float rl = 0.f, rd = 0.f;
+  auto fetch = [&](int it) {
+    const int f = it / nqb, qb = (it - f * nqb) * 32;
+    const int bq = bkv * p.kv_group + f;
+    const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
+    const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
+    const f16* QT = reinterpret_cast<const f16*>(p.qt) + (int64_t)bq * p.qt_batch_stride + (int64_t)h * d * p.qt_row_stride;
+    const f16* DOT = reinterpret_cast<const f16*>(p.doutt) + (int64_t)bq * p.dot_batch_stride + (int64_t)h * d * p.dot_row_stride;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int t = tid + 256 * i, row = t / (KS * 4), ch = t - row * (KS * 4);
+      const bool ok = t < QCH && qb + row < p.lq && 8 * ch < d;
+      rq[i] = ok ? ld_global_16B(Q + (int64_t)(qb + row) * p.q_row_stride + 8 * ch) : zero8();
+      rdo[i] = ok ? ld_global_16B(DO + (int64_t)(qb + row) * p.do_row_stride + 8 * ch) : zero8();
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int t = tid + 256 * i, row = t >> 2, ch = t & 3;
+      const bool ok = t < TCH && row < d && qb + 8 * ch < lq8;
+      rqt[i] = ok ? ld_global_16B(QT + (int64_t)row * p.qt_row_stride + qb + 8 * ch) : zero8();
+      rdot[i] = ok ? ld_global_16B(DOT + (int64_t)row * p.dot_row_stride + qb + 8 * ch) : zero8();
+    }
+    if (tid < 32) {
+      const int64_t st = ((int64_t)bq * p.heads + h) * p.lq + min(qb + tid, p.lq - 1);
+      rl = p.lse[st];
+      rd = p.delta[st];
+    }
+  };
+  auto commit = [&](int stage) {
+    f16* sq = lds + stage * (STAGE_H + 128);
+    f16* sdo = sq + 32 * RS;
+    f16* sqt = sdo + 32 * RS;
+    f16* sdot = sqt + DT * 16 * TS;
+    float* sst = reinterpret_cast<float*>(sdot + DT * 16 * TS);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int t = tid + 256 * i, row = t / (KS * 4), ch = t - row * (KS * 4);
+      if (t < QCH) {
+        *reinterpret_cast<f16x8*>(sq + row * RS + 8 * ch) = rq[i];
+        *reinterpret_cast<f16x8*>(sdo + row * RS + 8 * ch) = rdo[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int t = tid + 256 * i, row = t >> 2, ch = t & 3;
+      if (t < TCH) {
+        *reinterpret_cast<f16x8*>(sqt + row * TS + 8 * ch) = rqt[i];
+        *reinterpret_cast<f16x8*>(sdot + row * TS + 8 * ch) = rdot[i];
+      }
+    }
+    if (tid < 32) {
+      sst[tid] = rl;
+      sst[32 + tid] = rd;
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) fetch(it + 1);
+    const int qb = (it % nqb) * 32;
+    const f16* sq = lds + (it & 1) * (STAGE_H + 128);
+    const f16* sdo = sq + 32 * RS;
+    const f16* sqt = sdo + 32 * RS;
+    const f16* sdot = sqt + DT * 16 * TS;
+    const float* sst = reinterpret_cast<const float*>(sdot + DT * 16 * TS);
+    float pv[U][2][4], ds[U][2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = perm_row(l15, t);
+      f16x8 qa[KS], da[KS];
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        qa[s2] = *reinterpret_cast<const f16x8*>(sq + r * RS + 32 * s2 + 8 * g);
+        da[s2] = *reinterpret_cast<const f16x8*>(sdo + r * RS + 32 * s2 + 8 * g);
+      }
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sst + 8 * g + 4 * t);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sst + 32 + 8 * g + 4 * t);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f32x4 s = chain<KS>(qa, kf[u]);
+        const f32x4 dp = chain<KS>(da, vf[u]);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const bool ok = kok[u] && (qb + 8 * g + 4 * t + r4 < p.lq);
+          const float pr = ok ? __builtin_amdgcn_exp2f(c * s[r4] - l4[r4]) : 0.f;
+          pv[u][t][r4] = pr;
+          ds[u][t][r4] = ok ? pr * (dp[r4] - d4[r4]) : 0.f;
+        }
+      }
+    }
+    f16x8 pb[U], dsb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pb[u] = pack8(pv[u][0], pv[u][1]);
+      dsb[u] = pack8(ds[u][0], ds[u][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const f16x8 a1 = *reinterpret_cast<const f16x8*>(sdot + (16 * i + l15) * TS + 8 * g);
+      const f16x8 a2 = *reinterpret_cast<const f16x8*>(sqt + (16 * i + l15) * TS + 8 * g);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        dv[u][i] = mfma16x16x32(a1, pb[u], dv[u][i]);
+        dk[u][i] = mfma16x16x32(a2, dsb[u], dk[u][i]);
+      }
+    }
+    if (it + 1 < nit) commit((it + 1) & 1);     // the other stage was last read in iteration it - 1 (closed by its barrier)
+    __syncthreads();
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -572,7 +739,9 @@ int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
   if (rc < 0) return rc;
   if (p.dk != nullptr) {
     const dim3 gk((unsigned)i2v_cdiv(p.lk, two_k ? 128 : 64), p.heads, p.batch_q / p.kv_group);
-    if (two_k) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
+    static const int lds_off = getenv("I2V_ATTN_BWD_LDS") ? (atoi(getenv("I2V_ATTN_BWD_LDS")) == 0) : 0;
+    if (two_k && !lds_off && p.lq >= 64) hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
+    else if (two_k) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 1>), gk, dim3(256), 0, s, p, c);
     rc = i2v_check_launch("i2v_attention_bwd_f16(dK, dV)");
   }
