@@ -106,6 +106,87 @@ __global__ __launch_bounds__(256) void attn_lse_kernel(const i2v_attn_params p, 
   if (g == 0 && q < p.lq) lse[((int64_t)bq * p.heads + h) * p.lq + q] = m + __log2f(l);
 }
 
+// the same statistic with the 32-key K blocks staged once per workgroup in LDS and two query tiles per wave (long sequences)
+template <int KS, int U>
+__global__ __launch_bounds__(256) void attn_lse_lds_kernel(const i2v_attn_params p, const float c, float* __restrict__ lse) {
+  constexpr int RS = KS * 32 + 8, QCH = 32 * KS * 4, NQ = (QCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) f16 lds[2 * 32 * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, bq = blockIdx.z, bkv = bq / p.kv_group, d = p.head_dim;
+  const int q0 = blockIdx.x * (64 * U) + wave * (16 * U);
+  const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
+  const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
+  f16x8 qf[U][KS];
+  float m[U], l[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int q = q0 + 16 * u + l15;
+    row_frags<KS>(qf[u], Q + (int64_t)q * p.q_row_stride, q < p.lq, g, d);
+    m[u] = -INFINITY;
+    l[u] = 0.f;
+  }
+  const int nit = (p.lk + 31) / 32;
+  f16x8 rk[NQ];
+  auto fetch = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int t = tid + 256 * i, row = t / (KS * 4), ch = t - row * (KS * 4);
+      const bool ok = t < QCH && 32 * it + row < p.lk && 8 * ch < d;
+      rk[i] = ok ? ld_global_16B(Kg + (int64_t)(32 * it + row) * p.k_row_stride + 8 * ch) : zero8();
+    }
+  };
+  auto commit = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int t = tid + 256 * i, row = t / (KS * 4), ch = t - row * (KS * 4);
+      if (t < QCH) *reinterpret_cast<f16x8*>(lds + stage * 32 * RS + row * RS + 8 * ch) = rk[i];
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) fetch(it + 1);
+    const f16* sk = lds + (it & 1) * 32 * RS;
+    float v[U][2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = perm_row(l15, t);
+      f16x8 kf[KS];
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) kf[s2] = *reinterpret_cast<const f16x8*>(sk + r * RS + 32 * s2 + 8 * g);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f32x4 s = chain<KS>(kf, qf[u]);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) v[u][t][r4] = (32 * it + 8 * g + 4 * t + r4 < p.lk) ? c * s[r4] : -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float mx = fmaxf(fmaxf(fmaxf(v[u][0][0], v[u][0][1]), fmaxf(v[u][0][2], v[u][0][3])),
+                       fmaxf(fmaxf(v[u][1][0], v[u][1][1]), fmaxf(v[u][1][2], v[u][1][3])));
+      mx = group_max(mx);
+      const float mn = fmaxf(m[u], mx);
+      float add = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) add += __builtin_amdgcn_exp2f(v[u][t][r4] - mn);
+      l[u] = l[u] * __builtin_amdgcn_exp2f(m[u] - mn) + add;
+      m[u] = mn;
+    }
+    if (it + 1 < nit) commit((it + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int q = q0 + 16 * u + l15;
+    const float lt = group_sum(l[u]);
+    if (g == 0 && q < p.lq) lse[((int64_t)bq * p.heads + h) * p.lq + q] = m[u] + __log2f(lt);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dQ
 // U = 16-row tiles per wave (1 or 2): the K / V / K^T fragments a key block needs are fetched once and used for both of a
 // wave's query tiles (the fragments come straight from L2: no LDS staging yet, so loads per FLOP are what there is to save)
@@ -448,6 +529,133 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ, LDS-staged
+// The dQ sweep with the key-side operands of a 32-key block (K, V rows; K^T rows) staged once per workgroup (as above).
+template <int KS, int DT, int U>
+__global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const i2v_attn_bwd_params p, const float c) {
+  constexpr int RS = KS * 32 + 8, TS = 32 + 8;
+  constexpr int QCH = 32 * KS * 4, TCH = DT * 16 * 4;
+  constexpr int NQ = (QCH + 255) / 256, NT = (TCH + 255) / 256;
+  constexpr int STAGE_H = 2 * 32 * RS + DT * 16 * TS;
+  __shared__ __attribute__((aligned(16))) f16 lds[2 * STAGE_H];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y, bq = blockIdx.z, bkv = bq / p.kv_group, d = p.head_dim;
+  const int q0 = blockIdx.x * (64 * U) + wave * (16 * U);
+  const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
+  const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
+  const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
+  const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
+  const f16* KT = reinterpret_cast<const f16*>(p.kt) + (int64_t)bkv * p.kt_batch_stride + (int64_t)h * d * p.kt_row_stride;
+  f16x8 qf[U][KS], dof[U][KS];
+  float lse_q[U], del_q[U];
+  f32x4 acc[U][DT];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int q = q0 + 16 * u + l15;
+    const bool qok = q < p.lq;
+    row_frags<KS>(qf[u], Q + (int64_t)q * p.q_row_stride, qok, g, d);
+    row_frags<KS>(dof[u], DO + (int64_t)q * p.do_row_stride, qok, g, d);
+    const int64_t stat = ((int64_t)bq * p.heads + h) * p.lq + (qok ? q : 0);
+    lse_q[u] = qok ? p.lse[stat] : 0.f;
+    del_q[u] = qok ? p.delta[stat] : 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) acc[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int lk8 = (p.lk + 7) & ~7, nit = (p.lk + 31) / 32;
+  f16x8 rk[NQ], rv[NQ], rkt[NT];
+  auto fetch = [&](int it) {
+    const int kb = 32 * it;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int t = tid + 256 * i, row = t / (KS * 4), ch = t - row * (KS * 4);
+      const bool ok = t < QCH && kb + row < p.lk && 8 * ch < d;
+      rk[i] = ok ? ld_global_16B(Kg + (int64_t)(kb + row) * p.k_row_stride + 8 * ch) : zero8();
+      rv[i] = ok ? ld_global_16B(Vg + (int64_t)(kb + row) * p.v_row_stride + 8 * ch) : zero8();
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int t = tid + 256 * i, row = t >> 2, ch = t & 3;
+      const bool ok = t < TCH && row < d && kb + 8 * ch < lk8;
+      rkt[i] = ok ? ld_global_16B(KT + (int64_t)row * p.kt_row_stride + kb + 8 * ch) : zero8();
+    }
+  };
+  auto commit = [&](int stage) {
+    f16* sk = lds + stage * STAGE_H;
+    f16* sv = sk + 32 * RS;
+    f16* skt = sv + 32 * RS;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int t = tid + 256 * i, row = t / (KS * 4), ch = t - row * (KS * 4);
+      if (t < QCH) {
+        *reinterpret_cast<f16x8*>(sk + row * RS + 8 * ch) = rk[i];
+        *reinterpret_cast<f16x8*>(sv + row * RS + 8 * ch) = rv[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int t = tid + 256 * i, row = t >> 2, ch = t & 3;
+      if (t < TCH) *reinterpret_cast<f16x8*>(skt + row * TS + 8 * ch) = rkt[i];
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) fetch(it + 1);
+    const int kb = 32 * it;
+    const f16* sk = lds + (it & 1) * STAGE_H;
+    const f16* sv = sk + 32 * RS;
+    const f16* skt = sv + 32 * RS;
+    float ds[U][2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = perm_row(l15, t);
+      f16x8 kf[KS], vf[KS];
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        kf[s2] = *reinterpret_cast<const f16x8*>(sk + r * RS + 32 * s2 + 8 * g);
+        vf[s2] = *reinterpret_cast<const f16x8*>(sv + r * RS + 32 * s2 + 8 * g);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f32x4 s = chain<KS>(kf, qf[u]);
+        const f32x4 dp = chain<KS>(vf, dof[u]);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float pr = (kb + 8 * g + 4 * t + r4 < p.lk) ? __builtin_amdgcn_exp2f(c * s[r4] - lse_q[u]) : 0.f;
+          ds[u][t][r4] = pr * (dp[r4] - del_q[u]);
+        }
+      }
+    }
+    f16x8 dsb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dsb[u] = pack8(ds[u][0], ds[u][1]);
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const f16x8 a = *reinterpret_cast<const f16x8*>(skt + (16 * i + l15) * TS + 8 * g);
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u][i] = mfma16x16x32(a, dsb[u], acc[u][i]);
+    }
+    if (it + 1 < nit) commit((it + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int q = q0 + 16 * u + l15;
+    if (q >= p.lq) continue;
+    f16* DQ = reinterpret_cast<f16*>(p.dq) + (int64_t)bq * p.dq_batch_stride + (int64_t)q * p.dq_row_stride + h * d;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int dd = 16 * i + 4 * g;
+      if (dd >= d) continue;
+      f16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[u][i][r] * p.scale);
+      *reinterpret_cast<f16x4*>(DQ + dd) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ small kernels
 // dst[b][c][r] = src[b][r][c]; columns r in [rows, rows8) of dst are zero-filled
 __global__ __launch_bounds__(256) void transpose_kernel(const f16* __restrict__ src, int64_t src_bs, int64_t ld_src,
@@ -733,7 +941,9 @@ int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
   // two 16-row tiles per wave where the sequence is long enough to still fill the chip (halves the fragment loads per FLOP)
   const bool two_q = p.lq >= 512 && DT <= 6, two_k = p.lk >= 512 && DT <= 6;
   const dim3 gq((unsigned)i2v_cdiv(p.lq, two_q ? 128 : 64), p.heads, p.batch_q);
-  if (two_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DT, 2>), gq, dim3(256), 0, s, p, c);
+  static const int lds_off_q = getenv("I2V_ATTN_BWD_LDS") ? (atoi(getenv("I2V_ATTN_BWD_LDS")) == 0) : 0;
+  if (two_q && !lds_off_q && p.lk >= 64) hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<KS, DT, 2>), gq, dim3(256), 0, s, p, c);
+  else if (two_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DT, 2>), gq, dim3(256), 0, s, p, c);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DT, 1>), gq, dim3(256), 0, s, p, c);
   int rc = i2v_check_launch("i2v_attention_bwd_f16(dQ)");
   if (rc < 0) return rc;
@@ -764,9 +974,18 @@ extern "C" int i2v_attention_lse_f32(const i2v_attn_params* pp, float* lse, i2v_
                     al16(p.q) && al16(p.k), "i2v_attention_lse_f32: q / k strides must be multiples of 8 elements, 16-byte aligned");
   I2V_CHECK_ARG(p.heads <= 65535 && p.batch_q <= 65535, "i2v_attention_lse_f32: heads / batch_q exceed the grid limits");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)i2v_cdiv(p.lq, 64), p.heads, p.batch_q), block(256);
   const float c = p.scale * LOG2E;
   const int ks = (p.head_dim + 31) / 32;
+  const dim3 block(256);
+  static const int lds_off = getenv("I2V_ATTN_BWD_LDS") ? (atoi(getenv("I2V_ATTN_BWD_LDS")) == 0) : 0;
+  if (!lds_off && p.lq >= 512 && p.lk >= 64 && ks <= 3) {   // long sequences: K staged in LDS, two query tiles per wave
+    const dim3 grid2((unsigned)i2v_cdiv(p.lq, 128), p.heads, p.batch_q);
+    if (ks == 1) hipLaunchKernelGGL((attn_lse_lds_kernel<1, 2>), grid2, block, 0, s, p, c, lse);
+    else if (ks == 2) hipLaunchKernelGGL((attn_lse_lds_kernel<2, 2>), grid2, block, 0, s, p, c, lse);
+    else hipLaunchKernelGGL((attn_lse_lds_kernel<3, 2>), grid2, block, 0, s, p, c, lse);
+    return i2v_check_launch("i2v_attention_lse_f32");
+  }
+  const dim3 grid((unsigned)i2v_cdiv(p.lq, 64), p.heads, p.batch_q);
   if (ks == 1) hipLaunchKernelGGL((attn_lse_kernel<1>), grid, block, 0, s, p, c, lse);
   else if (ks == 2) hipLaunchKernelGGL((attn_lse_kernel<2>), grid, block, 0, s, p, c, lse);
   else if (ks == 3) hipLaunchKernelGGL((attn_lse_kernel<3>), grid, block, 0, s, p, c, lse);

@@ -61,10 +61,11 @@ def test_attention_backward_vs_autograd(dev, d, lq, lk, group, need_dkv):
         assert dk is None and dv is None
 
 
-def test_attention_lse(dev):
+@pytest.mark.parametrize("lq,lk", [(70, 77), (640, 520)])
+def test_attention_lse(dev, lq, lk):
     K = pkg().kernels
     g = torch.Generator().manual_seed(3)
-    bq, heads, d, lq, lk = 3, 4, 40, 70, 77
+    bq, heads, d = 3, 4, 40
     q, k = h(torch.randn(bq, lq, heads * d, generator=g)), h(torch.randn(bq, lk, heads * d, generator=g))
     s = torch.einsum("blhd,bmhd->bhlm", q.view(bq, lq, heads, d), k.view(bq, lk, heads, d)) * d ** -0.5
     ref = torch.logsumexp(s, dim=-1) * 1.4426950408889634
