@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_lse_lds_kernel(const i2v_attn_params
 
 // ------------------------------------------------------------------------------------------------ dQ
 // U = 16-row tiles per wave (1 or 2): the K / V / K^T fragments a key block needs are fetched once and used for both of a
-// wave's query tiles (the fragments come straight from L2: no LDS staging yet, so loads per FLOP are what there is to save)
+// wave's query tiles.  This form reads its fragments straight from L2 (short sequences); long ones take the LDS-staged form below.
 template <int KS, int DT, int U>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const i2v_attn_bwd_params p, const float c) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
