@@ -1053,6 +1053,54 @@ int splitk_plan(const i2v_gemm_params& p, int vec4, int* kps_out) {
   return splits;
 }
 
+// 256-row tiles with K split in two to four: problems whose 256-row tiles fill only a quarter to half of the chip (the 16 x 16
+// level: 8192 rows x 1280 columns = 128 tiles) with a long K.  As 128-row tiles they get one tile per CU, but a 128-row K tile
+// takes 1.5 us for half the FLOPs of a 256-row one at 2.1 us (the K loop runs at the DMA round trip of its one stage in
+// flight); splitting K over two workgroups of the full-height tile trades the fp32 partials' round trip
+// (84 MB each way at 8192 x 1280) for a third fewer K-loop cycles.  Measured (round 3, tools/split256_ab.py, same box):
+// conv 8192 x 1280 x 23040 425.7 -> 382.8 us, x 17280 329.4 -> 298.5, x 11520 + residual 232.7 -> 227.4, x 5760 130.2 -> 121.5;
+// GEMM 8192 x 1280 x 5120 + residual 122.9 -> 129.9 (the partials cost more than its 80 K tiles give back).  Whole step, same
+// box: 54.84 -> 54.13 ms with the 16 x 16 level's convolutions, 54.02 -> 53.76 with the 8 x 8 level's too (tiles >= 16),
+// 52.12 -> 51.99 with the plain GEMMs as well.  Default (I2V_GEMM_SPLIT256 unset / 1): convolutions with >= 90 K tiles and the
+// 8 x 8 level's plain GEMMs with >= 64; 2: every eligible GEMM; 0: off.
+int splitk256_plan(const i2v_gemm_params& p, int vec4, int* kps_out) {
+  static const int on = getenv("I2V_GEMM_SPLIT256") ? atoi(getenv("I2V_GEMM_SPLIT256")) : 1;
+  if (!on) return 0;
+  const int64_t t256_ = (int64_t)(p.M / 256 > 0 ? p.M / 256 : 1) * (p.N / BIG_BN);
+  if (on == 1 && p.a_mode == I2V_A_CONV3X3 && (p.K + 63) / 64 < 90) return 0;
+  if (on == 1 && p.a_mode != I2V_A_CONV3X3 && t256_ > 32) return 0;   // plain GEMMs: the 8 x 8 level only (52.12 -> 51.99 ms)
+  if (p.N % BIG_BN != 0 || !vec4 || p.epilogue != I2V_EPI_NONE || p.store_mode != I2V_STORE_ROWMAJOR || p.M % 256 != 0) return 0;
+  if (p.a2 != nullptr || p.rows_per_w > 0 || p.a_perm_frames > 0 || p.ln_wsum != nullptr) return 0;
+  const int nkt = (p.K + 63) / 64;
+  const int64_t t256 = (int64_t)(p.M / 256) * (p.N / BIG_BN);
+  static const int min_t = getenv("I2V_GEMM_SPLIT256_MINT") ? atoi(getenv("I2V_GEMM_SPLIT256_MINT")) : 16;
+  if (nkt < 64 || t256 < min_t || t256 > 128) return 0;
+  int splits = (int)(256 / t256);
+  if (splits > 8) splits = 8;
+  if (splits > nkt / 8) splits = nkt / 8;
+  const int kps = (int)i2v_cdiv(nkt, splits);
+  splits = (int)i2v_cdiv(nkt, kps);
+  if (splits < 2) return 0;
+  if (kps_out) *kps_out = kps;
+  return splits;
+}
+
+int launch_split256(const i2v_gemm_params& p, int vec4, int splits, int kps, hipStream_t s) {
+  const int tiles_m = p.M / 256, tiles_n = p.N / BIG_BN;
+  const dim3 grid(tiles_m * tiles_n, splits), block(512);
+  if (p.a_mode == I2V_A_CONV3X3)
+    hipLaunchKernelGGL((gemm_big_kernel<256, 64, 2, I2V_A_CONV3X3, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
+                       tiles_n, kps, tiles_m * tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_big_kernel<256, 64, 2, I2V_A_PLAIN, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, true>), grid, block, 0, s, p,
+                       tiles_n, kps, tiles_m * tiles_n);
+  const int64_t groups = (int64_t)p.M * (p.N / 4);
+  const int blocks = (int)(i2v_cdiv(groups, 256) < 2048 ? i2v_cdiv(groups, 256) : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, splits, vec4);
+  const int rc = i2v_check_launch("i2v_gemm_f16(split-K, 256-row tiles)");
+  return rc < 0 ? rc : 1;
+}
+
 int launch_split(const i2v_gemm_params& p, int vec4, int splits, int kps, hipStream_t s) {
   const int tiles_m = (int)i2v_cdiv(p.M, 128), tiles_n = p.N / BIG_BN;
   const dim3 grid(tiles_m * tiles_n, splits), block(512);
@@ -1074,7 +1122,9 @@ int launch_split(const i2v_gemm_params& p, int vec4, int splits, int kps, hipStr
 int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4) {
   static const int off = getenv("I2V_GEMM_SPLITK") ? (atoi(getenv("I2V_GEMM_SPLITK")) == 0) : 0;
   if (off) return 0;
-  const int splits = splitk_plan(p, vec4, nullptr);
+  int splits = splitk_plan(p, vec4, nullptr);
+  const int s256 = splitk256_plan(p, vec4, nullptr);
+  if (s256 > splits) splits = s256;
   return splits ? (int64_t)splits * p.M * p.N * (int64_t)sizeof(float) : 0;
 }
 
@@ -1147,6 +1197,16 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
   // one 8-wave block per CU: a tile count just above a multiple of 256 wastes most of the last round.  Pick the
   // tile height by (fill of the last round) x (measured relative rate: 256-row 1.0, 128-row 0.82,
   // profiles/r1_tile_sweep.txt); below 40 % the 3-blocks-per-CU kernel of gemm.hip is faster.
+  {   // 256-row tiles with K split (returns -2)
+    int kps256 = 0;
+    const int s256 = splitk256_plan(p, vec4, &kps256);
+    if (s256 && p.workspace && p.workspace_bytes >= (int64_t)s256 * p.M * p.N * (int64_t)sizeof(float) &&
+        (reinterpret_cast<uintptr_t>(p.workspace) % 16) == 0) {
+      if (splits_out) *splits_out = s256;
+      if (kps_out) *kps_out = kps256;
+      return -2;
+    }
+  }
   const double e256 = (double)t256 / (double)(i2v_cdiv(t256, 256) * 256);
   const double e128 = 0.82 * (double)t128 / (double)(i2v_cdiv(t128, 256) * 256);
   if (e256 >= e128 && e256 >= 0.40) return 256;
@@ -1206,5 +1266,6 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   if (plan == 256) return launch_big<256>(p, vec4, s);
   if (plan == 128) return launch_big<128>(p, vec4, s);
   if (plan == -1) return launch_split(p, vec4, splits, kps, s);
+  if (plan == -2) return launch_split256(p, vec4, splits, kps, s);
   return 0;
 }
