@@ -105,7 +105,8 @@ template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = fa
           bool FAST = false, int BNT = 320, int NW = 8>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n,
                                                                             const int kps, const int ntiles) {
-  static_assert(NS == 2, "the cross-tile prefetch of the persistent tile loop is written for two stages");
+  static_assert(NS == 2 || (NS <= 4 && !FAST && !SPLIT && NW == 8),
+                "the cross-tile prefetch of the persistent tile loop, the LayerNorm fold and split-K are written for two stages");
   static_assert(NW == 8 || (NW == 4 && !STAGGER && !SPLIT), "4-wave workgroups: one M-wave, no stagger partner, no split-K");
   constexpr int BN = BNT;
   constexpr int WNC = BN / 4;               // columns per N-wave: 80 / 64 / 32
@@ -347,7 +348,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
   // (everything older -- the previous epilogue's stores, the first K tile's DMA -- is waited for there too); done here,
   // the value is not carried into the K loop.
   float* const lds_ws = lds_ws2 + ws_buf * BN;
-  if (!have_first && kt0 < nkt) issue(kt0, sbase);
+  if (!have_first) {   // NS - 1 K tiles in flight before the loop
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+      if (kt0 + st < nkt) issue(kt0 + st, (sbase + st) % NS);
+  }
   if (LNF) {
     const float* lnws_g = reinterpret_cast<const float*>(p.ln_wsum);
     if (NW == 8) {
@@ -366,16 +371,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
     ws_buf ^= 1;
   }
   auto sync_tile = [&](int kt) {
-    wait_vmcnt<0>();   // K tile kt has landed (one tile in flight)
+    // K tile kt has landed.  Two stages: it is the only one in flight.  Deeper pipelines: the NS - 2 tiles issued after it
+    // stay in flight (every wave issues exactly AG + WG DMA instructions per tile; vmcnt counts in issue order); the last
+    // NS - 2 trips, with fewer tiles behind, wait for everything.
+    if (NS == 2 || kt + NS - 2 >= nkt)
+      wait_vmcnt<0>();
+    else
+      wait_vmcnt<(NS - 2) * (AG + WG)>();
     // one barrier per K tile: every wave's share of tile kt is in LDS, and every wave has finished reading tile
     // kt - 1 (or the previous output tile's epilogue slabs), whose stage is the one refilled next
     __builtin_amdgcn_s_barrier();
   };
   auto prefetch = [&](int kt) {
-    const int stage = (sbase + kt - kt0 + 1) & 1;
-    if (kt + 1 < nkt)
-      issue(kt + 1, stage);
-    else if (has_next)
+    const int stage = (sbase + kt - kt0 + NS - 1) % NS;   // the stage tile kt - 1 was read from (closed by this trip's barrier)
+    if (kt + NS - 1 < nkt)
+      issue(kt + NS - 1, stage);
+    else if (NS == 2 && has_next)
       issue_next_first(stage);
   };
   // Fragment reads.  BK = 64: a row is 128 B and the 16-row steps of a wave's blocks leave the swizzle term
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
       sync_tile(kt);
       if (kt == kt0) { I2V_STAMP(1); }
       prefetch(kt);
-      const int cur = (sbase + kt - kt0) & 1;
+      const int cur = (sbase + kt - kt0) % NS;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         f16x8 wf[NI], af[MI];
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
     for (int j = 0; j < MI; ++j) paf[j] = zero8();
     for (int kt = kt0; kt < nkt; ++kt) {
       sync_tile(kt);
-      const int cur = (sbase + kt - kt0) & 1;
+      const int cur = (sbase + kt - kt0) % NS;
       if (kt > kt0) mma(pwf, paf);   // before the DMA address arithmetic: the pending fragments die here
       prefetch(kt);
 #pragma unroll
@@ -513,11 +524,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
 
   // the next output tile's first K tile is in flight into stage `sbase`; the stage the loop read last is free for the
   // epilogue's transpose slabs once every wave has left the loop (the epilogues' own barrier)
-  sbase = (sbase + (nkt - kt0)) & 1;
+  sbase = NS == 2 ? (sbase + (nkt - kt0)) & 1 : 0;
   have_first = has_next;
   // (4-wave workgroups are never persistent: nothing is in flight after the loop and the slabs may span both stages --
   //  the V^T epilogue's four 8.4 KiB slabs exceed one 28 KiB stage)
-  char* const slab_stage = NW == 4 ? smem : smem + (sbase ^ 1) * STAGE;
+  // (deeper pipelines are never persistent either: every stage is free after the loop)
+  char* const slab_stage = (NW == 4 || NS > 2) ? smem : smem + (sbase ^ 1) * STAGE;
 
   // ---------------------------------------------------------------- epilogue (lane: row m, 4 consecutive n)
   // The (epilogue, store mode) pair is a template parameter and the accumulator indices are compile-time constants
@@ -1010,7 +1022,9 @@ int launch_big_conv_bn(const i2v_gemm_params& p, hipStream_t s) {
 }
 
 // Pipeline shape: two 64-deep stages.  Four 32-deep stages (three tiles in flight, <BM, 32, 4, ...>) measured 5-12 %
-// slower on every shape of the step (profiles/r1_tile_sweep.txt): the loop is not bound by DMA latency.
+// slower on every shape of the step (profiles/r1_tile_sweep.txt), and again in round 3 on the full-chip 16 x 16 level
+// (tools/l2_ab.py: 8192 x 1280 x 1280 40.6 -> 45.5 us, x 2560 70.7 -> 78.5): with every CU busy the extra barriers cost more
+// than the third tile in flight gives.  Deeper pipelines pay only where the chip is NOT full (deep_plan below).
 template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   (void)vec4;
@@ -1117,6 +1131,42 @@ int launch_split(const i2v_gemm_params& p, int vec4, int splits, int kps, hipStr
   return rc < 0 ? rc : 1;
 }
 
+// Deep-pipeline form for the problems that cannot fill the chip (the 8 x 8 level: 2048 rows): their K loop is a chain of
+// nkt DMA round trips (1.3 - 1.5 us each with one tile in flight, whatever the tile size), so the tile is made SMALLER --
+// 128 x 128 (32 KiB stages, four of them) or 128 x 256 (48 KiB, three) -- and the freed LDS holds two or three more K tiles
+// in flight: the chain advances at round trip / 3 (or / 2), and the smaller tiles also spread the problem over more CUs.
+// Returns the column tile (128 / 256) or 0.  I2V_GEMM_DEEP=0 turns it off.
+int deep_plan(const i2v_gemm_params& p, int vec4) {
+  static const int on = getenv("I2V_GEMM_DEEP") ? atoi(getenv("I2V_GEMM_DEEP")) : 1;
+  if (!on || !vec4) return 0;
+  if (p.a_mode != I2V_A_PLAIN || p.epilogue != I2V_EPI_NONE || p.store_mode == I2V_STORE_VT_T || p.ln_wsum != nullptr) return 0;
+  if (p.rows_per_w > 0 || p.a_perm_frames > 0 || p.c_is_f32) return 0;
+  static const int min_kt = getenv("I2V_GEMM_DEEP_MINKT") ? atoi(getenv("I2V_GEMM_DEEP_MINKT")) : 10;
+  if (p.N % 128 != 0 || (p.K + 63) / 64 < min_kt) return 0;
+  const int64_t tm = i2v_cdiv(p.M, 128);
+  if (tm * (p.N / 128) <= 256) return 128;
+  if (p.N % 256 == 0 && tm * (p.N / 256) <= 256) return 256;
+  return 0;
+}
+
+template <int BN, int NS>
+int launch_deep(const i2v_gemm_params& p, hipStream_t s) {
+  const int tiles_m = (int)i2v_cdiv(p.M, 128), tiles_n = p.N / BN;
+  const int ntiles = tiles_m * tiles_n;
+#define I2V_DEEP_LAUNCH(STORE) \
+  hipLaunchKernelGGL((gemm_big_kernel<128, 64, NS, I2V_A_PLAIN, I2V_EPI_NONE, STORE, false, true, false, false, BN>), \
+                     dim3(ntiles), dim3(512), 0, s, p, tiles_n, 0, ntiles)
+  if (p.store_mode == I2V_STORE_ROWPERM)
+    I2V_DEEP_LAUNCH(I2V_STORE_ROWPERM);
+  else if (p.store_mode == I2V_STORE_VT)
+    I2V_DEEP_LAUNCH(I2V_STORE_VT);
+  else
+    I2V_DEEP_LAUNCH(I2V_STORE_ROWMAJOR);
+#undef I2V_DEEP_LAUNCH
+  const int rc = i2v_check_launch("i2v_gemm_f16(big, deep pipeline)");
+  return rc < 0 ? rc : 1;
+}
+
 }  // namespace
 
 int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4) {
@@ -1133,6 +1183,7 @@ namespace {
 int big_bn(const i2v_gemm_params& p) {
   if (p.c_is_f32) return 0;   // fp32 results exist in the generic kernel only (narrow outputs)
   if (p.N % BIG_BN == 0) return BIG_BN;
+  if (p.a_mode == I2V_A_PLAIN) return deep_plan(p, 1) ? -1 : 0;   // -1: the deep-pipeline form (128 / 256 columns) or nothing
   static const int vae = getenv("I2V_GEMM_BIG_VAE") ? atoi(getenv("I2V_GEMM_BIG_VAE")) : 1;
   if (vae && p.a_mode == I2V_A_CONV3X3 && p.epilogue == I2V_EPI_NONE && p.store_mode == I2V_STORE_ROWMAJOR) {
     if (p.N % 256 == 0) return 256;
@@ -1189,9 +1240,9 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
         return 0;
     }
   }
-  const int64_t tn = p.N / bn;
+  const int64_t tn = bn > 0 ? p.N / bn : i2v_cdiv(p.N, BIG_BN);
   const int64_t t256 = i2v_cdiv(p.M, 256) * tn, t128 = i2v_cdiv(p.M, 128) * tn;
-  if (mode == 256 || mode == 128) return mode;
+  if (mode == 256 || mode == 128) return bn > 0 ? mode : 0;
   static const int min_k = getenv("I2V_GEMM_BIG_MINK") ? atoi(getenv("I2V_GEMM_BIG_MINK")) : 128;
   if (p.a_mode != I2V_A_CONV3X3 && p.K < min_k) return 0;   // a single K tile cannot hide its own DMA latency
   // one 8-wave block per CU: a tile count just above a multiple of 256 wastes most of the last round.  Pick the
@@ -1209,9 +1260,18 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
   }
   const double e256 = (double)t256 / (double)(i2v_cdiv(t256, 256) * 256);
   const double e128 = 0.82 * (double)t128 / (double)(i2v_cdiv(t128, 256) * 256);
+  if (bn == BIG_BN || bn == -1) {   // a single, partial round of tiles and a chain of >= 10 K tiles: the deep-pipeline form
+    static const int deep_mode = getenv("I2V_GEMM_DEEP") ? atoi(getenv("I2V_GEMM_DEEP")) : 2;
+    static const int max_kt = getenv("I2V_GEMM_DEEP_MAXKT") ? atoi(getenv("I2V_GEMM_DEEP_MAXKT")) : 63;
+    const int dbn = deep_plan(p, vec4);
+    if (dbn && (p.K + 63) / 64 <= max_kt && (deep_mode == 2 || bn == -1 || (e256 < 0.40 && e128 < 0.40)))
+      return -3 - (dbn == 256 ? 1 : 0);   // -3: 128-column tiles, -4: 256-column tiles
+    if (bn == -1) return 0;
+  }
   if (e256 >= e128 && e256 >= 0.40) return 256;
   if (e128 >= 0.40) return 128;
   if (bn != BIG_BN) return 0;   // (split-K exists for 320-column tiles only)
+
   // too few output tiles for the chip: split K when the caller supplied the fp32 scratch
   int kps = 0;
   const int splits = splitk_plan(p, vec4, &kps);
@@ -1267,5 +1327,7 @@ int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   if (plan == 128) return launch_big<128>(p, vec4, s);
   if (plan == -1) return launch_split(p, vec4, splits, kps, s);
   if (plan == -2) return launch_split256(p, vec4, splits, kps, s);
+  if (plan == -3) return launch_deep<128, 4>(p, s);
+  if (plan == -4) return launch_deep<256, 3>(p, s);
   return 0;
 }

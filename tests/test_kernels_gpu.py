@@ -108,6 +108,43 @@ def test_gemm_and_conv_split_k(dev):
     close(out.permute(0, 3, 1, 2), ref, name="split-K conv")
 
 
+@pytest.mark.parametrize("M,N,K_,kind", [
+    (2048, 1280, 1280, "plain"), (2000, 1280, 640, "plain"), (2048, 2560, 1280, "plain"), (2048, 3840, 1280, "plain"),
+    (512, 1280, 1280, "plain"), (128, 1280, 2560, "plain"), (1280, 2048, 1280, "vt"), (640, 2048, 640, "vt"),
+    (2048, 1280, 1280, "rowperm"), (2048, 1280, 1280, "dual"), (1100, 384, 704, "plain")])
+def test_gemm_deep_pipeline_small_levels(dev, M, N, K_, kind):
+    """problems that cannot fill the chip with output tiles and have >= 10 K tiles (the 8 x 8 level: 2048 rows): the 128 x 128
+    (four stages) / 128 x 256 (three stages) deep-pipeline form of the 8-wave kernel, every store mode it takes, ragged M,
+    N not a multiple of 320, the concatenated second source."""
+    k = K()
+    g = torch.Generator().manual_seed(M + 3 * N + K_)
+    a = h(torch.randn(M, K_, generator=g))
+    w = h(torch.randn(N, K_, generator=g) / math.sqrt(K_))
+    b = h(torch.randn(N, generator=g))
+    ad, wd, bd = a.half().to(dev), w.half().to(dev), b.half().to(dev)
+    if kind == "plain":
+        r = h(torch.randn(M, N, generator=g))
+        close(k.gemm(ad, wd, bd), a @ w.T + b, name="deep gemm")
+        close(k.gemm(ad, wd, bd, residual=r.half().to(dev), out_scale=0.5), (a @ w.T + b + r) * 0.5, name="deep gemm + residual")
+        rpv = 50 if M % 50 == 0 else 64
+        rv = h(torch.randn(M // rpv, N, generator=g))
+        close(k.gemm(ad, wd, bd, rowvec=rv.half().to(dev), rows_per_vec=rpv), a @ w.T + b + rv.repeat_interleave(rpv, 0),
+              name="deep gemm + row vector")
+    elif kind == "rowperm":
+        B_, F_, HW = 2, 16, M // 32
+        r = h(torch.randn(M, N, generator=g))
+        y = (a @ w.T + b).reshape(B_, HW, F_, N).permute(0, 2, 1, 3).reshape(M, N) + r
+        close(k.gemm(ad, wd, bd, residual=r.half().to(dev), store=k.I2V_STORE_ROWPERM, frames=F_, hw=HW), y, name="deep rowperm")
+    elif kind == "dual":
+        a2 = h(torch.randn(M, 640, generator=g))
+        w2 = h(torch.randn(N, K_ + 640, generator=g) / math.sqrt(K_ + 640))
+        close(k.gemm(ad, w2.half().to(dev), bd, a2=a2.half().to(dev)), torch.cat([a, a2], 1) @ w2.T + b, name="deep dual")
+    else:   # V^T projection: A = weights [C, K], W = tokens [T, K], T = N here (64 keys per batch)
+        vt = k.project_vt(wd, ad, 64)
+        ref = (w @ a.T).reshape(N // 64, 64, M).permute(0, 2, 1)
+        close(vt[:, :, :64], ref, name="deep vt")
+
+
 @pytest.mark.parametrize("batches,L,C,Kd", [(4, 6, 24, 16), (2, 64, 320, 64), (3, 4096, 640, 64), (5, 16, 320, 320)])
 def test_gemm_store_vt_t(dev, batches, L, C, Kd):
     """V^T from the natural operand order (A = tokens): generic kernel (small) and 256-row tile kernel (large)."""
