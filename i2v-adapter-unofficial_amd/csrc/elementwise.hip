@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256) void repeat_rows_kernel(const f16* __restrict_
   }
 }
 
+// 16 bytes per lane when the row length, the strides and both bases allow it (every caller of the step does: channel counts
+// are multiples of 8); the index arithmetic runs once per 8 elements and in 32 bits
+__global__ __launch_bounds__(256) void copy3d_vec8_kernel(const f16* __restrict__ src, int64_t sbs, int64_t ld_src,
+                                                          f16* __restrict__ dst, int64_t dbs, int64_t ld_dst, int batches,
+                                                          int rows, int cols8) {
+  const int64_t total = (int64_t)batches * rows * cols8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const unsigned t = (unsigned)(i / (unsigned)cols8);          // < 2^31 rows in all (checked on the host)
+    const unsigned c8 = (unsigned)(i - (int64_t)t * cols8);
+    const unsigned b = t / (unsigned)rows, r = t - b * (unsigned)rows;
+    *reinterpret_cast<f16x8*>(dst + b * dbs + r * ld_dst + 8 * c8) =
+        *reinterpret_cast<const f16x8*>(src + b * sbs + r * ld_src + 8 * c8);
+  }
+}
+
 __global__ __launch_bounds__(256) void copy3d_kernel(const f16* __restrict__ src, int64_t sbs, int64_t ld_src,
                                                      f16* __restrict__ dst, int64_t dbs, int64_t ld_dst, int64_t batches,
                                                      int64_t rows, int64_t cols) {
@@ -264,9 +279,17 @@ extern "C" int i2v_copy3d_f16(const void* src, int64_t src_batch_stride, int64_t
                               i2v_stream_t stream) {
   I2V_CHECK_ARG(src && dst && batches > 0 && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols,
                 "i2v_copy3d_f16: bad arguments");
-  hipLaunchKernelGGL(copy3d_kernel, dim3(ew_blocks(batches * rows * cols)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), src_batch_stride, ld_src,
-                     reinterpret_cast<f16*>(dst), dst_batch_stride, ld_dst, batches, rows, cols);
+  const bool vec8 = cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && src_batch_stride % 8 == 0 && dst_batch_stride % 8 == 0 &&
+                    (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 &&
+                    batches * rows < (1ll << 31) && cols < (1ll << 31);
+  if (vec8)
+    hipLaunchKernelGGL(copy3d_vec8_kernel, dim3(ew_blocks(batches * rows * (cols / 8))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), src_batch_stride, ld_src,
+                       reinterpret_cast<f16*>(dst), dst_batch_stride, ld_dst, (int)batches, (int)rows, (int)(cols / 8));
+  else
+    hipLaunchKernelGGL(copy3d_kernel, dim3(ew_blocks(batches * rows * cols)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(src), src_batch_stride, ld_src,
+                       reinterpret_cast<f16*>(dst), dst_batch_stride, ld_dst, batches, rows, cols);
   return i2v_check_launch("i2v_copy3d_f16");
 }
 

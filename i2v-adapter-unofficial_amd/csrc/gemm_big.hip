@@ -226,6 +226,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
           ok = (iy >= 0) && (ix >= 0) && (iy < p.in_h) && (ix < p.in_w);
         }
         const unsigned voff = ok ? (unsigned)(((cp[i] + iy * p.in_w + ix) * (int)p.lda + ci + lane_k) * 2) : OOB;
+        // (Round 3, timing experiment: with the A tile fetched for ONE tap in nine -- the traffic of a kernel that keeps an
+        //  18 x 18 halo of the tile's input pixels in LDS and reads the nine taps from it -- the convolutions ran 4 - 10 %
+        //  faster at 64 x 64, 12 - 18 % at 32 x 32, 4 - 13 % at 16 x 16 (tools/conv_ab.py): the A re-reads hit L2 and are not
+        //  what bounds the K loop; fragment reads already keep LDS ~80 % busy at the MFMA rate.  The halo kernel was not built.)
         bdma16(rs_a, sa + (wave + NW * i) * 1024, voff, 0);
       }
     } else if (FAST || (kb < ksp && tm0 + BM <= M)) {

@@ -184,13 +184,15 @@ class I2VAdapterTransformerBlock(HipModule):
                     vt1 = K.project_vt(n, p["w_v1"], L)
                 if enable_cross_frame_attn:
                     clips = n_img // num_frames
-                    first = torch.empty((clips, L, c), dtype=f16, device=x.device)
-                    if n is None:   # frame-0 rows only: gather the raw rows, normalise just those (1 / num_frames of the work)
-                        K.copy3d(x.view(clips, num_frames * L, c)[:, :L], first)
-                        first = K.layernorm(first.view(-1, c), p["g1"], p["b1"], self.eps).view(clips, L, c)
+                    src = x if n is None else n
+                    if clips == 1:   # one clip: its frame-0 rows are the first L rows as they stand
+                        first = src[:L]
                     else:
-                        K.copy3d(n.view(clips, num_frames * L, c)[:, :L], first)             # i2v:484 (no repeat)
-                    f2d = first.view(-1, c)
+                        first = torch.empty((clips, L, c), dtype=f16, device=x.device)
+                        K.copy3d(src.view(clips, num_frames * L, c)[:, :L], first)           # i2v:484 (no repeat)
+                    if n is None:   # frame-0 rows only: normalise just those (1 / num_frames of the work)
+                        first = K.layernorm(first.reshape(-1, c), p["g1"], p["b1"], self.eps)
+                    f2d = first.reshape(-1, c)
                     k0 = K.gemm(f2d, p["w_k_ad"])
                     v0t = K.project_vt(f2d, p["w_v_ad"], L)
             if fold1:

@@ -622,6 +622,13 @@ def test_layout_edges_and_misc(dev):
     dst = torch.zeros(4, 3, 8, dtype=torch.float16, device=dev)
     k.copy3d(big[:, 2:5, 8:16], dst)
     close(dst, big[:, 2:5, 8:16], rel=1e-6, name="copy3d")
+    dst7 = torch.zeros(4, 3, 7, dtype=torch.float16, device=dev)            # odd row length / unaligned base: scalar form
+    k.copy3d(big[:, 1:4, 3:10], dst7)
+    close(dst7, big[:, 1:4, 3:10], rel=1e-6, name="copy3d scalar")
+    wide = h(torch.randn(3, 16 * 50, 320, generator=g)).half().to(dev)      # frame-0 gather of the adapter block: 16-byte form
+    first = torch.zeros(3, 50, 320, dtype=torch.float16, device=dev)
+    k.copy3d(wide[:, :50], first)
+    assert torch.equal(first, wide[:, :50])
 
 
 def test_timestep_embedding(dev):
