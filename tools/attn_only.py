@@ -9,7 +9,7 @@ E = lambda n, v: int(os.environ.get(n, v))
 bq, grp, hd, d, lq, lk = E("BQ", 32), E("GRP", 16), E("HEADS", 8), E("D", 40), E("LQ", 4096), E("LK", 4096)
 c = hd * d
 q = torch.randn(bq * lq, c, device=dev).half(); kk = torch.randn(bq // grp * lk, c, device=dev).half()
-vt = torch.randn(bq // grp, c, lk, device=dev).half()
+vt = torch.randn(bq // grp, c, (lk + 7) // 8 * 8, device=dev).half()
 run = lambda: k.attention(q, kk, vt, batch_q=bq, lq=lq, lk=lk, heads=hd, head_dim=d, kv_group=grp)
 for _ in range(3):
     run()
