@@ -40,18 +40,8 @@ constexpr float DEFER_THR = 8.0f;    // log2 units
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-// max over lanes l, l ^ 16 (resp. l ^ 32): with both operands = x, v_permlane16_swap leaves (rows 0,0,2,2) in the first
-// result and (rows 1,1,3,3) in the second; v_permlane32_swap leaves (lo, lo) and (hi, hi).
-__device__ __forceinline__ float xor16_max(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-__device__ __forceinline__ float xor32_max(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
+__device__ __forceinline__ float xor16_max(float x) { return lane_xor16_max(x); }   // common.h
+__device__ __forceinline__ float xor32_max(float x) { return lane_xor32_max(x); }
 
 __device__ __forceinline__ uint32_t pack_rtz(float a, float b) {
   const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);   // v_cvt_pkrtz_f16_f32: two floats -> packed half2, one instruction
@@ -282,9 +272,13 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
       float mx = max3(sv[0][0], sv[0][1], fmaxf(sv[0][2], sv[0][3]));
 #pragma unroll
       for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(max3(mx, sv[kt][0], sv[kt][1]), fmaxf(sv[kt][2], sv[kt][3]));
-      mx = xor16_max(mx);   // v_permlane16_swap / v_permlane32_swap: cross-lane on the VALU, no LDS round trip
-      mx = xor32_max(mx);
+      // mx = the lane's own 16 keys.  The test needs no cross-lane traffic: if NO lane of the wave holds a score above the
+      // threshold, every P of the tile is <= 2^8 against the running max as it stands.  Only when some lane does (the first
+      // tile, then rarely) is the row maximum completed over the four lane groups of the query
+      // (v_permlane16_swap / v_permlane32_swap: cross-lane on the VALU, no LDS round trip) and the running max moved.
       if (__any(first || mx > DEFER_THR)) {          // wave-uniform; rare after the first tile
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         const float dlt = first ? mx : fmaxf(mx, 0.f);
         const float alpha = first ? 1.0f : fast_exp2(-dlt);   // O is still zero on the first tile
 #pragma unroll
@@ -436,6 +430,7 @@ inline bool al(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>
 }  // namespace
 
 int i2v_attention32_try(const i2v_attn_params& p, hipStream_t s);   // attention32.hip: head_dim 40 / 48 on 32x32x16 MFMAs
+int i2v_attention_pipe_try(const i2v_attn_params& p, hipStream_t s); // attention_pipe.hip: head_dim 40, software-pipelined key loop
 
 extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(pp != nullptr, "i2v_attention_f16: null params");
@@ -462,6 +457,10 @@ extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream)
   const int d = p.head_dim;
   if (d <= 16) return launch_d<32, 16>(p, s);
   if (d <= 32) return launch_d<32, 32>(p, s);
+  if (d > 32 && d < 48) {
+    const int rc = i2v_attention_pipe_try(p, s);
+    if (rc != 0) return rc < 0 ? rc : I2V_OK;
+  }
   if (d > 32 && d <= 48) {
     const int rc = i2v_attention32_try(p, s);
     if (rc != 0) return rc < 0 ? rc : I2V_OK;

@@ -29,11 +29,7 @@ constexpr float DEFER_THR32 = 8.0f;   // log2 units: O / l are rescaled only whe
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-__device__ __forceinline__ float xor32_maxf(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
+__device__ __forceinline__ float xor32_maxf(float x) { return lane_xor32_max(x); }   // common.h
 __device__ __forceinline__ uint32_t pack_rtz2(float a, float b) {
   const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
   return __builtin_bit_cast(uint32_t, h);
@@ -228,9 +224,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I2V_A32_WAV
     mx = fmaxf(mx, sacc[0][15]);
 #pragma unroll
     for (int v = 0; v < 16; v += 2) mx = max3f(mx, sacc[1][v], sacc[1][v + 1]);
-    mx = xor32_maxf(mx);
     const bool first = t == 0;
-    if (__any(first || mx > DEFER_THR32)) {   // wave-uniform; rare after the first tile
+    if (__any(first || mx > DEFER_THR32)) {   // wave-uniform; rare after the first tile (the lane's own 32 keys decide)
+      mx = xor32_maxf(mx);                    // the row max completed over the two halves only here
       const float want = first ? mx : fmaxf(mx, 0.f);
       const float negm_new = (float)(f16)(negm - want);   // the value the fragment will hold
       const float dlt = negm - negm_new;                  // what was really subtracted

@@ -63,6 +63,28 @@ __device__ __forceinline__ f16x8 zero8() {
   return z;
 }
 
+// max over lanes l, l ^ 16 (resp. l ^ 32) on the VALU (no LDS round trip).  v_permlane16_swap exchanges the odd 16-lane rows of
+// its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of
+// the second; with both registers holding x they end as (rows 0,0,2,2 / rows 1,1,3,3) resp. (lo, lo / hi, hi) of x, and the
+// max of the two is the reduction.
+// Written as inline assembly on purpose.  Through __builtin_amdgcn_permlane16_swap / 32_swap this compiler (ROCm 7.2 clang)
+// hands back the FIRST result for both elements of the returned pair: the max that follows folds away, the swaps stay, and
+// the "reduction" silently becomes the value of lane group 0.  Every attention kernel of rounds 1-2 therefore took its
+// running max from 16 of a tile's 64 keys -- exact in exact arithmetic (any shift common to a row is), invisible to tests
+// with unit-variance inputs, and wrong once logits spread enough for exp2(s - m) to leave fp16 (found in round 3:
+// tools/attn_amp_check.py, tests/test_kernels_gpu.py::test_attention_large_logits).
+// (s_nop 1: a VALU write of an operand needs two wait states before the swap reads it; the compiler cannot see into the asm.)
+__device__ __forceinline__ float lane_xor16_max(float x) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ __forceinline__ float lane_xor32_max(float x) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+
 // XCD-aware block remap (guide T1, bijective form): blocks b and b+8 share an XCD/L2, so give each XCD a
 // contiguous run of logical tile ids.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

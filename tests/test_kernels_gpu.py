@@ -346,6 +346,50 @@ def test_attention(dev, bq, group, heads, d, lq, lk):
     close(out2.view(bq, lq, c), prev.view(bq, lq, c) + 0.75 * ref, name="attention accumulate")
 
 
+@pytest.mark.parametrize("bq,group,heads,d,lq,lk,amp", [
+    (2, 1, 8, 40, 256, 512, 2.0), (4, 2, 8, 40, 256, 512, 4.0), (2, 1, 8, 40, 128, 64, 4.0), (2, 1, 4, 80, 128, 77, 3.0),
+    (2, 1, 2, 160, 64, 192, 4.0), (2, 1, 2, 64, 130, 320, 3.0), (2, 2, 2, 48, 100, 200, 4.0), (1, 1, 2, 128, 64, 128, 3.0)])
+def test_attention_large_logits(dev, bq, group, heads, d, lq, lk, amp):
+    """q and k scaled so that logits reach 20 - 90 (trained attention layers do; unit-variance inputs stop near 6).  The
+    running max must be the maximum over ALL keys of the tile: taken from one lane group only (rounds 1-2, a folded
+    cross-lane reduction) the result stays exact while exp2(s - m) fits fp16 and saturates / overflows beyond -- weights of
+    the large keys clipped, NaN from the kernels that sum P on the VALU.  Tolerance: the fp16 rounding of the pre-scaled Q
+    moves a logit by ~|logit| 2^-11."""
+    k = K()
+    g = torch.Generator().manual_seed(int(amp * 10) + d + lk)
+    c = heads * d
+    bkv = bq // group
+    q = h(torch.randn(bq, lq, c, generator=g) * amp)
+    kk = h(torch.randn(bkv, lk, c, generator=g) * amp)
+    v = h(torch.randn(bkv, lk, c, generator=g))
+    ref = _attn_ref(q, kk, v, heads, group)
+    ld = k.pad8(lk)
+    vt = torch.zeros((bkv, c, ld))
+    vt[:, :, :lk] = v.permute(0, 2, 1)
+    out = k.attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
+                      batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    close(out.view(bq, lq, c), ref, rel=6e-4 * amp * amp, name=f"attention, logits x{amp * amp:g}")
+
+
+def test_attention_spikes_in_every_lane_group(dev):
+    """one key far above the rest per (query tile, lane group): keys 8 g + 3 (+ 32, + a later tile) belong to lane group g of the
+    S^T accumulator; each group's spike must move the running max of the whole row."""
+    k = K()
+    g = torch.Generator().manual_seed(5)
+    bq, heads, d, lq, lk = 4, 2, 40, 128, 384
+    c = heads * d
+    q = h(torch.randn(bq, lq, c, generator=g))
+    kk = h(torch.randn(bq, lk, c, generator=g))
+    v = h(torch.randn(bq, lk, c, generator=g))
+    for b in range(bq):                       # batch b: the spike sits in lane group b, in key tile b + 1
+        kk[b, 64 * (b + 1) + 8 * b + 3 + 32 * (b & 1)] *= 14.0
+    ref = _attn_ref(q, kk, v, heads, 1)
+    vt = v.permute(0, 2, 1).contiguous()
+    out = k.attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
+                      batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d)
+    close(out.view(bq, lq, c), ref, rel=4e-3, name="attention, spiked keys")
+
+
 def test_attention_config5_key_length(dev):
     """BASELINE config 5's L0 level: Lq = Lk = 9216 (96 x 96 latent), head_dim 40, in the self (kv_group 1) and the
     cross-frame (every frame reads frame 0's K / V) forms, against torch SDPA on the host.  144 key tiles per query
@@ -402,6 +446,41 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_attention_software_pipelined_opt_in_child_process(dev):
+    """I2V_ATTN_PIPE=1 (read once per process, hence the child): the three-stage software-pipelined key loop of attention_pipe.hip
+    for head_dim 40 and whole 64-key tiles -- same results as the default kernel at unit and at large logits, odd and even tile
+    counts, cross-frame groups, accumulate; measured slower (profiles/r3_attn_pipe_ab.txt), kept as a tested A/B switch."""
+    import os, subprocess, sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import torch.nn.functional as F
+import i2v_adapter_unofficial_amd as pkg
+k = pkg.kernels; dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(4)
+for bq, group, heads, lq, lk, amp in ((4, 2, 8, 300, 704, 1.0), (2, 1, 8, 1024, 1024, 1.0), (2, 1, 4, 256, 192, 3.0), (2, 2, 2, 128, 320, 4.0)):
+    d = 40; c = heads * d; bkv = bq // group
+    hf = lambda t: t.half().float()
+    q, kk, v = hf(torch.randn(bq, lq, c, generator=g) * amp), hf(torch.randn(bkv, lk, c, generator=g) * amp), hf(torch.randn(bkv, lk, c, generator=g))
+    sp = lambda t, b: t.view(b, -1, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, bq), sp(kk.repeat_interleave(group, 0), bq), sp(v.repeat_interleave(group, 0), bq)).transpose(1, 2).reshape(bq, lq, c)
+    vt = v.permute(0, 2, 1).contiguous()
+    args = (q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev))
+    kw = dict(batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    out = k.attention(*args, **kw).float().cpu().view(bq, lq, c)
+    err = (out - ref).abs().max().item() / ref.abs().max().item()
+    prev = hf(torch.randn(bq * lq, c, generator=g)); out2 = prev.half().to(dev)
+    k.attention(*args, out=out2, accumulate=True, acc_scale=0.75, **kw)
+    err2 = (out2.float().cpu().view(bq, lq, c) - (prev.view(bq, lq, c) + 0.75 * ref)).abs().max().item()
+    print("ERR", err, err2)
+    assert err < 1e-3 * amp * amp and err2 < 5e-3 * amp * amp, (err, err2)
+print("OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, I2V_ATTN_PIPE="1"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_attention_strided_qk_and_spike(dev):
     """q / k read as column slices of a fused projection; one spiked key forces the online-softmax rescale."""
     k = K()
@@ -436,6 +515,24 @@ def test_temporal_attention(dev, npix, frames, heads, d):
     out = k.temporal_attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
                                n_pixels=npix, frames=frames, heads=heads, head_dim=d)
     close(out.view(npix, frames, c), ref, name="temporal attention")
+
+
+@pytest.mark.parametrize("npix,frames,heads,d,amp", [(64, 16, 8, 40, 3.0), (33, 32, 8, 80, 4.0), (8192, 16, 8, 40, 4.0),
+                                                     (16, 24, 2, 160, 3.0)])
+def test_temporal_attention_large_logits(dev, npix, frames, heads, d, amp):
+    """the frame-axis attention with logits up to ~90 (both kernels: one wave per (pixel, head) and the LDS-staged 64 x 64 form)"""
+    k = K()
+    g = torch.Generator().manual_seed(npix + frames + 1)
+    c = heads * d
+    q = h(torch.randn(npix, frames, c, generator=g) * amp)
+    kk = h(torch.randn(npix, frames, c, generator=g) * amp)
+    v = h(torch.randn(npix, frames, c, generator=g))
+    ref = _attn_ref(q, kk, v, heads, 1)
+    vt = torch.zeros((npix, c, k.pad8(frames)))
+    vt[:, :, :frames] = v.permute(0, 2, 1)
+    out = k.temporal_attention(q.reshape(-1, c).half().to(dev), kk.reshape(-1, c).half().to(dev), vt.half().to(dev),
+                               n_pixels=npix, frames=frames, heads=heads, head_dim=d)
+    close(out.view(npix, frames, c), ref, rel=6e-4 * amp * amp, name="temporal attention, large logits")
 
 
 @pytest.mark.parametrize("n,hh,ww,c1,c2,groups,fps,silu,perm", [

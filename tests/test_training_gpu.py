@@ -74,6 +74,36 @@ def test_attention_lse(dev, lq, lk):
     compare(got, ref, rel=1e-3, name="attention log2-sum-exp")
 
 
+@pytest.mark.parametrize("d,lq,lk,group,amp", [(40, 192, 256, 2, 3.0), (80, 64, 128, 1, 3.0), (40, 512, 640, 1, 2.5)])
+def test_attention_backward_large_logits(dev, d, lq, lk, group, amp):
+    """the log-sum-exp recompute and both backward sweeps with logits of 20 - 50 (nearly one-hot rows)"""
+    K = pkg().kernels
+    heads, bkv = 2, 2
+    bq, C = bkv * group, heads * d
+    g = torch.Generator().manual_seed(d + lq + int(10 * amp))
+    q = h(torch.randn(bq, lq, C, generator=g) * amp).requires_grad_()
+    k = h(torch.randn(bkv, lk, C, generator=g) * amp).requires_grad_()
+    v = h(torch.randn(bkv, lk, C, generator=g)).requires_grad_()
+    do = h(torch.randn(bq, lq, C, generator=g) * 0.5)
+    split = lambda t, b, l: t.view(b, l, heads, d).transpose(1, 2)
+    kk = split(k, bkv, lk).repeat_interleave(group, dim=0)
+    vv = split(v, bkv, lk).repeat_interleave(group, dim=0)
+    o = torch.nn.functional.scaled_dot_product_attention(split(q, bq, lq), kk, vv).transpose(1, 2).reshape(bq, lq, C)
+    o.backward(do)
+    to = lambda t: t.detach().half().to(dev).reshape(-1, C)
+    qd, kd, vd = to(q), to(k), to(v)
+    s = torch.einsum("blhd,bmhd->bhlm", q.detach().view(bq, lq, heads, d), kk.transpose(1, 2)) * d ** -0.5
+    lse = K.attention_lse(qd, kd, batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    compare(lse, torch.logsumexp(s, dim=-1) * 1.4426950408889634, rel=2e-3, name="log2-sum-exp, large logits")
+    od = K.attention(qd, kd, K.transpose_tokens(vd, lk), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    compare(od, o.reshape(-1, C), rel=6e-4 * amp * amp, name="attention forward, large logits")
+    dq, dk, dv = K.attention_bwd(qd, kd, vd, od, to(do), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    rel = GRAD_REL_TOL * amp * amp
+    compare(dq, q.grad.reshape(-1, C), rel=rel, name="dQ, large logits")
+    compare(dk, k.grad.reshape(-1, C), rel=rel, name="dK, large logits")
+    compare(dv, v.grad.reshape(-1, C), rel=rel, name="dV, large logits")
+
+
 def test_layernorm_geglu_backward_and_sums(dev):
     K = pkg().kernels
     g = torch.Generator().manual_seed(5)

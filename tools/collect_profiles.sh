@@ -16,7 +16,6 @@ mkdir -p gpurun_out
 tag=${1:-r2}
 export TMPDIR=/tmp
 if [ -x tools/build/ceilings ]; then tools/build/ceilings > gpurun_out/${tag}_ceilings.json 2> gpurun_out/${tag}_ceilings.err; fi
-python bench.py --shapes gpurun_out/${tag}_step_shapes.txt > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 : > gpurun_out/${tag}_bench_configs.jsonl
 python bench.py --frames 8 --size 256 --no-cpu-baseline 2>/dev/null >> gpurun_out/${tag}_bench_configs.jsonl
 python bench.py --ip --no-cpu-baseline 2>/dev/null >> gpurun_out/${tag}_bench_configs.jsonl
@@ -30,6 +29,11 @@ rm -rf gpurun_out/${tag}_prof
 bash tools/pmc_step.sh ${tag}_pmc > /dev/null 2>&1
 bash tools/pmc_traffic.sh > gpurun_out/${tag}_traffic.log 2>&1
 cp gpurun_out/traffic.json gpurun_out/${tag}_traffic.json
+# the headline line LAST, with this box's traffic and ceilings where bench.py looks for them (the copies under profiles/ on
+# the box are scratch; the ones to commit are the gpurun_out/ files)
+cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json
+if [ -s gpurun_out/${tag}_ceilings.json ]; then cp gpurun_out/${tag}_ceilings.json profiles/${tag}_ceilings.json; fi
+python bench.py --shapes gpurun_out/${tag}_step_shapes.txt > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 python -c "
 import json
 d = json.load(open('gpurun_out/${tag}_bench_default.json'))

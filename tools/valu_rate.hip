@@ -19,6 +19,12 @@
 #define RCP32(i) "v_rcp_f32 %" #i ", %8\n"
 #define CVT16(i) "v_cvt_f16_f32 %" #i ", %8\n"
 #define SUB32(i) "v_sub_f32 %" #i ", %8, %9\n"
+#define MAX32(i) "v_max_f32 %" #i ", %8, %9\n"
+#define MUL32(i) "v_mul_f32 %" #i ", %8, %9\n"
+#define PKFMA32(i) "v_pk_fma_f32 %" #i ", %8, %9, %9\n"
+#define PKMUL32(i) "v_pk_mul_f32 %" #i ", %8, %9\n"
+#define MED3(i) "v_med3_f32 %" #i ", %8, %9, %9\n"
+#define PERM16(i) "v_permlane16_swap_b32 %" #i ", %8\n"
 template <int MODE>
 __global__ void k(float* out, long long* cyc, int iters) {
   float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -38,6 +44,9 @@ __global__ void k(float* out, long long* cyc, int iters) {
     if (MODE == 10) REP8(RCP32);
     if (MODE == 11) REP8(CVT16);
     if (MODE == 12) REP8(SUB32);
+    if (MODE == 13) REP8(MAX32);
+    if (MODE == 14) REP8(MUL32);
+    if (MODE == 17) REP8(MED3);
   }
   long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0;
@@ -75,7 +84,8 @@ int main() {
   run<3>("v_exp_f16 op_sel hi", out, cyc); run<4>("v_max3_f32", out, cyc); run<5>("v_cvt_pkrtz_f16_f32", out, cyc);
   run<6>("v_pk_mul_f16", out, cyc); run<7>("v_pk_max_f16", out, cyc); run<8>("v_pk_add_f16", out, cyc);
   run<9>("v_ldexp_f32", out, cyc); run<10>("v_rcp_f32", out, cyc); run<11>("v_cvt_f16_f32", out, cyc);
-  run<12>("v_sub_f32", out, cyc);
+  run<12>("v_sub_f32", out, cyc); run<13>("v_max_f32", out, cyc); run<14>("v_mul_f32", out, cyc);
+  run<17>("v_med3_f32", out, cyc);
   }
   return 0;
 }
