@@ -148,6 +148,46 @@ def test_full_width_motion_module(dev, c, hw, frames):
                 name=f"full-width motion module C={c} {hw}x{hw} F={frames}")
 
 
+@pytest.mark.parametrize("kind,c,hw,frames,gain", [("t2d", 320, 32, 16, 4.0), ("t2d", 1280, 8, 16, 3.0), ("motion", 320, 32, 16, 4.0),
+                                                     ("motion", 640, 16, 16, 3.0)])
+def test_full_width_sharp_attention(dev, kind, c, hw, frames, gain):
+    """the transformer and the motion module with every to_q / to_k weight multiplied by `gain`: logits grow by gain^2 (to
+    ~30 - 60, where trained checkpoints live; torch's default init keeps them under 3), the softmax rows become nearly one-hot
+    and the running-max / rescale path of every attention kernel decides the result.  (A row maximum taken from a quarter of
+    the keys passed every unit-scale test of rounds 1-2.)"""
+    host_threads()
+    if kind == "t2d":
+        from oracle.i2v_adapter import I2VAdapterTransformer2DModel as O
+        kw = dict(num_attention_heads=8, attention_head_dim=c // 8, in_channels=c, num_layers=1, cross_attention_dim=768,
+                  norm_num_groups=32)
+        hip_cls = pkg().I2VAdapterTransformer2DModel
+    else:
+        from oracle.blocks import TransformerTemporalModel as O
+        kw = dict(num_attention_heads=8, attention_head_dim=c // 8, in_channels=c, norm_num_groups=32, attention_bias=False,
+                  activation_fn="geglu", positional_embeddings="sinusoidal", num_positional_embeddings=32)
+        hip_cls = pkg().TransformerTemporalModel
+    m = hip_model_random(kw, dev, seed=c + hw + 7, cls=hip_cls)
+    with torch.no_grad():
+        n_scaled = 0
+        for name, prm in m.named_parameters():
+            if name.endswith(("to_q.weight", "to_k.weight")):
+                prm.mul_(gain)
+                n_scaled += 1
+    assert n_scaled >= 4
+    o = oracle_from_hip(m, O, kw)
+    g = torch.Generator().manual_seed(c + 2)
+    x = h(torch.randn(2 * frames, c, hw, hw, generator=g))
+    with torch.no_grad():
+        if kind == "t2d":
+            ctx = h(torch.randn(2 * frames, 77, 768, generator=g))
+            ref = o(x, enable_cross_frame_attn=True, num_frames=frames, encoder_hidden_states=ctx, return_dict=False)[0]
+            got = m(x.half().to(dev), enable_cross_frame_attn=True, num_frames=frames, encoder_hidden_states=ctx.half().to(dev),
+                    return_dict=False)[0]
+        else:
+            ref, got = o(x, num_frames=frames)[0], m(x.half().to(dev), num_frames=frames)[0]
+    compare(got, ref, rel=MODULE_REL_TOL * gain, name=f"sharp attention {kind} C={c} gain={gain}")
+
+
 @pytest.mark.parametrize("cin,cout,hw", [(320, 320, 64), (960, 320, 32), (2560, 1280, 8), (1280, 1280, 16)])
 def test_full_width_resnet(dev, cin, cout, hw):
     from oracle.blocks import ResnetBlock2D as O
