@@ -16,10 +16,11 @@ def timeit(fns):
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / (5 * len(fns)) * 1e3
 tag = os.environ.get("AB_TAG", "")
 torch.manual_seed(0)
-shapes = [(8192, 1280, 1280, True, False), (8192, 1280, 1280, False, True), (8192, 2560, 1280, False, True),
+shapes = [(131072, 320, 320, True, False), (131072, 320, 1280, True, False), (131072, 640, 320, False, True),
+          (8192, 1280, 1280, True, False), (8192, 1280, 1280, False, True), (8192, 2560, 1280, False, True),
           (8192, 1280, 2560, True, False), (8192, 1280, 5120, True, False), (32768, 640, 640, True, False)]
 for M, N, K, res, ln in shapes:
-    n = 12
+    n = 12 if M * K < (1 << 27) else 4
     As = [torch.randn(M, K, device=dev).half() for _ in range(n)]
     w = (torch.randn(N, K, device=dev) * K ** -0.5).half(); b = (torch.randn(N, device=dev) * 0.1).half()
     r = torch.randn(M, N, device=dev).half() if res else None
