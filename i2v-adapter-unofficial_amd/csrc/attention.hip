@@ -395,8 +395,10 @@ int launch_q(const i2v_attn_params& p, hipStream_t s) {
   const float scale_log2 = p.scale * 1.4426950408889634f;
   // measured (profiles/r1_tile_sweep.txt): 2 query tiles per wave keep 2 waves / SIMD resident, so one wave's
   // softmax VALU overlaps the other's MFMAs; 4 tiles drop to 1 wave / SIMD and serialise the two pipes.
+  // head_dim 160 (round 3, tools/attn_only.py): two tiles per wave win there too, although they leave one wave per SIMD
+  // (256 + 52 registers): 256 x 256 keys 37 -> 32 us, 1024 x 1024 409 -> 330 us; 128 left at one tile (not on the UNet's path).
   int qt = 1;
-  if (p.lq >= 128 && DQK <= 96) qt = 2;
+  if (p.lq >= 128 && (DQK <= 96 || DQK == 160)) qt = 2;
   static const int qt_env = getenv("I2V_ATTN_QT") ? atoi(getenv("I2V_ATTN_QT")) : 0;   // tuning overrides
   static const int kvt_env = getenv("I2V_ATTN_KVT") ? atoi(getenv("I2V_ATTN_KVT")) : 0;
   if (qt_env == 1 || qt_env == 2) qt = qt_env;
