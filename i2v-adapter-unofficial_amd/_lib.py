@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # I2V_LIB_PATH selects another build of the same ABI (same-box A/B of two kernels, tools/ab_bench.sh); the in-tree
 # library is never overwritten by tooling
 LIB_PATH = os.environ.get("I2V_LIB_PATH") or os.path.join(_HERE, "libi2v_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
 I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
@@ -56,6 +56,7 @@ class AttnParams(C.Structure):
         ("batch_q", C.c_int32), ("kv_group", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("lq", C.c_int32), ("lk", C.c_int32),
         ("scale", C.c_float), ("accumulate", C.c_int32), ("acc_scale", C.c_float),
+        ("lse", C.c_void_p),
     ]
 
 

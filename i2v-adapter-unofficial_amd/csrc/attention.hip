@@ -371,6 +371,10 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
     const float inv = 1.0f / lt;
     const int row = q0 + j * 16 + l15;
     if (row >= lq) continue;
+    // training forward: log2-sum-exp of the row = running reference + log2(sum of P against it) (v_log_f32 is log2); the four
+    // lane groups of a query hold the same reference, lane group 0 writes
+    if (p.lse != nullptr && g == 0)
+      p.lse[((int64_t)bq * p.heads + h) * lq + row] = __builtin_amdgcn_logf(lt) - negm[j][0];
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
       const int dd = i * 16 + 4 * g;
@@ -441,6 +445,7 @@ extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream)
   I2V_CHECK_ARG(p.batch_q > 0 && p.kv_group > 0 && p.batch_q % p.kv_group == 0,
                 "i2v_attention_f16: batch_q (%d) must be a positive multiple of kv_group (%d)", p.batch_q, p.kv_group);
   I2V_CHECK_ARG(p.heads > 0 && p.lq > 0 && p.lk > 0, "i2v_attention_f16: heads, lq, lk must be positive");
+  I2V_CHECK_ARG(!(p.lse != nullptr && p.accumulate), "i2v_attention_f16: lse output is not combined with accumulate");
   I2V_CHECK_ARG(p.head_dim > 0 && p.head_dim % 8 == 0 && p.head_dim <= 160,
                 "i2v_attention_f16: head_dim (%d) must be a multiple of 8 and <= 160", p.head_dim);
   I2V_CHECK_ARG(p.q_row_stride % 8 == 0 && p.k_row_stride % 8 == 0 && p.q_batch_stride % 8 == 0 &&

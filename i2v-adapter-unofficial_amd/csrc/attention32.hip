@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I2V_A32_WAV
 // tile cannot start before its S^T chain ends nor the PV chain before the softmax: per wave the three phases are serial,
 // and three or four waves per SIMD do not cover each other completely).  Kept as a tested alternative.
 int i2v_attention32_try(const i2v_attn_params& p, hipStream_t s) {
+  if (p.lse != nullptr) return 0;   // the log-sum-exp output exists in attn_kernel only
   static const int on = getenv("I2V_ATTN32") ? atoi(getenv("I2V_ATTN32")) : 0;
   if (!on || p.head_dim != 40 || p.lq < 128) return 0;   // head_dim 40: slot 40 of the 48-deep contraction is free
   const float scale_log2 = p.scale * 1.4426950408889634f;

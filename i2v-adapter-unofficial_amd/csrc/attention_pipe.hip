@@ -305,6 +305,7 @@ void attn_pipe_kernel(const i2v_attn_params p, const float scale_log2) {
 // 0: not taken (the caller falls through to attn_kernel); > 0 launched; < 0 launch error.  I2V_ATTN_PIPE=1 selects it for the
 // head_dim-40 problems whose keys are whole 64-key tiles (the 64 x 64 level's self and cross-frame attention).
 int i2v_attention_pipe_try(const i2v_attn_params& p, hipStream_t s) {
+  if (p.lse != nullptr) return 0;   // the log-sum-exp output exists in attn_kernel only
   static const int on = getenv("I2V_ATTN_PIPE") ? atoi(getenv("I2V_ATTN_PIPE")) : 0;
   if (!on) return 0;
   if (p.head_dim <= 32 || p.head_dim >= 48 || p.lk % 64 != 0 || p.lk < 192 || p.lq < 128) return 0;

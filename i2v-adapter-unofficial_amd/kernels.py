@@ -263,9 +263,11 @@ def project_vt(tokens, w_v, batch_len, out=None, bias=None, ln=None, pe_t=None, 
 
 # ---------------------------------------------------------------------------------------------- attention
 def attention(q, k, vt, *, batch_q, lq, lk, heads, head_dim, kv_group=1, scale=None, out=None, accumulate=False,
-              acc_scale=1.0):
+              acc_scale=1.0, return_lse=False):
     """Flash attention forward.  q [batch_q * lq, >= heads*head_dim] (row-strided view is fine),
-    k [batch_kv * lk, ...], vt [batch_kv, heads*head_dim, >= pad8(lk)], returns [batch_q * lq, heads*head_dim]."""
+    k [batch_kv * lk, ...], vt [batch_kv, heads*head_dim, >= pad8(lk)], returns [batch_q * lq, heads*head_dim]
+    (return_lse: the pair (out, fp32 [batch_q, heads, lq] log2-sum-exp of the scaled logits), written by the same pass: what
+    attention_bwd otherwise recomputes)."""
     lib = _lib.load()
     q, ldq = _mat(q, "q")
     k, ldk = _mat(k, "k")
@@ -293,8 +295,14 @@ def attention(q, k, vt, *, batch_q, lq, lk, heads, head_dim, kv_group=1, scale=N
     p.batch_q, p.kv_group, p.heads, p.head_dim, p.lq, p.lk = batch_q, kv_group, heads, head_dim, lq, lk
     p.scale = float(head_dim) ** -0.5 if scale is None else scale
     p.accumulate, p.acc_scale = 1 if accumulate else 0, acc_scale
+    lse = None
+    if return_lse:
+        if accumulate:
+            raise ValueError("return_lse is not combined with accumulate")
+        lse = torch.empty((batch_q, heads, lq), dtype=torch.float32, device=q.device)
+        p.lse = _p(lse)
     _lib.check(lib.i2v_attention_f16(C.byref(p), _stream()), "i2v_attention_f16")
-    return out
+    return (out, lse) if return_lse else out
 
 
 def temporal_attention(q, k, vt, *, n_pixels, frames, heads, head_dim, scale=None):
@@ -656,9 +664,9 @@ def rowdot_heads(a, b, *, rows_per_batch, heads, head_dim):
     return out
 
 
-def attention_bwd(q, k, v, o, dout, *, batch_q, lq, lk, heads, head_dim, kv_group=1, scale=None, need_dkv=True):
+def attention_bwd(q, k, v, o, dout, *, batch_q, lq, lk, heads, head_dim, kv_group=1, scale=None, need_dkv=True, lse=None):
     """Gradients of softmax(scale q k^T) v with respect to q (and k, v when need_dkv): token-major fp16 matrices in, the
-    channel-major operand copies, the log-sum-exp and delta are made here.  Returns (dq, dk, dv); dk / dv [batch_kv * lk, C]
+    channel-major operand copies, the log-sum-exp (unless `lse` from the forward pass is given) and delta are made here.  Returns (dq, dk, dv); dk / dv [batch_kv * lk, C]
     are summed over the kv_group batch entries that share k / v (the frames of a clip for the cross-frame attention)."""
     lib = _lib.load()
     q, ldq = _mat(q, "q")
@@ -668,7 +676,10 @@ def attention_bwd(q, k, v, o, dout, *, batch_q, lq, lk, heads, head_dim, kv_grou
     dout, ldo = _mat(dout, "dout")
     Cc, bkv = heads * head_dim, batch_q // kv_group
     sc = float(head_dim) ** -0.5 if scale is None else scale
-    lse = attention_lse(q, k, batch_q=batch_q, lq=lq, lk=lk, heads=heads, head_dim=head_dim, kv_group=kv_group, scale=sc)
+    if lse is None:   # (the forward pass can hand it over: attention(..., return_lse=True))
+        lse = attention_lse(q, k, batch_q=batch_q, lq=lq, lk=lk, heads=heads, head_dim=head_dim, kv_group=kv_group, scale=sc)
+    elif lse.dtype != torch.float32 or tuple(lse.shape) != (batch_q, heads, lq) or not lse.is_contiguous():
+        raise ValueError(f"lse must be contiguous fp32 [{batch_q}, {heads}, {lq}]")
     delta = rowdot_heads(dout, o, rows_per_batch=lq, heads=heads, head_dim=head_dim)
     kt = transpose_tokens(k[:, :Cc], lk)
     dq = torch.empty((batch_q * lq, Cc), dtype=f16, device=q.device)

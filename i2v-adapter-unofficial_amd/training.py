@@ -42,6 +42,42 @@ def wgrad(dy, x, tokens_per_batch=None):
     return K.gemm(dyt, xt, out_scale=WGRAD_OUT_SCALE).float() / WGRAD_OUT_SCALE
 
 
+class _Memo:
+    """Operand copies derived from weights (transposes for the dgrad GEMMs, flipped conv kernels, fused / concatenated
+    projections) keyed on the identity and the version counter of their source tensors: the frozen layers' copies are made
+    once; anything derived from a trainable tensor (the adapter's to_q / to_out, registered with mark_trainable) is remade on
+    every call, whatever its version counter says.  (Rebuilt every step
+    they were ~430 aten launches and 8 ms of a 148 ms step.)  The sources are kept referenced, so an id is never reused."""
+
+    def __init__(self):
+        self.d = {}
+        self.volatile = set()      # ids of the trainable tensors (registered by AdapterBlockTrainer)
+        self._keep = []
+
+    def mark_trainable(self, tensors):
+        for t in tensors:
+            self.volatile.add(id(t))
+            self._keep.append(t)
+
+    def get(self, tag, srcs, fn):
+        if any(id(t) in self.volatile for t in srcs):   # derived from a trainable tensor: never kept
+            return fn()
+        key = (tag,) + tuple(id(t) for t in srcs)
+        ver = tuple(t._version for t in srcs)
+        hit = self.d.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[2]
+        val = fn()
+        self.d[key] = (ver, srcs, val)
+        return val
+
+    def clear(self):
+        self.d.clear()
+
+
+_memo = _Memo()
+
+
 class AdapterBlockTrainer:
     """forward(...) keeps what backward(...) needs; backward returns {"hidden_states": dL/dx (fp16, still loss-scaled),
     "i2v_adapter.to_q.weight", "i2v_adapter.to_out.0.weight", "i2v_adapter.to_out.0.bias": fp32, un-scaled}."""
@@ -51,30 +87,37 @@ class AdapterBlockTrainer:
             raise NotImplementedError("the spatial block of the hot path has a text cross-attention")
         self.block = block
         self._saved = None
+        ad = block.i2v_adapter
+        _memo.mark_trainable([ad.to_q.weight, ad.to_out[0].weight, ad.to_out[0].bias])     # unet:1001-1006
 
     def _weights(self):
         b = self.block
         a1, ad, a2, ff = b.attn1, b.i2v_adapter, b.attn2, b.ff
-        t = lambda w: w16(w.detach().t())
-        w1, b1 = pack_geglu(ff.net[0].proj.weight.detach(), ff.net[0].proj.bias.detach())
+        mm = lambda tag, srcs, fn: _memo.get(tag, tuple(srcs), fn)
+        c16 = lambda prm: mm("w16", [prm], lambda: w16(prm))                     # fp16 contiguous copy of one parameter
+        t = lambda prm: mm("t", [prm], lambda: w16(prm.detach().t()))           # its transpose (dgrad operand)
+        pw, pb = ff.net[0].proj.weight, ff.net[0].proj.bias
+        w1, b1 = mm("geglu", [pw, pb], lambda: pack_geglu(pw.detach(), pb.detach()))
+        q1w, k1w, v1w, o1w, o1b = a1.to_q.weight, a1.to_k.weight, a1.to_v.weight, a1.to_out[0].weight, a1.to_out[0].bias
+        qaw, kaw, vaw, oaw, oab = ad.to_q.weight, ad.to_k.weight, ad.to_v.weight, ad.to_out[0].weight, ad.to_out[0].bias
         return dict(
-            g1=w16(b.norm1.weight), be1=w16(b.norm1.bias), g2=w16(b.norm2.weight), be2=w16(b.norm2.bias),
-            g3=w16(b.norm3.weight), be3=w16(b.norm3.bias),
-            w_qkq=w16(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0)), w_v1=w16(a1.to_v.weight),
-            w_k_ad=w16(ad.to_k.weight), w_v_ad=w16(ad.to_v.weight),
-            w_o_dual=w16(torch.cat([a1.to_out[0].weight, ad.to_out[0].weight], dim=1)),
-            b_o_dual=w16(a1.to_out[0].bias.float() + ad.to_out[0].bias.float()),
-            w_q2=w16(a2.to_q.weight), w_k2=w16(a2.to_k.weight), w_v2=w16(a2.to_v.weight),
-            w_o2=w16(a2.to_out[0].weight), b_o2=w16(a2.to_out[0].bias),
-            w1=w1, b1=b1, w2=w16(ff.net[2].weight), b2=w16(ff.net[2].bias),
-            w_k_ip=w16(a2.to_k_ip.weight) if a2.ip_num_tokens else None,
-            w_v_ip=w16(a2.to_v_ip.weight) if a2.ip_num_tokens else None,
+            g1=c16(b.norm1.weight), be1=c16(b.norm1.bias), g2=c16(b.norm2.weight), be2=c16(b.norm2.bias),
+            g3=c16(b.norm3.weight), be3=c16(b.norm3.bias),
+            w_qkq=mm("qkq", [q1w, k1w, qaw], lambda: w16(torch.cat([q1w, k1w, qaw], dim=0))), w_v1=c16(v1w),
+            w_k_ad=c16(kaw), w_v_ad=c16(vaw),
+            w_o_dual=mm("o_dual", [o1w, oaw], lambda: w16(torch.cat([o1w, oaw], dim=1))),
+            b_o_dual=mm("b_o_dual", [o1b, oab], lambda: w16(o1b.float() + oab.float())),
+            w_q2=c16(a2.to_q.weight), w_k2=c16(a2.to_k.weight), w_v2=c16(a2.to_v.weight),
+            w_o2=c16(a2.to_out[0].weight), b_o2=c16(a2.to_out[0].bias),
+            w1=w1, b1=b1, w2=c16(ff.net[2].weight), b2=c16(ff.net[2].bias),
+            w_k_ip=c16(a2.to_k_ip.weight) if a2.ip_num_tokens else None,
+            w_v_ip=c16(a2.to_v_ip.weight) if a2.ip_num_tokens else None,
             # dgrad operands: dX = dY W  ==  gemm(dY, w = W^T)
-            w2_t=t(ff.net[2].weight), w1_t=w16(w1.t()), w_o2_t=t(a2.to_out[0].weight), w_q2_t=t(a2.to_q.weight),
-            w_o1_t=t(a1.to_out[0].weight), w_oa_t=t(ad.to_out[0].weight),
-            w_qk1_t=w16(torch.cat([a1.to_q.weight.t(), a1.to_k.weight.t()], dim=1)),      # [C, 2C]: [dq1 | dk1] -> dn1
-            w_vqa_t=w16(torch.cat([a1.to_v.weight.t(), ad.to_q.weight.t()], dim=1)),      # [dv1 | dqa] -> dn1
-            w_kva_t=w16(torch.cat([ad.to_k.weight.t(), ad.to_v.weight.t()], dim=1)))      # [dk0 | dv0] -> dn1[frame 0]
+            w2_t=t(ff.net[2].weight), w1_t=mm("t", [w1], lambda: w16(w1.t())), w_o2_t=t(a2.to_out[0].weight),
+            w_q2_t=t(a2.to_q.weight), w_o1_t=t(o1w), w_oa_t=t(oaw),
+            w_qk1_t=mm("qk1_t", [q1w, k1w], lambda: w16(torch.cat([q1w.t(), k1w.t()], dim=1))),   # [C, 2C]: [dq1 | dk1] -> dn1
+            w_vqa_t=mm("vqa_t", [v1w, qaw], lambda: w16(torch.cat([v1w.t(), qaw.t()], dim=1))),   # [dv1 | dqa] -> dn1
+            w_kva_t=mm("kva_t", [kaw, vaw], lambda: w16(torch.cat([kaw.t(), vaw.t()], dim=1))))   # [dk0 | dv0] -> dn1[frame 0]
 
     @torch.no_grad()
     def forward(self, x, n_img, L, num_frames, ctx_text, ctx_ip=None):
@@ -90,13 +133,16 @@ class AdapterBlockTrainer:
         proj = K.gemm(n1, w["w_qkq"])                                                # [q1 | k1 | q_adapter]
         q1, k1, qa = proj[:, :c], proj[:, c:2 * c], proj[:, 2 * c:]
         v1 = K.gemm(n1, w["w_v1"])
-        o1 = K.attention(q1, k1, K.transpose_tokens(v1, L), batch_q=n_img, lq=L, lk=L, heads=heads, head_dim=d)
+        # (return_lse: the forward kernel writes each row's log2-sum-exp beside O; the backward sweeps take it from the tape
+        #  instead of recomputing Q K^T for it)
+        o1, lse1 = K.attention(q1, k1, K.transpose_tokens(v1, L), batch_q=n_img, lq=L, lk=L, heads=heads, head_dim=d,
+                               return_lse=True)
         first = torch.empty((clips, L, c), dtype=f16, device=x.device)
         K.copy3d(n1.view(clips, num_frames * L, c)[:, :L], first)                    # i2v:484 (frame-0 tokens, no repeat)
         f2d = first.view(-1, c)
         k0, v0 = K.gemm(f2d, w["w_k_ad"]), K.gemm(f2d, w["w_v_ad"])
-        oa = K.attention(qa, k0, K.transpose_tokens(v0, L), batch_q=n_img, lq=L, lk=L, heads=heads, head_dim=d,
-                         kv_group=num_frames)
+        oa, lsea = K.attention(qa, k0, K.transpose_tokens(v0, L), batch_q=n_img, lq=L, lk=L, heads=heads, head_dim=d,
+                               kv_group=num_frames, return_lse=True)
         x1 = K.gemm(o1, w["w_o_dual"], w["b_o_dual"], a2=oa, residual=x)
         n2 = K.layernorm(x1, w["g2"], w["be2"], b.eps)
         q2 = K.gemm(n2, w["w_q2"])
@@ -104,8 +150,8 @@ class AdapterBlockTrainer:
         ctx2d = ctx_text.reshape(-1, dc).contiguous()
         kc, vc = K.gemm(ctx2d, w["w_k2"]), K.gemm(ctx2d, w["w_v2"])
         group2 = n_img // bc
-        o2 = K.attention(q2, kc, K.transpose_tokens(vc, lt), batch_q=n_img, lq=L, lk=lt, heads=heads, head_dim=d,
-                         kv_group=group2)
+        o2, lse2 = K.attention(q2, kc, K.transpose_tokens(vc, lt), batch_q=n_img, lq=L, lk=lt, heads=heads, head_dim=d,
+                               kv_group=group2, return_lse=True)
         ip = None
         if ctx_ip is not None and b.attn2.ip_num_tokens:
             li = ctx_ip.shape[1]
@@ -113,11 +159,11 @@ class AdapterBlockTrainer:
             kip, vip = K.gemm(ip2d, w["w_k_ip"]), K.gemm(ip2d, w["w_v_ip"])
             vipt = K.transpose_tokens(vip, li)
             kw = dict(batch_q=n_img, lq=L, lk=li, heads=heads, head_dim=d, kv_group=group2)
-            o_ip = K.attention(q2, kip, vipt, **kw)                                   # kept alone: its backward needs it
+            o_ip, lse_ip = K.attention(q2, kip, vipt, return_lse=True, **kw)          # kept alone: its backward needs it
             o_sum = torch.empty_like(o2)
             K.copy3d(o2.view(1, -1, c), o_sum.view(1, -1, c))
             K.attention(q2, kip, vipt, out=o_sum, accumulate=True, acc_scale=float(b.attn2.ip_scale), **kw)
-            ip = dict(k=kip, v=vip, o=o_ip, li=li, scale=float(b.attn2.ip_scale))
+            ip = dict(k=kip, v=vip, o=o_ip, li=li, scale=float(b.attn2.ip_scale), lse=lse_ip)
             o2_text, o2 = o2, o_sum
         else:
             o2_text = o2
@@ -127,7 +173,8 @@ class AdapterBlockTrainer:
         y = K.gemm(n3, w["w1"], w["b1"], epilogue=I2V_EPI_GEGLU)
         x3 = K.gemm(y, w["w2"], w["b2"], residual=x2)
         self._saved = dict(w=w, x=x, n1=n1, q1=q1, k1=k1, qa=qa, v1=v1, o1=o1, k0=k0, v0=v0, oa=oa, x1=x1, q2=q2, kc=kc,
-                           vc=vc, o2=o2_text, ip=ip, x2=x2, h=h, n_img=n_img, L=L, F=num_frames, lt=lt, group2=group2)
+                           vc=vc, o2=o2_text, ip=ip, x2=x2, h=h, n_img=n_img, L=L, F=num_frames, lt=lt, group2=group2,
+                           lse1=lse1, lsea=lsea, lse2=lse2)
         return x3
 
     @torch.no_grad()
@@ -148,11 +195,11 @@ class AdapterBlockTrainer:
         # text cross-attention (i2v:510-533); the context K / V are frozen: dQ only
         do2 = K.gemm(g2, w["w_o2_t"])
         dq2, _, _ = K.attention_bwd(s["q2"], s["kc"], s["vc"], s["o2"], do2, batch_q=n_img, lq=L, lk=s["lt"], heads=heads,
-                                    head_dim=d, kv_group=s["group2"], need_dkv=False)
+                                    head_dim=d, kv_group=s["group2"], need_dkv=False, lse=s["lse2"])
         if s["ip"] is not None:       # + ip_scale * softmax(q K_ip^T) V_ip: the same query, frozen K / V; dq is linear in dO
             ipb = s["ip"]
             dq_ip, _, _ = K.attention_bwd(s["q2"], ipb["k"], ipb["v"], ipb["o"], do2, batch_q=n_img, lq=L, lk=ipb["li"],
-                                          heads=heads, head_dim=d, kv_group=s["group2"], need_dkv=False)
+                                          heads=heads, head_dim=d, kv_group=s["group2"], need_dkv=False, lse=ipb["lse"])
             dn2 = K.gemm(dq2, w["w_q2_t"], residual=K.gemm(dq_ip, w["w_q2_t"], out_scale=ipb["scale"]))
         else:
             dn2 = K.gemm(dq2, w["w_q2_t"])
@@ -162,9 +209,9 @@ class AdapterBlockTrainer:
         d_wout = wgrad(g1, s["oa"])                                                   # i2v_adapter.to_out.0.weight
         d_bout = K.colsum(g1)
         dq1, dk1, dv1 = K.attention_bwd(s["q1"], s["k1"], s["v1"], s["o1"], do1, batch_q=n_img, lq=L, lk=L, heads=heads,
-                                        head_dim=d)
+                                        head_dim=d, lse=s["lse1"])
         dqa, dk0, dv0 = K.attention_bwd(s["qa"], s["k0"], s["v0"], s["oa"], doa, batch_q=n_img, lq=L, lk=L, heads=heads,
-                                        head_dim=d, kv_group=F)                       # dK0 / dV0 summed over the frames
+                                        head_dim=d, kv_group=F, lse=s["lsea"])        # dK0 / dV0 summed over the frames
         d_wq = wgrad(dqa, s["n1"])                                                    # i2v_adapter.to_q.weight
         dn1 = K.gemm(dq1, w["w_qk1_t"], a2=dk1)
         dn1 = K.gemm(dv1, w["w_vqa_t"], a2=dqa, residual=dn1, out=dn1)
@@ -186,12 +233,14 @@ from .blocks import pack_conv3x3  # noqa: E402
 
 
 def conv_dgrad_weight(weight, cout_pad=None):
-    """packed weights of the input-gradient convolution: W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]."""
-    return pack_conv3x3(weight.detach().transpose(0, 1).flip(2, 3), cin_pad=cout_pad)
+    """packed weights of the input-gradient convolution: W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx] (made once per weight
+    version: the convolutions are frozen)."""
+    return _memo.get(("conv_dgrad", cout_pad), (weight,),
+                     lambda: pack_conv3x3(weight.detach().transpose(0, 1).flip(2, 3), cin_pad=cout_pad))
 
 
 def _t(w):
-    return w16(w.detach().t())
+    return _memo.get("t", (w,), lambda: w16(w.detach().t()))
 
 
 class ResnetTrainer:
@@ -229,11 +278,14 @@ class ResnetTrainer:
         dx, dx2 = res if x2 is not None else (res, None)
         g2d = g.view(-1, m.out_channels)
         if m.conv_shortcut is not None:
-            wst = _t(m.conv_shortcut.weight.reshape(m.out_channels, m.in_channels))          # [Cin, Cout]
-            dx = K.gemm(g2d, wst[:c1].contiguous(), residual=dx.view(-1, c1)).view(n, hh, ww, c1)
+            sw = m.conv_shortcut.weight
+            wst = _memo.get("shortcut_t", (sw,), lambda: w16(sw.detach().reshape(m.out_channels, m.in_channels).t()))   # [Cin, Cout]
+            dx = K.gemm(g2d, _memo.get(("shortcut_t_lo", c1), (sw,), lambda: wst[:c1].contiguous()),
+                        residual=dx.view(-1, c1)).view(n, hh, ww, c1)
             if x2 is not None:
                 c2 = x2.shape[3]
-                dx2 = K.gemm(g2d, wst[c1:].contiguous(), residual=dx2.view(-1, c2)).view(n, hh, ww, c2)
+                dx2 = K.gemm(g2d, _memo.get(("shortcut_t_hi", c1), (sw,), lambda: wst[c1:].contiguous()),
+                             residual=dx2.view(-1, c2)).view(n, hh, ww, c2)
         else:
             dx = K.add(dx, g)
         return dx, dx2
@@ -318,14 +370,14 @@ class MotionModuleTrainer:
         gp = K.permute_rows(g.view(-1, c), clips, F, hw, True)
         dt = K.gemm(gp, _t(p["wo"]))                                                  # dL/dt3
         dy = K.gemm(dt, _t(ff["w2"]))
-        dn3 = K.gemm(K.geglu_bwd(h, dy), w16(ff["w1"].t()))
+        dn3 = K.gemm(K.geglu_bwd(h, dy), _t(ff["w1"]))
         dt = K.layernorm_bwd(t2, dn3, q["g3"], blk.eps, add=dt)
         for i in (2, 1):
             t_in, qk, v, o = stages[i - 1]
             do = K.gemm(dt, _t(q[f"wo{i}"]))
             dq, dk, dv = K.attention_bwd(qk[:, :c], qk[:, c:], v, o, do, batch_q=n_pixels, lq=F, lk=F, heads=blk.heads,
                                          head_dim=blk.dim_head, scale=blk.dim_head ** -0.5)
-            dnl = K.gemm(dq, w16(q[f"wqk{i}"].t()), a2=dk)                            # [dq | dk] [Wq ; Wk]
+            dnl = K.gemm(dq, _t(q[f"wqk{i}"]), a2=dk)                            # [dq | dk] [Wq ; Wk]
             dnl = K.gemm(dv, _t(q[f"wv{i}"]), residual=dnl, out=dnl)
             dt = K.layernorm_bwd(t_in, dnl, q[f"g{i}"], blk.eps, add=dt)
         dnp = K.gemm(dt, _t(p["wi"]))
@@ -552,4 +604,4 @@ class AdapterOptimizer:
                      max_norm=self.max_norm)
         for n, prm in zip(self.names, self.params):
             off, cnt = self.offsets[n]
-            prm.data.copy_(self.master[off: off + cnt].view_as(prm))
+            prm.copy_(self.master[off: off + cnt].view_as(prm))   # (on the parameter itself: its version counter moves)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 5
+#define I2V_ABI_VERSION 6
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -174,6 +174,9 @@ typedef struct i2v_attn_params {
   float scale;
   int32_t accumulate;
   float acc_scale;
+  float* lse;     /* optional (ABI 6): fp32 [batch_q][heads][lq], the log2-sum-exp of the scaled logits of every query row,
+                     written by the forward pass itself (what i2v_attention_lse_f32 recomputes; the training step keeps it
+                     for i2v_attention_bwd_f16).  NULL: not written.  Not combined with accumulate.                       */
 } i2v_attn_params;
 
 int i2v_attention_f16(const i2v_attn_params* p, i2v_stream_t stream);

@@ -72,6 +72,21 @@ def test_attention_lse(dev, lq, lk):
     got = K.attention_lse(q.half().to(dev).view(-1, heads * d), k.half().to(dev).view(-1, heads * d), batch_q=bq, lq=lq, lk=lk,
                           heads=heads, head_dim=d)
     compare(got, ref, rel=1e-3, name="attention log2-sum-exp")
+    # the same written by the forward pass itself (i2v_attn_params.lse, ABI 6), every head_dim class of the UNet
+    for d2, heads2 in ((40, 4), (80, 2), (160, 2), (64, 2)):
+        C2 = heads2 * d2
+        q2, k2 = h(torch.randn(bq, lq, C2, generator=g) * 1.5), h(torch.randn(bq, lk, C2, generator=g) * 1.5)
+        v2 = h(torch.randn(bq, lk, C2, generator=g))
+        s2 = torch.einsum("blhd,bmhd->bhlm", q2.view(bq, lq, heads2, d2), k2.view(bq, lk, heads2, d2)) * d2 ** -0.5
+        to = lambda t: t.half().to(dev).reshape(-1, C2)
+        o_plain = K.attention(to(q2), to(k2), K.transpose_tokens(to(v2), lk), batch_q=bq, lq=lq, lk=lk, heads=heads2, head_dim=d2)
+        o_fused, lse_fused = K.attention(to(q2), to(k2), K.transpose_tokens(to(v2), lk), batch_q=bq, lq=lq, lk=lk, heads=heads2,
+                                         head_dim=d2, return_lse=True)
+        assert torch.equal(o_plain, o_fused)
+        compare(lse_fused, torch.logsumexp(s2, dim=-1) * 1.4426950408889634, rel=1e-3, name=f"fused log2-sum-exp d={d2}")
+        with pytest.raises(ValueError, match="accumulate"):
+            K.attention(to(q2), to(k2), K.transpose_tokens(to(v2), lk), batch_q=bq, lq=lq, lk=lk, heads=heads2, head_dim=d2,
+                        out=o_plain, accumulate=True, return_lse=True)
 
 
 @pytest.mark.parametrize("d,lq,lk,group,amp", [(40, 192, 256, 2, 3.0), (80, 64, 128, 1, 3.0), (40, 512, 640, 1, 2.5)])
@@ -98,10 +113,47 @@ def test_attention_backward_large_logits(dev, d, lq, lk, group, amp):
     od = K.attention(qd, kd, K.transpose_tokens(vd, lk), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
     compare(od, o.reshape(-1, C), rel=6e-4 * amp * amp, name="attention forward, large logits")
     dq, dk, dv = K.attention_bwd(qd, kd, vd, od, to(do), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group)
+    # ... and with the log-sum-exp the forward pass wrote (what the trainer does)
+    od2, lse_f = K.attention(qd, kd, K.transpose_tokens(vd, lk), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group,
+                             return_lse=True)
+    compare(lse_f, torch.logsumexp(s, dim=-1) * 1.4426950408889634, rel=2e-3, name="fused log2-sum-exp, large logits")
+    dq_f, dk_f, dv_f = K.attention_bwd(qd, kd, vd, od2, to(do), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group,
+                                       lse=lse_f)
     rel = GRAD_REL_TOL * amp * amp
+    compare(dq_f, q.grad.reshape(-1, C), rel=rel, name="dQ from the forward's log-sum-exp")
+    compare(dk_f, k.grad.reshape(-1, C), rel=rel, name="dK from the forward's log-sum-exp")
+    compare(dv_f, v.grad.reshape(-1, C), rel=rel, name="dV from the forward's log-sum-exp")
     compare(dq, q.grad.reshape(-1, C), rel=rel, name="dQ, large logits")
     compare(dk, k.grad.reshape(-1, C), rel=rel, name="dK, large logits")
     compare(dv, v.grad.reshape(-1, C), rel=rel, name="dV, large logits")
+
+
+def test_trainer_operand_cache_follows_the_trainable_weights(dev):
+    """the copies derived from weights (transposes, fused projections, flipped conv kernels) are made once for the frozen
+    layers; whatever depends on the adapter's to_q / to_out is remade on every step, also when the optimiser writes the
+    parameter through `.data` (no version bump)."""
+    p = pkg()
+    from i2v_adapter_unofficial_amd.training import AdapterBlockTrainer
+    torch.manual_seed(3)
+    dim, heads = 64, 2
+    m = p.I2VAdapterTransformerBlock(dim, heads, dim // heads, dropout=0.0, cross_attention_dim=48)
+    m = m.to(device=dev, dtype=torch.float16).eval()
+    tr = AdapterBlockTrainer(m)
+    w0 = tr._weights()
+    qa_before = w0["w_qkq"][2 * dim:].clone()
+    m.i2v_adapter.to_q.weight.data.mul_(2.0)                  # what an optimiser step through .data does
+    m.i2v_adapter.to_out[0].weight.data.add_(1.0)
+    w1 = tr._weights()
+    assert torch.equal(w1["w_qkq"][2 * dim:], (qa_before.float() * 2).half())
+    assert torch.equal(w1["w_oa_t"], m.i2v_adapter.to_out[0].weight.detach().t().contiguous())
+    assert torch.equal(w1["w_o_dual"][:, dim:], m.i2v_adapter.to_out[0].weight.detach())
+    assert w1["w2_t"] is w0["w2_t"] and w1["w_qk1_t"] is w0["w_qk1_t"] and w1["w1"] is w0["w1"]      # frozen: made once
+    m.ff.net[2].weight.mul_(0.5) if not m.ff.net[2].weight.requires_grad else m.ff.net[2].weight.data.mul_(0.5)
+    with torch.no_grad():
+        m.attn1.to_q.weight.mul_(0.5)                          # an in-place write bumps the version: the copy is remade
+    w2 = tr._weights()
+    assert w2["w_qk1_t"] is not w0["w_qk1_t"]
+    assert torch.equal(w2["w_qk1_t"][:, :dim], m.attn1.to_q.weight.detach().t().contiguous())
 
 
 def test_layernorm_geglu_backward_and_sums(dev):
