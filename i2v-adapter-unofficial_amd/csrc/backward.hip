@@ -783,6 +783,26 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* __restrict__ 
   }
 }
 
+// GEGLU forward from the stored pre-activation: y[.., i] = h[.., 2 i] gelu(h[.., 2 i + 1]) (the training forward keeps h for the
+// backward and derives y from it, instead of running the projection GEMM a second time with the fused GEGLU epilogue)
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const f16* __restrict__ hh, int64_t ldh, f16* __restrict__ y, int64_t ldy,
+                                                        int64_t rows, int inner) {
+  const int nvec = inner / 8;    // 8 outputs = 16 interleaved inputs per thread
+  const int64_t total = rows * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / nvec;
+    const int v = (int)(idx - row * nvec);
+    const f16x8 h0 = ld_global_16B(hh + row * ldh + 16 * v), h1 = ld_global_16B(hh + row * ldh + 16 * v + 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (f16)((float)h0[2 * e] * gelu_erf((float)h0[2 * e + 1]));
+      o[4 + e] = (f16)((float)h1[2 * e] * gelu_erf((float)h1[2 * e + 1]));
+    }
+    *reinterpret_cast<f16x8*>(y + row * ldy + 8 * v) = o;
+  }
+}
+
 // out[c] += sum_r x[r][c] (fp32 atomics over row chunks; out is zeroed / accumulated by the caller)
 __global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ x, int64_t ldx, float* __restrict__ out,
                                                      int64_t rows, int cols, int64_t rows_per_block) {
@@ -1077,6 +1097,15 @@ extern "C" int i2v_geglu_bwd_f16(const void* h, int64_t ldh, const void* dy, int
                      reinterpret_cast<const f16*>(h), ldh, reinterpret_cast<const f16*>(dy), lddy, reinterpret_cast<f16*>(dh),
                      lddh, rows, inner);
   return i2v_check_launch("i2v_geglu_bwd_f16");
+}
+
+extern "C" int i2v_geglu_f16(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t rows, int32_t inner, i2v_stream_t stream) {
+  I2V_CHECK_ARG(h && y && rows > 0 && inner > 0 && inner % 8 == 0 && ldh % 8 == 0 && ldy % 8 == 0 && ldh >= 2 * inner &&
+                    ldy >= inner && al16(h) && al16(y),
+                "i2v_geglu_f16: bad arguments");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_grid(rows * (inner / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(h), ldh, reinterpret_cast<f16*>(y), ldy, rows, inner);
+  return i2v_check_launch("i2v_geglu_f16");
 }
 
 extern "C" int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t rows, int32_t cols, i2v_stream_t stream) {

@@ -726,6 +726,19 @@ def layernorm_bwd(x, dn, gamma, eps, add=None):
     return dx
 
 
+def geglu(h):
+    """y [rows, inner] = value * gelu_erf(gate) from the interleaved (value, gate) pre-activation h [rows, 2 inner]
+    (i2v_geglu_f16: what the I2V_EPI_GEGLU epilogue applies, run on a stored h)."""
+    lib = _lib.load()
+    h, ldh = _mat(h, "h")
+    rows, two_inner = h.shape
+    if two_inner % 16 != 0:
+        raise ValueError("geglu: the inner width must be a multiple of 8")
+    y = torch.empty((rows, two_inner // 2), dtype=f16, device=h.device)
+    _lib.check(lib.i2v_geglu_f16(_p(h), ldh, _p(y), two_inner // 2, rows, two_inner // 2, _stream()), "i2v_geglu_f16")
+    return y
+
+
 def geglu_bwd(h, dy):
     """h [rows, 2 inner] interleaved (value, gate) pre-activation, dy [rows, inner] -> dh [rows, 2 inner] (same order)."""
     lib = _lib.load()

@@ -26,7 +26,6 @@ and `AdapterOptimizer` (clip + AdamW over flat fp32 buckets, ONE all-reduce of t
 import torch
 
 from . import kernels as K
-from ._lib import I2V_EPI_GEGLU
 from .blocks import pack_geglu, w16
 
 f16 = torch.float16
@@ -170,7 +169,7 @@ class AdapterBlockTrainer:
         x2 = K.gemm(o2, w["w_o2"], w["b_o2"], residual=x1)
         n3 = K.layernorm(x2, w["g3"], w["be3"], b.eps)
         h = K.gemm(n3, w["w1"], w["b1"])                                             # pre-activation, (value, gate) interleaved
-        y = K.gemm(n3, w["w1"], w["b1"], epilogue=I2V_EPI_GEGLU)
+        y = K.geglu(h)                                                               # (kept for the backward: one GEMM, not two)
         x3 = K.gemm(y, w["w2"], w["b2"], residual=x2)
         self._saved = dict(w=w, x=x, n1=n1, q1=q1, k1=k1, qa=qa, v1=v1, o1=o1, k0=k0, v0=v0, oa=oa, x1=x1, q2=q2, kc=kc,
                            vc=vc, o2=o2_text, ip=ip, x2=x2, h=h, n_img=n_img, L=L, F=num_frames, lt=lt, group2=group2,
@@ -353,7 +352,7 @@ class MotionModuleTrainer:
         ff = blk.ff.packed()
         n3 = K.layernorm(t, q["g3"], q["b3"], blk.eps)
         h = K.gemm(n3, ff["w1"], ff["b1"])
-        y = K.gemm(n3, ff["w1"], ff["b1"], epilogue=I2V_EPI_GEGLU)
+        y = K.geglu(h)
         t3 = K.gemm(y, ff["w2"], ff["b2"], residual=t)
         self.saved = (x, stages, t, h)
         return K.gemm(t3, p["wo"], p["bo"], residual=x.view(-1, c), store=I2V_STORE_ROWPERM, frames=F, hw=hw).view(n, hh, ww, c)

@@ -373,6 +373,10 @@ int i2v_layernorm_bwd_f16(const void* x, int64_t ldx, const void* dn, int64_t ld
  * I2V_EPI_GEGLU, dy [rows, inner] -> dh[.., 2i] = dy gelu(gate), dh[.., 2i + 1] = dy value gelu'(gate). */
 int i2v_geglu_bwd_f16(const void* h, int64_t ldh, const void* dy, int64_t lddy, void* dh, int64_t lddh, int64_t rows,
                       int32_t inner, i2v_stream_t stream);
+/* GEGLU forward from a stored pre-activation (ABI 6): y[r][i] = h[r][2 i] gelu_erf(h[r][2 i + 1]), h [rows][>= 2 inner] with
+ * (value, gate) interleaved as the I2V_EPI_GEGLU GEMM packs its weights, y [rows][>= inner]; inner % 8 == 0.  The training
+ * forward keeps h for i2v_geglu_bwd_f16 and derives y from it (diffusers GEGLU.forward, i2v:554). */
+int i2v_geglu_f16(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t rows, int32_t inner, i2v_stream_t stream);
 /* out[c] += sum_r x[r][c], fp32 (the bias gradient of a Linear; the caller zeroes out before the first call). */
 int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t rows, int32_t cols, i2v_stream_t stream);
 /* Seed gradient of the training loss (train_image_to_video.py:848-856: MSE summed over every frame but the first of each

@@ -156,6 +156,25 @@ def test_trainer_operand_cache_follows_the_trainable_weights(dev):
     assert torch.equal(w2["w_qk1_t"][:, :dim], m.attn1.to_q.weight.detach().t().contiguous())
 
 
+def test_geglu_forward_from_stored_preactivation(dev):
+    """i2v_geglu_f16 against torch and against the GEMM's fused GEGLU epilogue on the same operands"""
+    K = pkg().kernels
+    g = torch.Generator().manual_seed(6)
+    rows, C, inner = 300, 64, 128
+    x = h(torch.randn(rows, C, generator=g) * 2)
+    w = h(torch.randn(2 * inner, C, generator=g) / 8)
+    b = h(torch.randn(2 * inner, generator=g))
+    xd, wd, bd = x.half().to(dev), w.half().to(dev), b.half().to(dev)
+    hd = K.gemm(xd, wd, bd)
+    y = K.geglu(hd)
+    hf = hd.float().cpu()
+    compare(y, hf[:, 0::2] * torch.nn.functional.gelu(hf[:, 1::2]), rel=1e-3, name="geglu forward")
+    compare(y, K.gemm(xd, wd, bd, epilogue=K.I2V_EPI_GEGLU).float().cpu(), rel=2e-3, name="geglu forward vs the fused epilogue")
+    big = torch.tensor([[30.0, 40.0, -30.0, -40.0, 5.0, -20.0, 0.0, 0.0] * 2], device=dev).half()      # saturated gates
+    yb = K.geglu(big).float().cpu()
+    assert torch.isfinite(yb).all() and torch.allclose(yb[0, :4], torch.tensor([1200.0, 0.0, 0.0, 0.0]), atol=1e-3)
+
+
 def test_layernorm_geglu_backward_and_sums(dev):
     K = pkg().kernels
     g = torch.Generator().manual_seed(5)
