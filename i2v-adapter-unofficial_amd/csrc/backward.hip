@@ -368,15 +368,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_pa
 // The same sweep with the query-side operands of a 32-query block (Q, dO rows; Q^T, dO^T rows; lse, delta) staged ONCE per
 // workgroup in LDS (two stages, the next block's chunks in flight in registers under the current block's MFMAs) instead of
 // fetched from L2 by each of the four waves: a quarter of the L2 traffic, and no load round trip inside an iteration.
-template <int KS, int DT, int U>
+// QB: queries per staged block (one barrier per block): 32, or 64 = two 32-query contraction steps per barrier
+template <int KS, int DT, int U, int QB = 32>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bwd_params p, const float c) {
   constexpr int RS = KS * 32 + 8;                    // LDS row stride of the Q / dO tiles (halfs)
-  constexpr int TS = 32 + 8;                         // ... of the Q^T / dO^T tiles
-  constexpr int QCH = 32 * KS * 4;                   // 16-byte chunks of a [32][KS * 32] tile
-  constexpr int TCH = DT * 16 * 4;                   // ... of a [DT * 16][32] tile
+  constexpr int TS = QB + 8;                         // ... of the Q^T / dO^T tiles
+  constexpr int QCH = QB * KS * 4;                   // 16-byte chunks of a [QB][KS * 32] tile
+  constexpr int TCH = DT * 16 * (QB / 8);            // ... of a [DT * 16][QB] tile
   constexpr int NQ = (QCH + 255) / 256, NT = (TCH + 255) / 256;
-  constexpr int STAGE_H = 2 * 32 * RS + 2 * DT * 16 * TS;     // halfs per stage (+ 64 floats of lse / delta)
-  __shared__ __attribute__((aligned(16))) f16 lds[2 * (STAGE_H + 128)];
+  constexpr int STAGE_H = 2 * QB * RS + 2 * DT * 16 * TS;     // halfs per stage (+ 2 QB floats of lse / delta)
+  __shared__ __attribute__((aligned(16))) f16 lds[2 * (STAGE_H + 4 * QB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int h = blockIdx.y, bkv = blockIdx.z, d = p.head_dim;
   const int key0 = blockIdx.x * (64 * U) + wave * (16 * U);
@@ -394,12 +395,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
 #pragma unroll
     for (int i = 0; i < DT; ++i) dk[u][i] = dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int nqb = (p.lq + 31) / 32, nit = p.kv_group * nqb;
+  const int nqb = (p.lq + QB - 1) / QB, nit = p.kv_group * nqb;
   const int lq8 = (p.lq + 7) & ~7;
   f16x8 rq[NQ], rdo[NQ], rqt[NT], rdot[NT];
   float rl = 0.f, rd = 0.f;
   auto fetch = [&](int it) {
-    const int f = it / nqb, qb = (it - f * nqb) * 32;
+    const int f = it / nqb, qb = (it - f * nqb) * QB;
     const int bq = bkv * p.kv_group + f;
     const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
     const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
@@ -414,21 +415,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int t = tid + 256 * i, row = t >> 2, ch = t & 3;
+      const int t = tid + 256 * i, row = t / (QB / 8), ch = t - row * (QB / 8);
       const bool ok = t < TCH && row < d && qb + 8 * ch < lq8;
       rqt[i] = ok ? ld_global_16B(QT + (int64_t)row * p.qt_row_stride + qb + 8 * ch) : zero8();
       rdot[i] = ok ? ld_global_16B(DOT + (int64_t)row * p.dot_row_stride + qb + 8 * ch) : zero8();
     }
-    if (tid < 32) {
+    if (tid < QB) {
       const int64_t st = ((int64_t)bq * p.heads + h) * p.lq + min(qb + tid, p.lq - 1);
       rl = p.lse[st];
       rd = p.delta[st];
     }
   };
   auto commit = [&](int stage) {
-    f16* sq = lds + stage * (STAGE_H + 128);
-    f16* sdo = sq + 32 * RS;
-    f16* sqt = sdo + 32 * RS;
+    f16* sq = lds + stage * (STAGE_H + 4 * QB);
+    f16* sdo = sq + QB * RS;
+    f16* sqt = sdo + QB * RS;
     f16* sdot = sqt + DT * 16 * TS;
     float* sst = reinterpret_cast<float*>(sdot + DT * 16 * TS);
 #pragma unroll
@@ -441,15 +442,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int t = tid + 256 * i, row = t >> 2, ch = t & 3;
+      const int t = tid + 256 * i, row = t / (QB / 8), ch = t - row * (QB / 8);
       if (t < TCH) {
         *reinterpret_cast<f16x8*>(sqt + row * TS + 8 * ch) = rqt[i];
         *reinterpret_cast<f16x8*>(sdot + row * TS + 8 * ch) = rdot[i];
       }
     }
-    if (tid < 32) {
+    if (tid < QB) {
       sst[tid] = rl;
-      sst[32 + tid] = rd;
+      sst[QB + tid] = rd;
     }
   };
   fetch(0);
@@ -457,12 +458,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
   __syncthreads();
   for (int it = 0; it < nit; ++it) {
     if (it + 1 < nit) fetch(it + 1);
-    const int qb = (it % nqb) * 32;
-    const f16* sq = lds + (it & 1) * (STAGE_H + 128);
-    const f16* sdo = sq + 32 * RS;
-    const f16* sqt = sdo + 32 * RS;
-    const f16* sdot = sqt + DT * 16 * TS;
-    const float* sst = reinterpret_cast<const float*>(sdot + DT * 16 * TS);
+    const f16* sq0 = lds + (it & 1) * (STAGE_H + 4 * QB);
+    const f16* sdo0 = sq0 + QB * RS;
+    const f16* sqt0 = sdo0 + QB * RS;
+    const f16* sdot0 = sqt0 + DT * 16 * TS;
+    const float* sst0 = reinterpret_cast<const float*>(sdot0 + DT * 16 * TS);
+#pragma unroll
+    for (int sb = 0; sb < QB / 32; ++sb) {   // 32-query contraction steps of the staged block
+    const int qb = (it % nqb) * QB + 32 * sb;
+    const f16* sq = sq0 + 32 * sb * RS;
+    const f16* sdo = sdo0 + 32 * sb * RS;
+    const f16* sqt = sqt0 + 32 * sb;
+    const f16* sdot = sdot0 + 32 * sb;
+    const float* sst = sst0 + 32 * sb;
     float pv[U][2][4], ds[U][2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
         da[s2] = *reinterpret_cast<const f16x8*>(sdo + r * RS + 32 * s2 + 8 * g);
       }
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(sst + 8 * g + 4 * t);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sst + 32 + 8 * g + 4 * t);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sst + QB + 8 * g + 4 * t);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const f32x4 s = chain<KS>(qa, kf[u]);
@@ -504,6 +512,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
         dk[u][i] = mfma16x16x32(a2, dsb[u], dk[u][i]);
       }
     }
+    }   // sb
     if (it + 1 < nit) commit((it + 1) & 1);     // the other stage was last read in iteration it - 1 (closed by its barrier)
     __syncthreads();
   }
@@ -970,7 +979,19 @@ int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
   if (p.dk != nullptr) {
     const dim3 gk((unsigned)i2v_cdiv(p.lk, two_k ? 128 : 64), p.heads, p.batch_q / p.kv_group);
     static const int lds_off = getenv("I2V_ATTN_BWD_LDS") ? (atoi(getenv("I2V_ATTN_BWD_LDS")) == 0) : 0;
-    if (two_k && !lds_off && p.lq >= 64) hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
+    // 64 staged queries per barrier (two 32-query contraction steps): the 32-query loop has 28 MFMAs per wave between barriers.
+    // Same box, 16 frames x 4096 tokens, d = 40 (tools/attn_bwd_probe.py): self-attention backward 2.95 -> 2.73 ms per call, the
+    // cross-frame form (one K / V for 16 frames: 256 workgroups walking 1024 blocks each) 3.72 -> 3.16.  I2V_ATTN_BWD_QB=32: off.
+    static const int qb64 = getenv("I2V_ATTN_BWD_QB") ? (atoi(getenv("I2V_ATTN_BWD_QB")) == 64) : 1;
+    bool done = false;
+    if constexpr (DT <= 6) {   // (two_k implies it; the 64-query stages of wider heads would not fit LDS)
+      if (two_k && !lds_off && p.lq >= 128 && qb64) {
+        hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<KS, DT, 2, 64>), gk, dim3(256), 0, s, p, c);
+        done = true;
+      }
+    }
+    if (done) {
+    } else if (two_k && !lds_off && p.lq >= 64) hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
     else if (two_k) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 1>), gk, dim3(256), 0, s, p, c);
     rc = i2v_check_launch("i2v_attention_bwd_f16(dK, dV)");
