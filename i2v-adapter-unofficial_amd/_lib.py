@@ -75,7 +75,7 @@ class AttnBwdParams(C.Structure):
         ("dv", C.c_void_p), ("dv_row_stride", C.c_int64), ("dv_batch_stride", C.c_int64),
         ("batch_q", C.c_int32), ("kv_group", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("lq", C.c_int32), ("lk", C.c_int32),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("kv_partitions", C.c_int32), ("dkv_partial", C.c_void_p),
     ]
 
 

@@ -379,7 +379,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
   constexpr int STAGE_H = 2 * QB * RS + 2 * DT * 16 * TS;     // halfs per stage (+ 2 QB floats of lse / delta)
   __shared__ __attribute__((aligned(16))) f16 lds[2 * (STAGE_H + 4 * QB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int h = blockIdx.y, bkv = blockIdx.z, d = p.head_dim;
+  // blockIdx.z = (K / V batch entry, partition of its kv_group query batches)
+  const int parts = p.kv_partitions > 1 ? p.kv_partitions : 1;
+  const int h = blockIdx.y, bkv = blockIdx.z / parts, part = blockIdx.z - bkv * parts, d = p.head_dim;
+  const int fpp = p.kv_group / parts, f0 = part * fpp;          // this workgroup's query batches: f0 .. f0 + fpp - 1
   const int key0 = blockIdx.x * (64 * U) + wave * (16 * U);
   const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
   const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
@@ -395,13 +398,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
 #pragma unroll
     for (int i = 0; i < DT; ++i) dk[u][i] = dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int nqb = (p.lq + QB - 1) / QB, nit = p.kv_group * nqb;
+  const int nqb = (p.lq + QB - 1) / QB, nit = fpp * nqb;
   const int lq8 = (p.lq + 7) & ~7;
   f16x8 rq[NQ], rdo[NQ], rqt[NT], rdot[NT];
   float rl = 0.f, rd = 0.f;
   auto fetch = [&](int it) {
     const int f = it / nqb, qb = (it - f * nqb) * QB;
-    const int bq = bkv * p.kv_group + f;
+    const int bq = bkv * p.kv_group + f0 + f;
     const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
     const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
     const f16* QT = reinterpret_cast<const f16*>(p.qt) + (int64_t)bq * p.qt_batch_stride + (int64_t)h * d * p.qt_row_stride;
@@ -516,6 +519,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
     if (it + 1 < nit) commit((it + 1) & 1);     // the other stage was last read in iteration it - 1 (closed by its barrier)
     __syncthreads();
   }
+  if (parts > 1) {   // fp32 partials [2][parts][batch_kv * lk][heads * d]; dkv_sum_kernel adds them in a fixed order
+    const int64_t rows_kv = (int64_t)(p.batch_q / p.kv_group) * p.lk, cc = (int64_t)p.heads * d;
+    float* wk = p.dkv_partial + ((int64_t)part * rows_kv) * cc;
+    float* wv = wk + (int64_t)parts * rows_kv * cc;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!kok[u]) continue;
+      const int64_t row = (int64_t)bkv * p.lk + key0 + 16 * u + l15;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const int dd = 16 * i + 4 * g;
+        if (dd >= d) continue;
+        *reinterpret_cast<f32x4*>(wk + row * cc + h * d + dd) = dk[u][i] * p.scale;
+        *reinterpret_cast<f32x4*>(wv + row * cc + h * d + dd) = dv[u][i];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (!kok[u]) continue;
@@ -535,6 +556,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const i2v_attn_bw
       *reinterpret_cast<f16x4*>(DK + dd) = ok4;
       *reinterpret_cast<f16x4*>(DV + dd) = ov4;
     }
+  }
+}
+
+// dk / dv (fp16) = sum over the partitions of the fp32 partials, partition 0 first
+__global__ __launch_bounds__(256) void dkv_sum_kernel(const i2v_attn_bwd_params p) {
+  const int parts = p.kv_partitions, d = p.head_dim;
+  const int64_t rows_kv = (int64_t)(p.batch_q / p.kv_group) * p.lk, cc = (int64_t)p.heads * d, n4 = rows_kv * (cc / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / (cc / 4);
+    const int c4 = (int)(i - row * (cc / 4)) * 4;
+    const int b = (int)(row / p.lk), key = (int)(row - (int64_t)b * p.lk);
+    const float* wk = p.dkv_partial + row * cc + c4;
+    const float* wv = wk + (int64_t)parts * rows_kv * cc;
+    f32x4 sk = *reinterpret_cast<const f32x4*>(wk), sv = *reinterpret_cast<const f32x4*>(wv);
+    for (int q = 1; q < parts; ++q) {
+      sk += *reinterpret_cast<const f32x4*>(wk + (int64_t)q * rows_kv * cc);
+      sv += *reinterpret_cast<const f32x4*>(wv + (int64_t)q * rows_kv * cc);
+    }
+    f16x4 ok4, ov4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ok4[r] = (f16)sk[r];
+      ov4[r] = (f16)sv[r];
+    }
+    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.dk) + (int64_t)b * p.dk_batch_stride + (int64_t)key * p.dk_row_stride + c4) = ok4;
+    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.dv) + (int64_t)b * p.dv_batch_stride + (int64_t)key * p.dv_row_stride + c4) = ov4;
   }
 }
 
@@ -977,8 +1024,12 @@ int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
   int rc = i2v_check_launch("i2v_attention_bwd_f16(dQ)");
   if (rc < 0) return rc;
   if (p.dk != nullptr) {
-    const dim3 gk((unsigned)i2v_cdiv(p.lk, two_k ? 128 : 64), p.heads, p.batch_q / p.kv_group);
     static const int lds_off = getenv("I2V_ATTN_BWD_LDS") ? (atoi(getenv("I2V_ATTN_BWD_LDS")) == 0) : 0;
+    // (the partitions of a kv_group exist in the LDS-staged kernel only; elsewhere the request is ignored: one workgroup per key
+    //  block walks the whole group and writes dk / dv itself)
+    const bool lds_form = two_k && !lds_off && p.lq >= 64;
+    const int parts = (lds_form && p.kv_partitions > 1) ? p.kv_partitions : 1;
+    const dim3 gk((unsigned)i2v_cdiv(p.lk, two_k ? 128 : 64), p.heads, (p.batch_q / p.kv_group) * parts);
     // 64 staged queries per barrier (two 32-query contraction steps): the 32-query loop has 28 MFMAs per wave between barriers.
     // Same box, 16 frames x 4096 tokens, d = 40 (tools/attn_bwd_probe.py): self-attention backward 2.95 -> 2.73 ms per call, the
     // cross-frame form (one K / V for 16 frames: 256 workgroups walking 1024 blocks each) 3.72 -> 3.16.  I2V_ATTN_BWD_QB=32: off.
@@ -994,6 +1045,10 @@ int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
     } else if (two_k && !lds_off && p.lq >= 64) hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
     else if (two_k) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 2>), gk, dim3(256), 0, s, p, c);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, DT, 1>), gk, dim3(256), 0, s, p, c);
+    if (parts > 1) {
+      const int64_t n4 = (int64_t)(p.batch_q / p.kv_group) * p.lk * ((int64_t)p.heads * p.head_dim / 4);
+      hipLaunchKernelGGL(dkv_sum_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, p);
+    }
     rc = i2v_check_launch("i2v_attention_bwd_f16(dK, dV)");
   }
   return rc;
@@ -1053,6 +1108,12 @@ extern "C" int i2v_attention_bwd_f16(const i2v_attn_bwd_params* pp, i2v_stream_t
   for (int64_t st : strides) I2V_CHECK_ARG(st % 8 == 0, "i2v_attention_bwd_f16: strides must be multiples of 8 elements");
   I2V_CHECK_ARG(al16(p.q) && al16(p.k) && al16(p.v) && al16(p.kt) && al16(p.dout) && al16(p.dq) && al16(p.lse) && al16(p.delta),
                 "i2v_attention_bwd_f16: pointers must be 16-byte aligned");
+  I2V_CHECK_ARG(p.kv_partitions >= 0, "i2v_attention_bwd_f16: kv_partitions must be >= 0");
+  if (p.dk != nullptr && p.kv_partitions > 1)
+    I2V_CHECK_ARG(p.dkv_partial != nullptr && al16(p.dkv_partial) && p.kv_group % p.kv_partitions == 0 &&
+                      (p.heads * p.head_dim) % 4 == 0,
+                  "i2v_attention_bwd_f16: kv_partitions (%d) needs the dkv_partial scratch and must divide kv_group (%d)",
+                  p.kv_partitions, p.kv_group);
   if (p.dk != nullptr) {
     I2V_CHECK_ARG(p.dv && p.qt && p.doutt, "i2v_attention_bwd_f16: dk needs dv, qt and doutt");
     const int lq8 = (p.lq + 7) & ~7;

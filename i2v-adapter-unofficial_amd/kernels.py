@@ -702,8 +702,24 @@ def attention_bwd(q, k, v, o, dout, *, batch_q, lq, lk, heads, head_dim, kv_grou
         p.dv, p.dv_row_stride, p.dv_batch_stride = _p(dv), Cc, lk * Cc
     p.batch_q, p.kv_group, p.heads, p.head_dim, p.lq, p.lk = batch_q, kv_group, heads, head_dim, lq, lk
     p.scale = sc
+    parts = dkv_partitions(batch_q, kv_group, heads, head_dim, lq, lk) if need_dkv else 1
+    if parts > 1:   # the cross-frame form: too few (key block, head) workgroups for the chip; the frames are dealt out
+        ws = torch.empty((2, parts, bkv * lk, Cc), dtype=torch.float32, device=q.device)
+        p.kv_partitions, p.dkv_partial = parts, _p(ws)
     _lib.check(lib.i2v_attention_bwd_f16(C.byref(p), _stream()), "i2v_attention_bwd_f16")
     return dq, dk, dv
+
+
+def dkv_partitions(batch_q, kv_group, heads, head_dim, lq, lk):
+    """how many workgroups share the frames of one K / V in the dK / dV sweep (1 = off): a power of two dividing kv_group that
+    brings the sweep to about one thousand workgroups (the LDS-staged kernel only: two key tiles per wave, head_dim <= 96)."""
+    if os.environ.get("I2V_ATTN_BWD_PARTS", "1") == "0" or kv_group < 2 or lk < 512 or lq < 128 or head_dim > 96:
+        return 1
+    blocks = ((lk + 127) // 128) * heads * (batch_q // kv_group)
+    parts = 1
+    while parts * 2 <= min(kv_group, 8) and kv_group % (parts * 2) == 0 and blocks * parts < 1024:
+        parts *= 2
+    return parts
 
 
 def layernorm_bwd(x, dn, gamma, eps, add=None):

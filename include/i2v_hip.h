@@ -352,6 +352,12 @@ typedef struct i2v_attn_bwd_params {
   void* dv;          int64_t dv_row_stride, dv_batch_stride;
   int32_t batch_q, kv_group, heads, head_dim, lq, lk;
   float scale;
+  int32_t kv_partitions; /* (ABI 6) > 1: the kv_group query batches that share one K / V (the frames of a clip in the cross-frame
+                            attention) are dealt to kv_partitions workgroups per key block instead of one -- that form has
+                            batch_q / kv_group times fewer workgroups than the self-attention and cannot fill the chip alone;
+                            kv_group % kv_partitions == 0.  The partial dK / dV go to dkv_partial and a second kernel sums them
+                            into dk / dv (fixed order: run-to-run identical).  0 / 1: off.                                       */
+  float* dkv_partial;    /* scratch, fp32 [2][kv_partitions][batch_q / kv_group * lk][heads * head_dim]                       */
 } i2v_attn_bwd_params;
 int i2v_attention_bwd_f16(const i2v_attn_bwd_params* p, i2v_stream_t stream);
 

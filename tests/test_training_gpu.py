@@ -26,11 +26,14 @@ def h(t):
 
 @pytest.mark.parametrize("d,lq,lk,group,need_dkv", [(40, 256, 256, 1, True), (40, 128, 128, 4, True), (80, 64, 64, 2, True),
                                                     (160, 64, 64, 1, True), (40, 96, 77, 2, False), (64, 32, 160, 1, True),
-                                                    (40, 512, 640, 1, True), (80, 576, 512, 2, True)])
+                                                    (40, 512, 640, 1, True), (80, 576, 512, 2, True),
+                                                    # a kv_group dealt to 8 / 4 workgroups per key block (kv_partitions: fp32 partials + sum)
+                                                    (40, 256, 640, 8, True), (64, 128, 512, 4, True)])
 def test_attention_backward_vs_autograd(dev, d, lq, lk, group, need_dkv):
     """dQ, dK, dV of softmax(q k^T / sqrt d) v against autograd; kv_group > 1 = several query batches share one K / V (the
     cross-frame attention: dK / dV are the sums over the group); lk = 77 is the text context (dQ only, masked tail);
-    sequences >= 512 take the two-tiles-per-wave forms of both sweeps."""
+    sequences >= 512 take the two-tiles-per-wave forms of both sweeps; with a kv_group and few key blocks the group's query batches
+    are dealt to several workgroups per key block (kernels.dkv_partitions)."""
     K = pkg().kernels
     heads, bkv = 2, 2
     bq, C = bkv * group, heads * d
@@ -51,6 +54,8 @@ def test_attention_backward_vs_autograd(dev, d, lq, lk, group, need_dkv):
     dq, dk, dv = K.attention_bwd(qd, kd, vd, od, to(do), batch_q=bq, lq=lq, lk=lk, heads=heads, head_dim=d, kv_group=group,
                                  need_dkv=need_dkv)
     compare(dq, q.grad.reshape(-1, C), rel=GRAD_REL_TOL, name=f"dQ d={d} lq={lq} lk={lk} group={group}")
+    if group >= 4 and lk >= 512:
+        assert K.dkv_partitions(bq, group, heads, d, lq, lk) > 1
     if need_dkv:
         compare(dk, k.grad.reshape(-1, C), rel=GRAD_REL_TOL, name=f"dK d={d} group={group}")
         compare(dv, v.grad.reshape(-1, C), rel=GRAD_REL_TOL, name=f"dV d={d} group={group}")
