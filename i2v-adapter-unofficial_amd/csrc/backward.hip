@@ -268,7 +268,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const i2v_attn_bwd_par
 template <int KS, int DT, int U>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_params p, const float c) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
-  const int h = blockIdx.y, bkv = blockIdx.z, d = p.head_dim;
+  // blockIdx.z = (K / V batch entry, partition of its kv_group query batches: i2v_attn_bwd_params.kv_partitions)
+  const int parts = p.kv_partitions > 1 ? p.kv_partitions : 1;
+  const int h = blockIdx.y, bkv = blockIdx.z / parts, part = blockIdx.z - bkv * parts, d = p.head_dim;
+  const int fpp = p.kv_group / parts;
   const int key0 = blockIdx.x * (64 * U) + wave * (16 * U);
   const f16* Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
   const f16* Vg = reinterpret_cast<const f16*>(p.v) + (int64_t)bkv * p.v_batch_stride + h * d;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_pa
 #pragma unroll
     for (int i = 0; i < DT; ++i) dk[u][i] = dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int f = 0; f < p.kv_group; ++f) {           // every batch entry that attends to this K / V
+  for (int f = part * fpp; f < (part + 1) * fpp; ++f) {   // this workgroup's share of the batch entries that attend to this K / V
     const int bq = bkv * p.kv_group + f;
     const f16* Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
     const f16* DO = reinterpret_cast<const f16*>(p.dout) + (int64_t)bq * p.do_batch_stride + h * d;
@@ -341,6 +344,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const i2v_attn_bwd_pa
         }
       }
     }
+  }
+  if (parts > 1) {   // fp32 partials [2][parts][batch_kv * lk][heads * d]; dkv_sum_kernel adds them in a fixed order
+    const int64_t rows_kv = (int64_t)(p.batch_q / p.kv_group) * p.lk, cc = (int64_t)p.heads * d;
+    float* wk = p.dkv_partial + ((int64_t)part * rows_kv) * cc;
+    float* wv = wk + (int64_t)parts * rows_kv * cc;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!kok[u]) continue;
+      const int64_t row = (int64_t)bkv * p.lk + key0 + 16 * u + l15;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const int dd = 16 * i + 4 * g;
+        if (dd >= d) continue;
+        *reinterpret_cast<f32x4*>(wk + row * cc + h * d + dd) = dk[u][i] * p.scale;
+        *reinterpret_cast<f32x4*>(wv + row * cc + h * d + dd) = dv[u][i];
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -1025,10 +1046,7 @@ int launch_bwd(const i2v_attn_bwd_params& p, hipStream_t s) {
   if (rc < 0) return rc;
   if (p.dk != nullptr) {
     static const int lds_off = getenv("I2V_ATTN_BWD_LDS") ? (atoi(getenv("I2V_ATTN_BWD_LDS")) == 0) : 0;
-    // (the partitions of a kv_group exist in the LDS-staged kernel only; elsewhere the request is ignored: one workgroup per key
-    //  block walks the whole group and writes dk / dv itself)
-    const bool lds_form = two_k && !lds_off && p.lq >= 64;
-    const int parts = (lds_form && p.kv_partitions > 1) ? p.kv_partitions : 1;
+    const int parts = p.kv_partitions > 1 ? p.kv_partitions : 1;   // (every form of the sweep deals the group out)
     const dim3 gk((unsigned)i2v_cdiv(p.lk, two_k ? 128 : 64), p.heads, (p.batch_q / p.kv_group) * parts);
     // 64 staged queries per barrier (two 32-query contraction steps): the 32-query loop has 28 MFMAs per wave between barriers.
     // Same box, 16 frames x 4096 tokens, d = 40 (tools/attn_bwd_probe.py): self-attention backward 2.95 -> 2.73 ms per call, the

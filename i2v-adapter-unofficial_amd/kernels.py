@@ -712,10 +712,11 @@ def attention_bwd(q, k, v, o, dout, *, batch_q, lq, lk, heads, head_dim, kv_grou
 
 def dkv_partitions(batch_q, kv_group, heads, head_dim, lq, lk):
     """how many workgroups share the frames of one K / V in the dK / dV sweep (1 = off): a power of two dividing kv_group that
-    brings the sweep to about one thousand workgroups (the LDS-staged kernel only: two key tiles per wave, head_dim <= 96)."""
-    if os.environ.get("I2V_ATTN_BWD_PARTS", "1") == "0" or kv_group < 2 or lk < 512 or lq < 128 or head_dim > 96:
+    brings the sweep to about one thousand workgroups."""
+    if os.environ.get("I2V_ATTN_BWD_PARTS", "1") == "0" or kv_group < 2 or lq < 32:
         return 1
-    blocks = ((lk + 127) // 128) * heads * (batch_q // kv_group)
+    two_k = lk >= 512 and head_dim <= 96                      # (the sweep's own choice of 128 or 64 keys per workgroup)
+    blocks = ((lk + 127) // 128 if two_k else (lk + 63) // 64) * heads * (batch_q // kv_group)
     parts = 1
     while parts * 2 <= min(kv_group, 8) and kv_group % (parts * 2) == 0 and blocks * parts < 1024:
         parts *= 2
