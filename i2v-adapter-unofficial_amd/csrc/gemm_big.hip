@@ -1062,7 +1062,11 @@ int splitk_plan(const i2v_gemm_params& p, int vec4, int* kps_out) {
   // K >= 2560 gains 1.6 - 2.3x (8 x 8 level convs 316 -> 654 TFLOP/s)
   if (nkt < 40 || t128 > 128) return 0;
   int splits = (int)(256 / t128);
-  if (splits > 8) splits = 8;
+  // (the weight gradients of the training step contract over every token: 320 x 320 x 65536 = 3 tiles with 1024 K tiles each.
+  //  Eight splits left them on 24 workgroups, 138 us; plain GEMMs with >= 256 K tiles -- none on the inference path -- may take 64:
+  //  54 us)
+  const int cap = (p.a_mode == I2V_A_PLAIN && nkt >= 256) ? 64 : 8;
+  if (splits > cap) splits = cap;
   if (splits > nkt / 8) splits = nkt / 8;
   if (splits < 2) return 0;
   const int kps = (int)i2v_cdiv(nkt, splits);
