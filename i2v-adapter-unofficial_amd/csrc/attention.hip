@@ -435,8 +435,13 @@ inline bool al(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>
 
 }  // namespace
 
-int i2v_attention32_try(const i2v_attn_params& p, hipStream_t s);   // attention32.hip: head_dim 40 / 48 on 32x32x16 MFMAs
-int i2v_attention_pipe_try(const i2v_attn_params& p, hipStream_t s); // attention_pipe.hip: head_dim 40, software-pipelined key loop
+// Measured-and-rejected forms of the head_dim-40 kernel (profiles/r3_attn_pipe_ab.txt, r2_attn_fragment_layout_pmc.txt) live in
+// csrc/variants/ and are compiled only into an A/B library (tools/build_variant.sh --variants: -DI2V_VARIANTS), where the
+// I2V_ATTN32 / I2V_ATTN_PIPE switches select them.
+#ifdef I2V_VARIANTS
+int i2v_attention32_try(const i2v_attn_params& p, hipStream_t s);   // variants/attention32.hip: head_dim 40 / 48 on 32x32x16 MFMAs
+int i2v_attention_pipe_try(const i2v_attn_params& p, hipStream_t s); // variants/attention_pipe.hip: software-pipelined key loop
+#endif
 
 extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(pp != nullptr, "i2v_attention_f16: null params");
@@ -464,6 +469,7 @@ extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream)
   const int d = p.head_dim;
   if (d <= 16) return launch_d<32, 16>(p, s);
   if (d <= 32) return launch_d<32, 32>(p, s);
+#ifdef I2V_VARIANTS
   if (d > 32 && d < 48) {
     const int rc = i2v_attention_pipe_try(p, s);
     if (rc != 0) return rc < 0 ? rc : I2V_OK;
@@ -472,6 +478,7 @@ extern "C" int i2v_attention_f16(const i2v_attn_params* pp, i2v_stream_t stream)
     const int rc = i2v_attention32_try(p, s);
     if (rc != 0) return rc < 0 ? rc : I2V_OK;
   }
+#endif
   if (d <= 48) return launch_d<64, 48>(p, s);
   if (d <= 64) return launch_d<64, 64>(p, s);
   if (d <= 80) return launch_d<96, 80>(p, s);

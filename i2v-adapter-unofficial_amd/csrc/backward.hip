@@ -1027,6 +1027,66 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ param, c
   }
 }
 
+// Run-to-run identical, rank-to-rank identical gradient norm + the overflow guard of a mixed-precision step:
+// sumsq_partials_kernel writes one partial per workgroup (no atomics); adamw_prepare_kernel (ONE workgroup) sums them in a
+// fixed order, publishes the total, and decides the step: a non-finite norm (an inf / NaN anywhere in the fp16-scaled
+// gradients) sets *found_inf and leaves the applied-step counter alone, otherwise the counter advances.
+// adamw_guarded_kernel is a no-op under *found_inf -- parameters, both moments and the bias-correction step stay as they
+// were, which is what accelerate's GradScaler does for the reference's fp16 run (train_image_to_video.py:306-308, 876-882).
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partials) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_prepare_kernel(const float* __restrict__ partials, int n_partials,
+                                                            float* __restrict__ norm_sq, int32_t* __restrict__ applied_steps,
+                                                            int32_t* __restrict__ found_inf) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];   // fixed order per thread, fixed tree below
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float total = (red[0] + red[1]) + (red[2] + red[3]);
+    *norm_sq = total;
+    const bool bad = !(fabsf(total) <= 3.0e38f);     // inf or NaN (written without isfinite: -fno-honor-nans builds fold it)
+    *found_inf = bad ? 1 : 0;
+    if (!bad) *applied_steps += 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_guarded_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                            float b1, float b2, float eps, float wd, float grad_coef,
+                                                            const float* __restrict__ norm_sq, float max_norm,
+                                                            const int32_t* __restrict__ applied_steps,
+                                                            const int32_t* __restrict__ found_inf) {
+  if (*found_inf) return;                                       // overflowed gradients: the whole update is skipped
+  const float step = (float)*applied_steps;
+  const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
+  float coef = grad_coef;
+  if (max_norm > 0.f) {
+    const float total = sqrtf(*norm_sq) * grad_coef;
+    coef *= fminf(1.0f, max_norm / (total + 1e-6f));
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g = grad[i] * coef;
+    float p = param[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * g;
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    p -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    param[i] = p;
+  }
+}
+
 inline int ew_grid(int64_t n) {
   const int64_t b = i2v_cdiv(n, 256);
   return (int)(b < 65535 * 4 ? (b > 0 ? b : 1) : 65535 * 4);
@@ -1269,6 +1329,23 @@ extern "C" int i2v_sumsq_f32(const float* x, int64_t n, float* out, i2v_stream_t
   const int64_t b = i2v_cdiv(n, 256);
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(b < 1024 ? b : 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, out);
   return i2v_check_launch("i2v_sumsq_f32");
+}
+
+extern "C" int i2v_adamw_guarded_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, float grad_coef, float max_norm,
+                                     float* partials, int32_t n_partials, float* norm_sq, int32_t* applied_steps,
+                                     int32_t* found_inf, i2v_stream_t stream) {
+  I2V_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "i2v_adamw_guarded_f32: bad arguments");
+  I2V_CHECK_ARG(partials && norm_sq && applied_steps && found_inf && n_partials >= 1 && n_partials <= 1024,
+                "i2v_adamw_guarded_f32: partials[1..1024], norm_sq, applied_steps and found_inf are required");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t b = i2v_cdiv(n, 256);
+  const int np = (int)(b < n_partials ? b : n_partials);
+  hipLaunchKernelGGL(sumsq_partials_kernel, dim3(np), dim3(256), 0, s, grad, n, partials);
+  hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(256), 0, s, partials, np, norm_sq, applied_steps, found_inf);
+  hipLaunchKernelGGL(adamw_guarded_kernel, dim3((unsigned)(b < 4096 ? b : 4096)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
+                     n, lr, beta1, beta2, eps, weight_decay, grad_coef, norm_sq, max_norm, applied_steps, found_inf);
+  return i2v_check_launch("i2v_adamw_guarded_f32");
 }
 
 extern "C" int i2v_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

@@ -966,7 +966,9 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   return rc < 0 ? rc : 1;
 }
 
-// Two workgroups of 4 waves per CU: 128 x 320 x 32 tiles (see the NW template parameter)
+// Two workgroups of 4 waves per CU: 128 x 320 x 32 tiles (see the NW template parameter).  Measured 5 - 40 % slower on every
+// flavour (below), so the instantiations are compiled only into the A/B library (tools/build_variant.sh --variants).
+#ifdef I2V_VARIANTS
 template <int AMODE>
 int launch_big4(const i2v_gemm_params& p, hipStream_t s) {
   constexpr int BM = 128;
@@ -1013,6 +1015,7 @@ bool use_4wave(const i2v_gemm_params& p, int plan_rows) {
   (void)plan_rows;
   return mode == 1 && p.a_mode == I2V_A_PLAIN && p.N % BIG_BN == 0 && p.K % 32 == 0;
 }
+#endif
 
 // 3x3 convolutions whose channel count is not a multiple of 320 (the VAE: 128 / 256 / 512): column tiles of 256 or 128
 template <int BM, int BN>
@@ -1316,21 +1319,27 @@ int i2v_gemm_big_unsplit_ok(const i2v_gemm_params& p, int vec4) {
   return plan == 256 || plan == 128;
 }
 
-int i2v_gemm_alt_try(const i2v_gemm_params& p, hipStream_t s);   // gemm_alt.hip: short-K problems, alternating wave groups
+#ifdef I2V_VARIANTS
+int i2v_gemm_alt_try(const i2v_gemm_params& p, hipStream_t s);   // variants/gemm_alt.hip: short-K problems, alternating wave groups
+#endif
 
 int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   int splits = 0, kps = 0;
   const int plan = big_plan(p, vec4, &splits, &kps);
   const int bn = big_bn(p);
+#ifdef I2V_VARIANTS
   if (bn == BIG_BN && (plan == 256 || plan == 128)) {
     const int rc = i2v_gemm_alt_try(p, s);
     if (rc != 0) return rc;
   }
+#endif
   if (bn == 256 && plan == 256) return launch_big_conv_bn<256, 256>(p, s);
   if (bn == 256 && plan == 128) return launch_big_conv_bn<128, 256>(p, s);
   if (bn == 128 && plan == 256) return launch_big_conv_bn<256, 128>(p, s);
   if (bn == 128 && plan == 128) return launch_big_conv_bn<128, 128>(p, s);
+#ifdef I2V_VARIANTS
   if ((plan == 256 || plan == 128) && use_4wave(p, plan)) return launch_big4<I2V_A_PLAIN>(p, s);
+#endif
   if (plan == 256) return launch_big<256>(p, vec4, s);
   if (plan == 128) return launch_big<128>(p, vec4, s);
   if (plan == -1) return launch_split(p, vec4, splits, kps, s);

@@ -16,7 +16,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "common.h"
+#include "../common.h"
 
 namespace {
 

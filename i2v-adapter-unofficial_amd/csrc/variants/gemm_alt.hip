@@ -22,7 +22,7 @@
 #include <cstdlib>
 #include <utility>
 
-#include "gemm_common.h"
+#include "../gemm_common.h"
 
 namespace {
 

@@ -19,6 +19,7 @@ from . import kernels as K
 from . import streams
 from .blocks import (gn_proj_in, Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
                      to_tokens, w16)
+from ._lib import HipLibraryError
 from .checkpoint import PretrainedMixin
 
 f16 = torch.float16
@@ -316,6 +317,22 @@ class I2VAdapterTransformer2DModel(HipModule):
         return dict(g=w16(self.norm.weight), b=w16(self.norm.bias),
                     wi=w16(self.proj_in.weight.reshape(self.inner_dim, self.in_channels)), bi=w16(self.proj_in.bias),
                     wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias))
+
+    def packed(self):
+        # only this module's own leaf parameters feed its pack (the transformer blocks pack themselves): a training step
+        # that writes the adapter's to_q / to_out in place must not rebuild -- and re-allocate -- proj_in / proj_out's copies
+        leaves = [self.norm.weight, self.norm.bias, self.proj_in.weight, self.proj_in.bias, self.proj_out.weight,
+                  self.proj_out.bias]
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in leaves)
+        if self._packed is None or key != self._packed_key:
+            for p in leaves:
+                if not p.is_cuda:
+                    raise HipLibraryError(
+                        f"{type(self).__name__} has parameters on {p.device}: the HIP path has no CPU fallback")
+            with torch.no_grad():
+                self._packed = self._pack()
+            self._packed_key = key
+        return self._packed
 
     def _fwd(self, x, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip, cfg_expand=False):
         """cfg_expand: x is one of the two identical CFG halves; the output has both (see the block's _fwd)."""

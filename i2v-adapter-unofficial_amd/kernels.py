@@ -898,3 +898,26 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr, betas, eps, weight_decay
                                  float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_coef), _p(norm_sq),
                                  float(max_norm), _stream()), "i2v_adamw_f32")
     return param
+
+
+def adamw_guarded_step(param, grad, exp_avg, exp_avg_sq, *, lr, betas, eps, weight_decay, grad_coef, max_norm, partials,
+                       norm_sq, applied_steps, found_inf):
+    """clip_grad_norm_ + AdamW of a flat fp32 bucket in one call, deterministic and overflow-safe (i2v_adamw_guarded_f32):
+    `partials` fp32 [<= 1024] scratch, `norm_sq` fp32 [1] (out: sum grad^2), `applied_steps` int32 [1] (device step counter,
+    advanced only by an applied step), `found_inf` int32 [1] (out: 1 = the gradients held inf / NaN and NOTHING was updated)."""
+    lib = _lib.load()
+    for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, name, dtype=torch.float32)
+        if not t.is_contiguous() or t.numel() != param.numel():
+            raise ValueError(f"adamw_guarded_step: {name} must be contiguous with {param.numel()} elements")
+    _req(partials, "partials", dtype=torch.float32)
+    _req(norm_sq, "norm_sq", dtype=torch.float32)
+    _req(applied_steps, "applied_steps", dtype=torch.int32)
+    _req(found_inf, "found_inf", dtype=torch.int32)
+    if not partials.is_contiguous() or not 1 <= partials.numel() <= 1024:
+        raise ValueError("adamw_guarded_step: partials must be a contiguous fp32 vector of 1 .. 1024 elements")
+    _lib.check(lib.i2v_adamw_guarded_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr),
+                                         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(grad_coef),
+                                         float(max_norm), _p(partials), partials.numel(), _p(norm_sq), _p(applied_steps),
+                                         _p(found_inf), _stream()), "i2v_adamw_guarded_f32")
+    return param

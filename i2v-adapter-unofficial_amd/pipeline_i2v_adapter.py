@@ -228,13 +228,24 @@ class I2VAdapterPipeline:
             graph.replay()
         return gst["latents"].clone()     # the static buffer stays with the graph; the caller gets its own tensor
 
+    def _resolve_call_defaults(self, output_type, callback, use_graph):
+        """(output_type, use_graph) as `__call__` uses them.  output_type=None is the reference's default "pil" (pipe:556);
+        a pipeline assembled without a VAE (latents in, latents out: the benchmarks and most tests) has nothing to decode
+        with and returns the latents.  pipe:693-697 calls back after every step: a replayed hipGraph has no per-step host
+        hook, so a `callback` runs the same kernels as eager launches (bit-identical, tests/test_modules_gpu.py)."""
+        if output_type is None:
+            output_type = "pil" if self.vae is not None else "latent"
+        if callback is not None:
+            use_graph = False
+        return output_type, use_graph
+
     # ------------------------------------------------------------------------------------------ __call__
     @torch.no_grad()
     def __call__(self, prompt=None, condition_image=None, num_frames: Optional[int] = 16,
                  height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 50,
                  guidance_scale: float = 7.5, negative_prompt=None, num_videos_per_prompt: Optional[int] = 1,
                  eta: float = 0.0, generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
-                 ip_adapter_image=None, output_type: Optional[str] = "latent", return_dict: bool = True,
+                 ip_adapter_image=None, output_type: Optional[str] = None, return_dict: bool = True,
                  callback=None, callback_steps: Optional[int] = 1, cross_attention_kwargs=None, clip_skip=None,
                  frame_similarity_sample_ratio: float = 1, frame_similarity_blurred_strength: float = 0.6,
                  condition_image_latents=None, image_embeds=None, negative_image_embeds=None,
@@ -259,8 +270,7 @@ class I2VAdapterPipeline:
                              "(pipe:647-656) needs the condition image and crashes without it")
         if eta != 0.0:
             raise NotImplementedError("eta = 0 on the hot path (pipe:550)")
-        if callback is not None and use_graph:
-            raise ValueError("callbacks need use_graph=False (a replayed hipGraph has no per-step host hook)")
+        output_type, use_graph = self._resolve_call_defaults(output_type, callback, use_graph)
         dev = self.unet.device
         if dev.type != "cuda":
             raise HipLibraryError(f"unet is on {dev}: the HIP path has no CPU fallback")

@@ -43,10 +43,14 @@ def wgrad(dy, x, tokens_per_batch=None):
 
 class _Memo:
     """Operand copies derived from weights (transposes for the dgrad GEMMs, flipped conv kernels, fused / concatenated
-    projections) keyed on the identity and the version counter of their source tensors: the frozen layers' copies are made
-    once; anything derived from a trainable tensor (the adapter's to_q / to_out, registered with mark_trainable) is remade on
-    every call, whatever its version counter says.  (Rebuilt every step
-    they were ~430 aten launches and 8 ms of a 148 ms step.)  The sources are kept referenced, so an id is never reused."""
+    projections), made once for the frozen layers.  (Rebuilt every step they were ~430 aten launches and 8 ms of a 148 ms step.)
+
+    An entry is keyed by (tag, ids of its source tensors) and is valid while every source is the SAME live object with the
+    same version counter, storage address, dtype and device -- an in-place write, a `.data` swap, `.to()` / `.half()` or a
+    `load_state_dict(assign=True)` all rebuild it.  Sources are held by WEAK reference: when one dies (a packed tensor that
+    its module rebuilt, a deleted model) the entry -- and the GPU memory of its copy -- goes with it, and a recycled id can
+    never alias an old entry.  Anything derived from a trainable tensor (the adapter's to_q / to_out, registered with
+    mark_trainable) is remade on every call and never kept."""
 
     def __init__(self):
         self.d = {}
@@ -58,16 +62,22 @@ class _Memo:
             self.volatile.add(id(t))
             self._keep.append(t)
 
+    @staticmethod
+    def _sig(t):
+        return (t._version, t.data_ptr(), t.dtype, t.device)
+
     def get(self, tag, srcs, fn):
+        import weakref
         if any(id(t) in self.volatile for t in srcs):   # derived from a trainable tensor: never kept
             return fn()
         key = (tag,) + tuple(id(t) for t in srcs)
-        ver = tuple(t._version for t in srcs)
+        sig = tuple(self._sig(t) for t in srcs)
         hit = self.d.get(key)
-        if hit is not None and hit[0] == ver:
+        if hit is not None and hit[0] == sig and all(r() is t for r, t in zip(hit[1], srcs)):
             return hit[2]
         val = fn()
-        self.d[key] = (ver, srcs, val)
+        drop = lambda _ref, key=key, d=self.d: d.pop(key, None)     # a source died: its entry (and the copy) goes
+        self.d[key] = (sig, tuple(weakref.ref(t, drop) for t in srcs), val)
         return val
 
     def clear(self):
@@ -505,11 +515,23 @@ class UNetAdapterTrainer:
                     x = tr.forward(x)
                     tape.append(("up", tr, None))
         a = K.groupnorm(x, p["g_out"], p["be_out"], u.config.norm_num_groups, u.config.norm_eps, silu=True)
-        w_out = torch.zeros((8,) + tuple(u.conv_out.weight.shape[1:]), dtype=u.conv_out.weight.dtype, device=x.device)
-        w_out[: u.conv_out.weight.shape[0]] = u.conv_out.weight.detach()
-        b_out = torch.zeros((8,), dtype=f16, device=x.device)
-        b_out[: u.conv_out.bias.shape[0]] = u.conv_out.bias.detach().to(f16)
-        y = K.conv3x3(a, pack_conv3x3(w_out), b_out)
+        # conv_out padded to 8 output channels (the head's tokens are [.., 8] fp16); frozen: the padded weight, its packed
+        # form and (in backward) its input-gradient form are made once per weight version, not once per step
+        cw, cb = u.conv_out.weight, u.conv_out.bias
+
+        def _pad_w():
+            w = torch.zeros((8,) + tuple(cw.shape[1:]), dtype=cw.dtype, device=cw.device)
+            w[: cw.shape[0]] = cw.detach()
+            return w
+
+        def _pad_b():
+            bb = torch.zeros((8,), dtype=f16, device=cb.device)
+            bb[: cb.shape[0]] = cb.detach().to(f16)
+            return bb
+
+        w_out = _memo.get("conv_out_pad8", (cw,), _pad_w)
+        y = K.conv3x3(a, _memo.get("conv_out_pad8_packed", (cw,), lambda: pack_conv3x3(w_out)),
+                      _memo.get("conv_out_bias_pad8", (cb,), _pad_b))
         self.saved = dict(tape=tape, x_last=x, y=y, F=F, w_out=w_out)
         return y
 
@@ -576,7 +598,17 @@ class AdapterOptimizer:
         self.grad = torch.zeros_like(self.master)
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.master), torch.zeros_like(self.master)
         self.norm_sq = torch.zeros((1,), dtype=torch.float32, device=dev)
-        self.step_count = 0
+        self._partials = torch.zeros((1024,), dtype=torch.float32, device=dev)
+        # device-side state of the guarded step: steps actually applied (the bias correction uses THIS count) and whether
+        # the last step was skipped because its gradients held inf / NaN (fp16 activation gradients under a static scale)
+        self.applied_steps = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.found_inf = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.step_count = 0            # steps requested (applied + skipped)
+
+    def last_step_skipped(self) -> bool:
+        """did the last `step` find inf / NaN gradients and leave everything unchanged?  (one host read; the trainer halves
+        its loss scale on True, as accelerate's GradScaler does for the reference's fp16 run)"""
+        return bool(self.found_inf.item())
 
     def fill_gradients(self, grads):
         for n in self.names:
@@ -596,11 +628,13 @@ class AdapterOptimizer:
         self.fill_gradients(grads)
         world = self.reduce_gradients()
         self.step_count += 1
-        self.norm_sq.zero_()
-        K.sumsq(self.grad, out=self.norm_sq)
-        K.adamw_step(self.master, self.grad, self.exp_avg, self.exp_avg_sq, lr=self.lr, betas=self.betas, eps=self.eps,
-                     weight_decay=self.wd, step=self.step_count, grad_coef=1.0 / world, norm_sq=self.norm_sq,
-                     max_norm=self.max_norm)
+        # one call: fixed-order gradient norm (identical on every rank: the clip coefficients cannot drift apart), overflow
+        # check, clip + AdamW.  With inf / NaN in the bucket nothing moves -- masters, moments, bias-correction step -- and
+        # the fp16 parameters below are rewritten with their old values.
+        K.adamw_guarded_step(self.master, self.grad, self.exp_avg, self.exp_avg_sq, lr=self.lr, betas=self.betas,
+                             eps=self.eps, weight_decay=self.wd, grad_coef=1.0 / world, max_norm=self.max_norm,
+                             partials=self._partials, norm_sq=self.norm_sq, applied_steps=self.applied_steps,
+                             found_inf=self.found_inf)
         for n, prm in zip(self.names, self.params):
             off, cnt = self.offsets[n]
             prm.copy_(self.master[off: off + cnt].view_as(prm))   # (on the parameter itself: its version counter moves)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 6
+#define I2V_ABI_VERSION 7
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -419,6 +419,18 @@ int i2v_sumsq_f32(const float* x, int64_t n, float* out, i2v_stream_t stream);
 int i2v_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, float grad_coef, const float* norm_sq,
                   float max_norm, i2v_stream_t stream);
+
+/* The same step as ONE call that is safe under fp16 loss scaling and identical on every data-parallel rank
+ * (train_image_to_video.py:306-308 `--mixed_precision fp16`: accelerate's GradScaler skips a step whose gradients hold
+ * inf / NaN; :876-882 clip + step): sum grad^2 as per-workgroup partials (`partials`, fp32 [n_partials <= 1024]) summed
+ * in a fixed order into *norm_sq -- no atomics, so every rank derives the same clip coefficient from the same all-reduced
+ * bucket --; a non-finite norm sets *found_inf = 1 and the update is a no-op (parameters, both moments and the
+ * bias-correction step unchanged), otherwise *found_inf = 0, *applied_steps += 1 and AdamW runs with bias correction
+ * 1 - beta^(*applied_steps).  The caller reads *found_inf when it wants to back its loss scale off; nothing here syncs. */
+int i2v_adamw_guarded_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float grad_coef, float max_norm,
+                          float* partials, int32_t n_partials, float* norm_sq, int32_t* applied_steps, int32_t* found_inf,
+                          i2v_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,25 @@ def test_cpu_tensors_fail_loudly():
                             torch.zeros(8, dtype=torch.float16), 1e-5)
 
 
+def test_pipeline_call_defaults_follow_reference():
+    """pipe:556 (`output_type="pil"`) and pipe:693-697 (per-step callback): resolved on the host, no GPU needed."""
+    import inspect
+    p = pkg()
+    u = p.UNetMotionCrossFrameAttnModel(**SMALL_UNET)
+    sig = inspect.signature(p.I2VAdapterPipeline.__call__)
+    assert sig.parameters["output_type"].default is None and sig.parameters["use_graph"].default is True
+    no_vae = p.I2VAdapterPipeline(unet=u)
+    assert no_vae._resolve_call_defaults(None, None, True) == ("latent", True)
+    assert no_vae._resolve_call_defaults("pt", None, True) == ("pt", True)
+    # a callback under the default mode falls back to eager launches instead of raising
+    assert no_vae._resolve_call_defaults(None, lambda i, t, x: None, True) == ("latent", False)
+    from i2v_adapter_unofficial_amd.vae import AutoencoderKL
+    vae = AutoencoderKL(block_out_channels=(32, 32, 64, 64), norm_num_groups=8, layers_per_block=1)
+    with_vae = p.I2VAdapterPipeline(vae=vae, unet=u)
+    assert with_vae._resolve_call_defaults(None, None, True) == ("pil", True)
+    assert with_vae._resolve_call_defaults("latent", None, False) == ("latent", False)
+
+
 def test_constructor_validation_matches_reference():
     p = pkg()
     with pytest.raises(ValueError, match="same number of `down_block_types`"):

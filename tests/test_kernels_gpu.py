@@ -413,8 +413,20 @@ def test_attention_config5_key_length(dev):
         close(out.view(bq, L, c), ref, name=f"attention Lq=Lk=9216 d=40 group={group}")
 
 
+def _variants_env(**switches):
+    """environment of a child process that runs the measured-and-rejected kernel forms (csrc/variants/, the 4-wave GEMM
+    instantiations): they are not in the default library, only in the A/B build `bash tools/build_variant.sh --variants`
+    (-> .ab_libs/variants.so, selected through I2V_LIB_PATH).  Skips when that library has not been built."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, ".ab_libs", "variants.so")
+    if not os.path.exists(lib):
+        pytest.skip("variant kernels are not in the default build: bash tools/build_variant.sh --variants")
+    return dict(os.environ, I2V_LIB_PATH=lib, **switches)
+
+
 def test_attention_32x32_formulation_opt_in(dev):
-    """the head_dim-40 kernel on 32x32x16 MFMAs (attention32.hip) is opt-in (I2V_ATTN32=1, read once per process): run
+    """the head_dim-40 kernel on 32x32x16 MFMAs (csrc/variants/attention32.hip) is opt-in (I2V_ATTN32=1, read once per process): run
     it in a child process against torch SDPA, with a query tail, a key tail, K/V sharing and the accumulate form."""
     import os, subprocess, sys
     code = r"""
@@ -441,13 +453,13 @@ for bq, group, heads, lq, lk in ((4, 2, 8, 300, 700), (2, 1, 8, 1024, 1024)):
     assert err < 3e-3 and err2 < 5e-3, (err, err2)
 print("OK")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, I2V_ATTN32="1"), capture_output=True, text=True,
+    r = subprocess.run([sys.executable, "-c", code], env=_variants_env(I2V_ATTN32="1"), capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_attention_software_pipelined_opt_in_child_process(dev):
-    """I2V_ATTN_PIPE=1 (read once per process, hence the child): the three-stage software-pipelined key loop of attention_pipe.hip
+    """I2V_ATTN_PIPE=1 (read once per process, hence the child): the three-stage software-pipelined key loop of csrc/variants/attention_pipe.hip
     for head_dim 40 and whole 64-key tiles -- same results as the default kernel at unit and at large logits, odd and even tile
     counts, cross-frame groups, accumulate; measured slower (profiles/r3_attn_pipe_ab.txt), kept as a tested A/B switch."""
     import os, subprocess, sys
@@ -476,7 +488,7 @@ for bq, group, heads, lq, lk, amp in ((4, 2, 8, 300, 704, 1.0), (2, 1, 8, 1024, 
     assert err < 1e-3 * amp * amp and err2 < 5e-3 * amp * amp, (err, err2)
 print("OK")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, I2V_ATTN_PIPE="1"), capture_output=True, text=True,
+    r = subprocess.run([sys.executable, "-c", code], env=_variants_env(I2V_ATTN_PIPE="1"), capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
@@ -846,18 +858,18 @@ def test_gemm_4wave_two_workgroups_per_cu_variant(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu",
                         "-k", "(gemm or fold or project_vt) and not 4wave and not conv"], cwd=root,
-                       env=dict(os.environ, I2V_GEMM_4W="1"), capture_output=True, text=True, timeout=1500)
+                       env=_variants_env(I2V_GEMM_4W="1"), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 
 
 def test_gemm_alternating_groups_opt_in_child_process(dev):
-    """I2V_GEMM_ALT=2 (read once per process) sends the short-K GEMM flavours to the alternating-groups kernel (gemm_alt.hip:
+    """I2V_GEMM_ALT=2 (read once per process) sends the short-K GEMM flavours to the alternating-groups kernel (csrc/variants/gemm_alt.hip:
     one wave group in the K loop of a 128-row tile while the other runs the previous tile's epilogue; measured slower, kept
     as a switch): tools/alt_ab.py checks every flavour against a torch fp32 reference in a child process."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "alt_ab.py")], cwd=root, env=dict(os.environ, I2V_GEMM_ALT="2"),
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "alt_ab.py")], cwd=root, env=_variants_env(I2V_GEMM_ALT="2"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     errs = [float(m) for m in re.findall(r"rel err ([0-9.e+-]+)", r.stdout)]

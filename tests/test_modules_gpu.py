@@ -295,6 +295,13 @@ def test_pipeline_trajectory(dev, use_graph):
     again = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, condition_image_latents=cond, use_graph=use_graph,
                  **kw, **gens()).frames
     assert torch.equal(got, again), "same seeds must reproduce the trajectory bit for bit"
+    # pipe:693-697: a per-step callback under the DEFAULT mode (use_graph=True) runs the steps as eager launches instead
+    # of raising; it sees every step (callback_steps = 1) and the trajectory is the same bit for bit
+    seen = []
+    cb = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, condition_image_latents=cond,
+              callback=lambda i, t, lat: seen.append((i, int(t), tuple(lat.shape))), **kw, **gens()).frames
+    assert [s[0] for s in seen] == list(range(9)) and seen[0][2] == (1, 4, 4, 16, 16)
+    assert torch.equal(cb, got)
     assert again.data_ptr() != got.data_ptr()
     if use_graph:
         # the captured step is reused by later calls of the same shape: a DIFFERENT sample through the cached graph must

@@ -478,3 +478,99 @@ def test_adamw_clip_matches_torch(dev):
     got = dict(hold.named_parameters())
     for n, prm in zip(opt.names, ref_params):
         assert torch.equal(got[n].detach().cpu(), prm.detach().half())
+
+
+def test_adamw_step_with_overflowed_gradients_is_skipped(dev):
+    """one inf in the fp16-scaled gradients must not poison the weights.  The guarded step leaves parameters,
+    both moments and the bias-correction step untouched and raises the device flag (what accelerate's GradScaler does for the
+    reference's `--mixed_precision fp16` run, train_image_to_video.py:306-308); the next finite step then equals the step a
+    torch optimiser takes that never saw the bad one.  The gradient norm is summed in a fixed order: bit-identical run to run."""
+    from i2v_adapter_unofficial_amd.training import AdapterOptimizer
+    p = pkg()
+    m = p.I2VAdapterTransformerBlock(64, 4, 16, cross_attention_dim=32)
+
+    class Holder(torch.nn.Module):
+        def __init__(self, blk):
+            super().__init__()
+            self.encoder_hid_proj = None
+            self.blocks = torch.nn.ModuleList([blk])
+    hold = Holder(m).to(dev).half()
+    ref_params = [torch.nn.Parameter(prm.detach().float().cpu().clone()) for n, prm in hold.named_parameters()
+                  if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n]
+    ref_opt = torch.optim.AdamW(ref_params, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    opt = AdapterOptimizer(hold, lr=1e-3, max_grad_norm=1.0)
+    g = torch.Generator().manual_seed(5)
+    draw = lambda s: {n: torch.randn(prm.shape, generator=g) * s for n, prm in zip(opt.names, ref_params)}
+
+    def ref_step(grads):
+        for prm, n in zip(ref_params, opt.names):
+            prm.grad = grads[n].clone()
+        torch.nn.utils.clip_grad_norm_(ref_params, 1.0)
+        ref_opt.step()
+
+    g1 = draw(0.5)
+    ref_step(g1)
+    opt.step({n: v.to(dev) for n, v in g1.items()})
+    assert not opt.last_step_skipped() and opt.applied_steps.item() == 1
+    before = [t.clone() for t in (opt.master, opt.exp_avg, opt.exp_avg_sq)]
+    params_before = {n: prm.detach().clone() for n, prm in hold.named_parameters()}
+    for bad_value in (float("inf"), float("nan")):
+        bad = {n: v.clone() for n, v in draw(0.5).items()}
+        bad[opt.names[1]].view(-1)[7] = bad_value
+        opt.step({n: v.to(dev) for n, v in bad.items()})
+        assert opt.last_step_skipped() and opt.applied_steps.item() == 1 and opt.step_count >= 2
+        for t, b in zip((opt.master, opt.exp_avg, opt.exp_avg_sq), before):
+            assert torch.equal(t, b), "a skipped step must not touch masters or moments"
+        for n, prm in hold.named_parameters():
+            assert torch.equal(prm.detach(), params_before[n])
+    g2 = draw(0.01)
+    ref_step(g2)
+    opt.step({n: v.to(dev) for n, v in g2.items()})
+    assert not opt.last_step_skipped() and opt.applied_steps.item() == 2
+    for n, prm in zip(opt.names, ref_params):
+        off, cnt = opt.offsets[n]
+        compare(opt.master[off: off + cnt].view_as(prm), prm, rel=1e-5, name=f"AdamW master after a skipped step: {n}")
+    # fixed-order norm: the same bucket gives the same bits every time
+    norms = []
+    for _ in range(3):
+        opt.fill_gradients({n: v.to(dev) for n, v in g1.items()})
+        pkg().kernels.adamw_guarded_step(opt.master.clone(), opt.grad, opt.exp_avg.clone(), opt.exp_avg_sq.clone(), lr=0.0,
+                               betas=opt.betas, eps=opt.eps, weight_decay=0.0, grad_coef=1.0, max_norm=1.0,
+                               partials=opt._partials, norm_sq=opt.norm_sq, applied_steps=opt.applied_steps.clone(),
+                               found_inf=opt.found_inf.clone())
+        norms.append(opt.norm_sq.clone())
+    assert torch.equal(norms[0], norms[1]) and torch.equal(norms[1], norms[2])
+    want = sum((v.double() ** 2).sum() for v in g1.values()).item()
+    assert abs(norms[0].item() - want) <= 1e-5 * want
+
+
+def test_training_steps_do_not_grow_memory(dev):
+    """forward + backward + optimiser step, repeated -- the in-place parameter writes of the optimiser must
+    neither re-pack frozen weights nor leave operand copies behind: the memo's size and the allocated bytes are constant from
+    the third cycle on."""
+    from tests.parity import hip_unet_from_oracle, oracle_small_unet, small_unet_inputs
+    from i2v_adapter_unofficial_amd import training
+    from i2v_adapter_unofficial_amd.training import AdapterOptimizer, UNetAdapterTrainer
+    hu = hip_unet_from_oracle(oracle_small_unet(seed=79), dev)
+    inp = small_unet_inputs(b=1, f=4, hw=16)
+    t = torch.tensor([481])
+    target = h(torch.randn(inp["sample"].shape, generator=torch.Generator().manual_seed(80)))
+    sample, ctx, tgt = inp["sample"].half().to(dev), inp["ctx"][:1].half().to(dev), target.to(dev)
+    tr, opt = UNetAdapterTrainer(hu), AdapterOptimizer(hu, lr=1e-4)
+    t2d = hu.down_blocks[0].attentions[0]
+    packs, sizes, mem, losses = [], [], [], []
+    for step in range(6):
+        tr.forward(sample, t.to(dev), ctx)
+        loss, grads = tr.backward(tgt, loss_scale=2.0 ** 10)
+        opt.step(grads)
+        del grads
+        torch.cuda.synchronize()
+        packs.append(t2d.packed()["wo"].data_ptr())
+        sizes.append(len(training._memo.d))
+        mem.append(torch.cuda.memory_allocated())
+        losses.append(loss.item())
+    assert not opt.last_step_skipped()
+    assert len(set(packs)) == 1, "Transformer2D re-packed proj_in / proj_out although only the adapter's weights moved"
+    assert len(set(sizes[2:])) == 1, f"operand memo keeps growing: {sizes}"
+    assert len(set(mem[2:])) == 1, f"allocated bytes keep growing: {mem}"
+    assert all(l == l for l in losses) and losses[-1] != losses[0], "the steps must actually move the weights"

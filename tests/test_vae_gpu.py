@@ -136,6 +136,10 @@ def test_pipeline_with_vae_end_to_end(dev, tmp_path):
     assert torch.equal(sliced, vid)
     frames = pipe(output_type="pil", **kw, **gens()).frames
     assert len(frames) == 1 and len(frames[0]) == 4 and frames[0][0].size == (64, 64)
+    # the reference's default output is "pil" (pipe:556): with a VAE attached, no output_type means PIL frames
+    dflt = pipe(**kw, **gens()).frames
+    assert isinstance(dflt[0][0], PIL.Image.Image) and len(dflt[0]) == 4
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(dflt[0], frames[0]))
     path = p.export_to_gif(frames[0], os.path.join(tmp_path, "sample.gif"))
     gif = PIL.Image.open(path)
     assert gif.n_frames == 4 and gif.size == (64, 64)

@@ -3,12 +3,21 @@
 # with the in-tree objects of the others into .ab_libs/NAME.so (select it with I2V_LIB_PATH; the in-tree library and
 # objects are untouched).
 # usage: bash tools/build_variant.sh NAME "extra hipcc flags" file.hip [file.hip ...]
+#        bash tools/build_variant.sh --variants
+#          -> .ab_libs/variants.so: the default library plus the measured-and-rejected kernel forms that the default build
+#             leaves out (csrc/variants/{attention32,attention_pipe,gemm_alt}.hip and the 4-wave gemm_big instantiations,
+#             -DI2V_VARIANTS), selected there by I2V_ATTN32 / I2V_ATTN_PIPE / I2V_GEMM_ALT / I2V_GEMM_4W.
 set -e
 cd "$(dirname "$0")/.."
-name=$1; extra=$2; shift 2
-python __graft_entry__.py > /dev/null          # in-tree objects up to date
 csrc=i2v-adapter-unofficial_amd/csrc
+if [ "$1" = "--variants" ]; then
+  name=variants; extra="-DI2V_VARIANTS"; set -- attention.hip gemm_big.hip variants/attention32.hip variants/attention_pipe.hip variants/gemm_alt.hip
+else
+  name=$1; extra=$2; shift 2
+fi
+python __graft_entry__.py > /dev/null          # in-tree objects up to date
 mkdir -p .ab_libs/obj_$name
+rm -f .ab_libs/obj_$name/*.o
 objs=()
 for o in $csrc/build/*.o; do
   b=$(basename "$o" .o); keep=1
@@ -17,7 +26,7 @@ for o in $csrc/build/*.o; do
 done
 for f in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form \
-    -fno-honor-nans $extra -c $csrc/$f -o .ab_libs/obj_$name/${f%.hip}.o &
+    -fno-honor-nans $extra -c $csrc/$f -o .ab_libs/obj_$name/$(basename ${f%.hip}).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o .ab_libs/$name.so "${objs[@]}" .ab_libs/obj_$name/*.o
