@@ -416,6 +416,8 @@ def main():
         # per-sample work outside the step: K / V^T of the context for the 16 cross-attention layers, written into the
         # buffers the captured graph reads
         st["ctx_proj"] = model.project_context(st["ctx_text"], st["ctx_ip"], out=st.get("ctx_proj"))
+        # ... and the time-embedding chain of every timestep of the schedule (a function of t alone): the step selects its row
+        st["temb_table"] = model.project_time_table(st["t_table"], out=st.get("temb_table"))
         st["step_idx"].zero_()
 
     with torch.no_grad():

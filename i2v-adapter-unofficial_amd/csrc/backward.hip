@@ -1055,7 +1055,9 @@ __global__ __launch_bounds__(256) void adamw_prepare_kernel(const float* __restr
   if (threadIdx.x == 0) {
     const float total = (red[0] + red[1]) + (red[2] + red[3]);
     *norm_sq = total;
-    const bool bad = !(fabsf(total) <= 3.0e38f);     // inf or NaN (written without isfinite: -fno-honor-nans builds fold it)
+    // inf or NaN, tested on the BITS (exponent all ones): this library is built with -fno-honor-nans, under which the compiler
+    // rewrites !(|x| <= c) as |x| > c -- false for NaN (the first form of this test let a NaN gradient through)
+    const bool bad = (__builtin_bit_cast(uint32_t, total) & 0x7f800000u) == 0x7f800000u;
     *found_inf = bad ? 1 : 0;
     if (!bad) *applied_steps += 1;
   }

@@ -47,6 +47,27 @@ __device__ __forceinline__ f32x4 mfma16x16x32(f16x8 a, f16x8 b, f32x4 c) {
 // constants (1/sqrt 2 into p, 0.5 into the coefficients, log2 e / 2 into the exp2 argument) are folded, |x| and the
 // negations are free source modifiers, and there is no sign select: 11 plain VALU + rcp + exp2 per value (the GEGLU
 // epilogue of a K = 320 GEMM spends as long in this function as in its MFMAs).
+// -DI2V_GELU_POLY (A/B switch): transcendental-free form.  gelu(x) = max(x, 0) - f(min(|x|, 4.5)) with
+// f(t) = t (1 - Phi(t)) fitted by a degree-10 polynomial (weighted least squares iterated to near-minimax, /tmp-free:
+// tools/fit_gelu.py): max |error| 5.4e-5 over all x in fp32 Horner form -- 10 FMAs + min + max + sub against 11 VALU +
+// v_rcp + v_exp above.  A degree low enough to matter (<= 7) leaves > 5e-4, i.e. more than the fp16 rounding of the result.
+#ifdef I2V_GELU_POLY
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float t = fminf(fabsf(x), 4.5f);
+  float p = -1.249767080e-05f;
+  p = fmaf(p, t, 2.955848309e-04f);
+  p = fmaf(p, t, -2.873543129e-03f);
+  p = fmaf(p, t, 1.433596371e-02f);
+  p = fmaf(p, t, -3.558747558e-02f);
+  p = fmaf(p, t, 2.392290017e-02f);
+  p = fmaf(p, t, 5.806891481e-02f);
+  p = fmaf(p, t, -3.189784297e-03f);
+  p = fmaf(p, t, -3.956423631e-01f);
+  p = fmaf(p, t, 4.992980543e-01f);
+  p = fmaf(p, t, 2.421257562e-05f);
+  return fmaxf(x, 0.0f) - p;
+}
+#else
 __device__ __forceinline__ float gelu_erf(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
@@ -55,6 +76,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float h = poly * __builtin_amdgcn_exp2f(-(y * y));
   return fmaf(-ax, h, fmaxf(x, 0.0f));
 }
+#endif
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ f16x8 ld_global_16B(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }

@@ -65,6 +65,14 @@ __global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __
   }
 }
 
+// out[c] = table[clamp(*row_index)][c]: the row of a per-timestep table that belongs to the step a replayed hipGraph is at
+__global__ __launch_bounds__(256) void select_row_kernel(const f16* __restrict__ table, int64_t ld, int rows,
+                                                         const int32_t* __restrict__ row_index, f16* __restrict__ out, int cols8) {
+  const int r = min(max(*row_index, 0), rows - 1);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cols8; i += gridDim.x * 256)
+    *reinterpret_cast<f16x8*>(out + 8 * i) = *reinterpret_cast<const f16x8*>(table + (int64_t)r * ld + 8 * i);
+}
+
 __global__ __launch_bounds__(256) void silu_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     y[i] = (f16)silu_f((float)x[i]);
@@ -256,6 +264,17 @@ extern "C" int i2v_timestep_embedding(const float* t, const int32_t* t_index, in
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3(ew_blocks((int64_t)n * dim / 2)), dim3(256), 0, s, t, t_index,
                      t_rows, reinterpret_cast<f16*>(out), n, dim);
   return i2v_check_launch("i2v_timestep_embedding");
+}
+
+extern "C" int i2v_select_row_f16(const void* table, int64_t ld, int32_t rows, const int32_t* row_index, void* out, int32_t cols,
+                                  i2v_stream_t stream) {
+  I2V_CHECK_ARG(table && row_index && out && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols,
+                "i2v_select_row_f16: cols and ld must be positive multiples of 8 with ld >= cols");
+  I2V_CHECK_ARG(reinterpret_cast<uintptr_t>(table) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0,
+                "i2v_select_row_f16: 16-byte aligned pointers expected");
+  hipLaunchKernelGGL(select_row_kernel, dim3(ew_blocks(cols / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(table), ld, rows, row_index, reinterpret_cast<f16*>(out), cols / 8);
+  return i2v_check_launch("i2v_select_row_f16");
 }
 
 extern "C" int i2v_silu_f16(const void* x, void* y, int64_t n, i2v_stream_t stream) {

@@ -449,6 +449,13 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
                "problem (M %d N %d K %d, rows_per_w %d, a_perm %d x %d): they need the 8-wave kernel with full row tiles",
                p.M, p.N, p.K, p.rows_per_w, p.a_perm_frames, p.a_perm_hw);
   }
+#ifdef I2V_VARIANTS
+  // the K = 320 projections of the 64 x 64 level: weight-stationary kernel (variants/gemm_ws.hip; opt-in, I2V_GEMM_WS=1)
+  {
+    const int ws = i2v_gemm_ws_try(p, reinterpret_cast<hipStream_t>(stream));
+    if (ws != 0) return ws < 0 ? ws : I2V_OK;
+  }
+#endif
   // large problems whose N is a multiple of 320 go to the 8-wave LDS-DMA kernel (gemm_big.hip)
   {
     const int big = i2v_gemm_big_try(p, vec4, reinterpret_cast<hipStream_t>(stream));

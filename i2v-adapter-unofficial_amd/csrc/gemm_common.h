@@ -121,3 +121,7 @@ int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4);
 int i2v_gemm_big_unsplit_ok(const i2v_gemm_params& p, int vec4);
 // fp32 scratch bytes with which gemm_big.hip would split K for this problem (0: no split)
 int64_t i2v_gemm_big_workspace_bytes(const i2v_gemm_params& p, int vec4);
+// implemented in gemm_ws.hip: the weight-stationary kernel for K = 320 row-major projections with >= 16384 rows (W slices in
+// registers, A streamed through three LDS stages); same return convention as i2v_gemm_big_try
+int i2v_gemm_ws_try(const i2v_gemm_params& p, hipStream_t s);
+int i2v_gemm_ws_ok(const i2v_gemm_params& p);

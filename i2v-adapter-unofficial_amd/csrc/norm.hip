@@ -529,7 +529,15 @@ __global__ __launch_bounds__(256) void ln_kernel(const i2v_ln_params p) {
     for (int i = 0; i < NV; ++i) {
       const int vi = lane + 64 * i;
       f16x8 t = zero8();
-      if (live && vi < nvec) t = ld_global_16B(x + (int64_t)(row0 + r) * p.ldx + vi * 8);
+      if (live && vi < nvec) {
+        const int row = row0 + r;
+        int64_t off = (int64_t)row * p.ldx;
+        if (p.x_rows_per_batch > 0) {   // batched row blocks (frame-0 rows of every clip): wave-uniform arithmetic
+          const int b = row / p.x_rows_per_batch;
+          off = (int64_t)b * p.x_batch_stride + (int64_t)(row - b * p.x_rows_per_batch) * p.ldx;
+        }
+        t = ld_global_16B(x + off + vi * 8);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[r][i][e] = (float)t[e];
@@ -766,6 +774,8 @@ extern "C" int i2v_layernorm_f16(const i2v_ln_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.ldx >= p.C && p.ldy >= p.C, "i2v_layernorm_f16: bad ldx / ldy");
   I2V_CHECK_ARG(al16(p.x) && al16(p.y) && al16(p.gamma) && al16(p.beta), "i2v_layernorm_f16: 16-byte alignment");
   if (p.pe) I2V_CHECK_ARG(p.pe_period > 0 && p.ld_pe % 8 == 0 && al16(p.pe), "i2v_layernorm_f16: bad pe arguments");
+  I2V_CHECK_ARG(p.x_rows_per_batch >= 0 && (p.x_rows_per_batch == 0 || (p.x_batch_stride % 8 == 0 && p.x_batch_stride > 0)),
+                "i2v_layernorm_f16: x_batch_stride must be a positive multiple of 8 elements");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 block(256);
   const int nv = (int)i2v_cdiv(p.C / 8, 64);

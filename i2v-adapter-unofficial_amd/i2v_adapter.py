@@ -185,14 +185,15 @@ class I2VAdapterTransformerBlock(HipModule):
                     vt1 = K.project_vt(n, p["w_v1"], L)
                 if enable_cross_frame_attn:
                     clips = n_img // num_frames
-                    src = x if n is None else n
-                    if clips == 1:   # one clip: its frame-0 rows are the first L rows as they stand
-                        first = src[:L]
+                    if n is None:
+                        # LayerNorm 1 folded away: normalise just the frame-0 rows of every clip (1 / num_frames of the
+                        # work), read IN PLACE from x as a batch of row blocks -- no gathered copy (i2v:484, no repeat)
+                        first = K.layernorm(x.view(clips, num_frames * L, c)[:, :L], p["g1"], p["b1"], self.eps)
+                    elif clips == 1:   # one clip: its frame-0 rows are the first L rows as they stand
+                        first = n[:L]
                     else:
                         first = torch.empty((clips, L, c), dtype=f16, device=x.device)
-                        K.copy3d(src.view(clips, num_frames * L, c)[:, :L], first)           # i2v:484 (no repeat)
-                    if n is None:   # frame-0 rows only: normalise just those (1 / num_frames of the work)
-                        first = K.layernorm(first.reshape(-1, c), p["g1"], p["b1"], self.eps)
+                        K.copy3d(n.view(clips, num_frames * L, c)[:, :L], first)             # i2v:484 (no repeat)
                     f2d = first.reshape(-1, c)
                     k0 = K.gemm(f2d, p["w_k_ad"])
                     v0t = K.project_vt(f2d, p["w_v_ad"], L)

@@ -408,10 +408,21 @@ def groupnorm_fold(x, gamma, beta, groups, eps, w, bias, *, x2=None, frames_per_
 
 
 def layernorm(x, gamma, beta, eps, *, pe=None, pe_period=0):
-    """LayerNorm over the last dim of a 2-D token matrix (+ pe[row % pe_period])."""
+    """LayerNorm over the last dim of a 2-D token matrix (+ pe[row % pe_period]).  x may also be a 3-D view
+    [batches, rows_per_batch, C] with arbitrary batch stride (e.g. the frame-0 rows of every clip, i2v:484): the rows are
+    read in place and the result is the dense [batches * rows_per_batch, C] matrix."""
     lib = _lib.load()
-    x, ldx = _mat(x, "x")
-    rows, Cc = x.shape
+    batched = None
+    if x.dim() == 3:
+        _req(x, "x")
+        if x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(0) % 8 != 0 or x.stride(0) <= 0:
+            raise ValueError("batched layernorm input needs unit last stride and row / batch strides that are multiples of 8")
+        batched = (x.shape[1], x.stride(0))
+        ldx = x.stride(1)
+        rows, Cc = x.shape[0] * x.shape[1], x.shape[2]
+    else:
+        x, ldx = _mat(x, "x")
+        rows, Cc = x.shape
     _req(gamma, "gamma")
     _req(beta, "beta")
     y = torch.empty((rows, Cc), dtype=f16, device=x.device)
@@ -425,6 +436,8 @@ def layernorm(x, gamma, beta, eps, *, pe=None, pe_period=0):
         p.pe, p.ld_pe, p.pe_period = _p(pe), ldpe, pe_period
     p.y, p.ldy = _p(y), Cc
     p.rows, p.C, p.eps = rows, Cc, eps
+    if batched is not None:
+        p.x_rows_per_batch, p.x_batch_stride = batched
     _lib.check(lib.i2v_layernorm_f16(C.byref(p), _stream()), "i2v_layernorm_f16")
     return y
 
@@ -497,6 +510,19 @@ def silu(x):
     y = torch.empty_like(x)
     _lib.check(lib.i2v_silu_f16(_p(x), _p(y), x.numel(), _stream()), "i2v_silu_f16")
     return y
+
+
+def select_row(table, row_index, out=None):
+    """[1, cols] = table[clamp(*row_index)] for a device int32 scalar `row_index` (a replayed step's row of a per-timestep
+    table)."""
+    lib = _lib.load()
+    table, ld = _mat(table, "table")
+    _req(row_index, "row_index", dtype=torch.int32)
+    if out is None:
+        out = torch.empty((1, table.shape[1]), dtype=f16, device=table.device)
+    _lib.check(lib.i2v_select_row_f16(_p(table), ld, table.shape[0], _p(row_index), _p(out), table.shape[1], _stream()),
+               "i2v_select_row_f16")
+    return out
 
 
 def repeat_rows(x, repeat):

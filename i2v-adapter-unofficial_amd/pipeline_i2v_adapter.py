@@ -167,11 +167,13 @@ class I2VAdapterPipeline:
         """One iteration of pipe:666-697 as kernel launches on the current stream (captured into a hipGraph)."""
         unet = self.unet
         x = K.ddim_prep(st["latents"], st["cond"], unet.packed()["cin_pad"], st["copies"])    # pipe:668-673
-        temb = unet._embed_time(st["t_table"], t_index=st["step_idx"])
+        # the time-embedding chain of this step's timestep: one row of the table computed once per sample (_time_table)
+        temb_proj = K.select_row(st["temb_table"], st["step_idx"])
         # the CFG halves are copies of one tensor at one timestep (pipe:672-673): what does not depend on the prompt is
         # computed once (unet._fwd_tokens, cfg_shared)
-        y = unet._fwd_tokens(x, temb, True, st.get("ctx_proj") or st["ctx_text"], st["ctx_ip"],
-                             st["num_frames"], cfg_shared=CFG_SHARED and st["copies"] == 2)   # pipe:676-683
+        y = unet._fwd_tokens(x, None, True, st.get("ctx_proj") or st["ctx_text"], st["ctx_ip"],
+                             st["num_frames"], cfg_shared=CFG_SHARED and st["copies"] == 2,
+                             temb_proj=temb_proj)                                              # pipe:676-683
         K.ddim_cfg_step(st["latents"], y, st["coef"], st["step_idx"], st["guidance"], st["copies"])  # pipe:686-691
 
     def _graph_key(self, st):
@@ -188,6 +190,7 @@ class I2VAdapterPipeline:
     def _run_steps(self, st, n_steps, use_graph):
         if not use_graph:
             st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
+            st["temb_table"] = self.unet.project_time_table(st["t_table"])
             for _ in range(n_steps):
                 self._step(st)
             return st["latents"]
@@ -204,12 +207,14 @@ class I2VAdapterPipeline:
                     gst[name].copy_(st[name])
             gst["step_idx"].zero_()
             self.unet.project_context(gst["ctx_text"], gst["ctx_ip"], out=gst["ctx_proj"])
+            self.unet.project_time_table(gst["t_table"], out=gst["temb_table"])
         else:
             # one shape at a time (a graph pins its workspace): the old graph and its pool go before the new capture,
             # so two pools never coexist at the peak
             cache.clear()
             self._graph = None
             st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
+            st["temb_table"] = self.unet.project_time_table(st["t_table"])
             # warm-up outside capture: packs weights, sizes the allocator; then restore the state it advanced
             saved = st["latents"].clone()
             self._step(st)
@@ -334,6 +339,7 @@ class I2VAdapterPipeline:
             st["latents"] = self._run_steps(st, len(timesteps), use_graph)
         else:
             st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
+            st["temb_table"] = self.unet.project_time_table(st["t_table"])
             for i, t in enumerate(timesteps):                                                   # pipe:666-697
                 self._step(st)
                 if i % callback_steps == 0:

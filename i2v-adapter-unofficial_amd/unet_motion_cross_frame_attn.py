@@ -638,13 +638,24 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
             self._temb_packed, self._temb_packed_key = (w, b, slices), key
         return self._temb_packed
 
-    def _fwd_tokens(self, x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=False):
-        """x: model-input tokens [B*F, H, W, cin_pad] fp16; temb [B, 4*C0] fp16 (pre-SiLU); ctx_text [B, Lt, D]
+    def project_time_table(self, timesteps_f32, out=None):
+        """[T, sum Cout] fp16: `time_emb_proj(silu(time_embedding(time_proj(t))))` of every ResnetBlock2D (unet:1336-1343,
+        SURVEY A2) for ALL T timesteps of a schedule at once.  The chain depends on t only -- not on the latents -- so the
+        pipeline computes it once per sample (like `project_context`) and a replayed step selects its row by the device-side
+        step counter (`K.select_row`): 6 launches of M = 1 products per step become one 40 KB copy."""
+        wt, bt, _ = self._temb_pack()
+        temb = self._embed_time(timesteps_f32.to(torch.float32).contiguous())
+        return K.gemm(K.silu(temb), wt, bt, out=out)
+
+    def _fwd_tokens(self, x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=False, temb_proj=None):
+        """x: model-input tokens [B*F, H, W, cin_pad] fp16; temb [B, 4*C0] fp16 (pre-SiLU) -- or temb_proj [B or 1, sum Cout]:
+        the resnets' time-embedding projections already computed (project_time_table); ctx_text [B, Lt, D]
         (+ ctx_ip [B, 4, D]) or a ProjectedContext; returns noise-prediction tokens [B*F, H, W, out_channels]."""
         p = self.packed()
         wt, bt, slices = self._temb_pack()
         # ResnetBlock2D: time_emb_proj(nonlinearity(temb)) of all 22 resnets in one GEMM
-        temb_act = ProjectedTemb(K.gemm(K.silu(temb), wt, bt), slices)
+        temb_act = ProjectedTemb(temb_proj if temb_proj is not None else K.gemm(K.silu(temb), wt, bt), slices)
+        temb_rows = temb_proj.shape[0] if temb_proj is not None else temb.shape[0]
         # cfg_shared: the caller's batch is [unconditional half ; conditional half] of the SAME latents at the SAME timestep
         # (pipe:672-673 `torch.cat([latents] * 2)`).  Until the first text cross-attention the two halves are the same
         # numbers -- conv_in, the first resnet, GroupNorm / proj_in and the whole self- + cross-frame attention stage of the
@@ -652,7 +663,7 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
         # where the prompt enters.  Same arithmetic per element; the bits are identical whenever the dispatcher picks the same
         # kernel forms for the half and the full batch (it does at 16 f x 512 x 512), else equal to reduction-order rounding
         # (tests/test_full_width_gpu.py).
-        cfg_shared = (cfg_shared and x.shape[0] % (2 * num_frames) == 0 and (temb.shape[0] == 1 or temb.shape[0] % 2 == 0) and
+        cfg_shared = (cfg_shared and x.shape[0] % (2 * num_frames) == 0 and (temb_rows == 1 or temb_rows % 2 == 0) and
                       isinstance(self.down_blocks[0], CrossFrameAttnDownBlockMotion))
         if cfg_shared:
             x = x[: x.shape[0] // 2]

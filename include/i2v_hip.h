@@ -246,6 +246,11 @@ typedef struct i2v_ln_params {
   void* y; int64_t ldy;
   int32_t rows, C;
   float eps;
+  /* x_rows_per_batch > 0: the input is a batch of row blocks, output row r reads x + (r / x_rows_per_batch) *
+   * x_batch_stride + (r % x_rows_per_batch) * ldx (elements).  The cross-frame attention normalises only the frame-0
+   * rows of each clip (i2v:484: `norm_hidden_states[0:batch:num_frames]`): rows_per_batch = tokens per frame, batch
+   * stride = one clip, read in place instead of through a gathered copy.  0: one dense matrix (the output is always dense). */
+  int32_t x_rows_per_batch; int64_t x_batch_stride;
 } i2v_ln_params;
 
 int i2v_layernorm_f16(const i2v_ln_params* p, i2v_stream_t stream);
@@ -272,6 +277,11 @@ int i2v_tokens_to_nchw(const void* src, int32_t src_is_f32, int64_t ld, void* ds
  * t[clamp(*t_index, 0, t_rows - 1)] is used for every row (graph replay). */
 int i2v_timestep_embedding(const float* t, const int32_t* t_index, int32_t t_rows, void* out, int32_t n,
                            int32_t dim, i2v_stream_t stream);
+/* out[0, :] = table[clamp(*row_index, 0, rows - 1), :] (fp16, cols % 8 == 0): the pipeline computes
+ * time_emb_proj(silu(time_embedding(time_proj(t)))) of every resnet (unet:1336-1343) for ALL timesteps of the
+ * schedule once per sample; a replayed step picks its row by the device-side step counter (pipe:666 `for i, t in ...`). */
+int i2v_select_row_f16(const void* table, int64_t ld, int32_t rows, const int32_t* row_index, void* out, int32_t cols,
+                       i2v_stream_t stream);
 /* y = silu(x), fp16, n elements (nonlinearity(temb), ResnetBlock2D). */
 int i2v_silu_f16(const void* x, void* y, int64_t n, i2v_stream_t stream);
 /* y[r, :] = x[r / repeat, :]  (repeat_interleave of temb / context rows, unet:1344,1355). */

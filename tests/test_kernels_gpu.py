@@ -680,6 +680,85 @@ def test_gemm_layernorm_fold(dev, M, N, K_, kind, mean):
         close(vt[:, :, :L], ref, name=f"LN-folded V^T {kind}")
 
 
+_WS_CASES = [(16384, 320, "bias"), (20032, 320, "res"), (16384 + 64 * 7, 640, "ln"), (32768, 640, "ln_pe"), (16384, 960, "ln"),
+             (24576, 2560, "geglu_ln"), (16384, 640, "geglu"), (65536, 320, "res_views"), (131072, 320, "res"),
+             (16448, 1280, "pe")]
+
+
+@pytest.mark.parametrize("M,N,kind", _WS_CASES)
+def test_gemm_k320_row_major_flavours(dev, M, N, kind):
+    """every epilogue flavour of the K = 320 row-major projections with >= 16384 rows (q | k | v, out-projections, GEGLU of the
+    64 x 64 level) against fp32 torch, through whichever kernel the library dispatches (the 8-wave tile kernel by default)."""
+    _ws_case(dev, M, N, kind)
+
+
+def test_gemm_weight_stationary_opt_in_child_process(dev):
+    """csrc/variants/gemm_ws.hip (W slices in registers, A through three LDS stages; measured not faster, opt-in
+    I2V_GEMM_WS=1 in the variants library): the same cases in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "k320_row_major"], cwd=root, env=_variants_env(I2V_GEMM_WS="1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _ws_case(dev, M, N, kind):
+    """bias, residual, LayerNorm fold (+ positional table), GEGLU (+ fold), row counts that leave 256 workgroups unequal shares,
+    A / residual / C as column slices of wider matrices."""
+    from i2v_adapter_unofficial_amd.blocks import fold_layernorm, fold_layernorm_geglu
+    k = K()
+    K_ = 320
+    g = torch.Generator().manual_seed(M + N)
+    x = h(torch.randn(M, K_, generator=g) * 1.5 + (2.0 if "ln" in kind else 0.0))
+    w = h(torch.randn(N, K_, generator=g) / math.sqrt(K_))
+    b = h(torch.randn(N, generator=g))
+    ga, be = h(1 + 0.2 * torch.randn(K_, generator=g)), h(0.2 * torch.randn(K_, generator=g))
+    xd, wd, bd = x.half().to(dev), w.half().to(dev), b.half().to(dev)
+    frames = 16
+    pe = h(torch.randn(32, K_, generator=g))
+    if kind == "bias":
+        close(k.gemm(xd, wd, bd, out_scale=0.5), 0.5 * (x @ w.T + b), name="ws gemm + bias")
+        close(k.gemm(xd, wd), x @ w.T, name="ws gemm, no bias")
+    elif kind == "res":
+        r = h(torch.randn(M, N, generator=g))
+        close(k.gemm(xd, wd, bd, residual=r.half().to(dev)), x @ w.T + b + r, name="ws gemm + residual")
+    elif kind == "res_views":
+        # A = a column slice of a wider matrix (lda 960), the residual and the output likewise (ldr, ldc = 640)
+        wide = torch.zeros(M, 960, dtype=torch.float16, device=dev)
+        wide[:, 320:640] = xd
+        r = h(torch.randn(M, N, generator=g))
+        rw = torch.zeros(M, 640, dtype=torch.float16, device=dev)
+        rw[:, 320:] = r.half().to(dev)
+        out = torch.full((M, 640), float("nan"), dtype=torch.float16, device=dev)
+        k.gemm(wide[:, 320:640], wd, bd, residual=rw[:, 320:], out=out[:, :320])
+        close(out[:, :320], x @ w.T + b + r, name="ws gemm on column-slice views")
+        assert torch.isnan(out[:, 320:]).all(), "columns outside the output view were written"
+    elif kind in ("ln", "ln_pe"):
+        n = F.layer_norm(x, (K_,), ga, be, eps=1e-5)
+        wf, ws, cb = (t.to(dev) for t in fold_layernorm(w, b, ga, be))
+        kw, ref = {}, n @ w.T + b
+        if kind == "ln_pe":
+            kw = dict(rowvec=(pe @ w.T).half().to(dev), rowvec_period=frames)
+            ref = (n.view(-1, frames, K_) + pe[:frames]).view(M, K_) @ w.T + b
+        close(k.gemm(xd, wf, cb, ln=(ws, 1e-5), **kw), ref, name=f"ws gemm, LayerNorm fold {kind}")
+    elif kind == "pe":
+        tab = h(torch.randn(8, N, generator=g))
+        close(k.gemm(xd, wd, bd, rowvec=tab.half().to(dev), rowvec_period=8), x @ w.T + b + tab.repeat(M // 8, 1),
+              name="ws gemm + periodic row vector")
+    elif kind == "geglu":
+        from i2v_adapter_unofficial_amd.blocks import pack_geglu
+        wg, bg = pack_geglu(wd, bd)
+        y = x @ w.T + b
+        close(k.gemm(xd, wg, bg, epilogue=k.I2V_EPI_GEGLU), y[:, : N // 2] * F.gelu(y[:, N // 2:]), name="ws geglu")
+    else:
+        n = F.layer_norm(x, (K_,), ga, be, eps=1e-5)
+        wf, ws, cb = (t.to(dev) for t in fold_layernorm_geglu(w, b, ga, be))
+        y = n @ w.T + b
+        close(k.gemm(xd, wf, cb, epilogue=k.I2V_EPI_GEGLU, ln=(ws, 1e-5)), y[:, : N // 2] * F.gelu(y[:, N // 2:]),
+              name="ws geglu, LayerNorm fold")
+
+
 def test_gemm_layernorm_fold_unsupported_shapes_fail_loudly(dev):
     """the fold exists only in the 8-wave kernel: small problems answer `unsupported` and a forced call is an error,
     never a silently un-normalised result."""
@@ -709,6 +788,41 @@ def test_layernorm(dev, rows, c, pe_period):
     out = k.layernorm(x.half().to(dev), ga.half().to(dev), be.half().to(dev), 1e-5,
                       pe=None if pe is None else pe.half().to(dev), pe_period=pe_period)
     close(out, ref, name="layernorm")
+
+
+@pytest.mark.parametrize("clips,frames,L,c", [(2, 4, 48, 320), (3, 2, 7, 640), (1, 16, 64, 1280)])
+def test_layernorm_batched_row_blocks(dev, clips, frames, L, c):
+    """the frame-0 rows of every clip (i2v:484) normalised IN PLACE from the [clips * frames * L, C] token matrix (a 3-D
+    view with the clip as batch stride): bit-identical to LayerNorm of the gathered copy, and to torch."""
+    k = K()
+    g = torch.Generator().manual_seed(clips * 100 + L)
+    x = h(torch.randn(clips * frames * L, c, generator=g) * 2 + 0.5)
+    ga, be = h(torch.randn(c, generator=g)), h(torch.randn(c, generator=g))
+    xd = x.half().to(dev)
+    view = xd.view(clips, frames * L, c)[:, :L]
+    out = k.layernorm(view, ga.half().to(dev), be.half().to(dev), 1e-5)
+    assert out.shape == (clips * L, c)
+    gathered = view.contiguous().view(-1, c)
+    assert torch.equal(out, k.layernorm(gathered, ga.half().to(dev), be.half().to(dev), 1e-5))
+    close(out, F.layer_norm(x.view(clips, frames * L, c)[:, :L].reshape(-1, c), (c,), ga, be, eps=1e-5),
+          name="layernorm over batched row blocks")
+    with pytest.raises(ValueError):       # a batch stride that is not a multiple of 8 elements
+        k.layernorm(torch.zeros(2, 9, c + 4, dtype=torch.float16, device=dev)[:, :4, :c], ga.half().to(dev),
+                    be.half().to(dev), 1e-5)
+
+
+def test_select_row_follows_the_device_step_counter(dev):
+    """K.select_row: the row of a per-timestep table at the DEVICE-side index (clamped to the table), as the replayed step
+    reads its time-embedding projections."""
+    k = K()
+    table = torch.randn(5, 64, generator=torch.Generator().manual_seed(2)).half().to(dev)
+    idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    for i, want in ((0, 0), (3, 3), (4, 4), (9, 4), (-2, 0)):
+        idx.fill_(i)
+        assert torch.equal(k.select_row(table, idx), table[want: want + 1])
+    wide = torch.randn(3, 96, generator=torch.Generator().manual_seed(3)).half().to(dev)
+    idx.fill_(1)
+    assert torch.equal(k.select_row(wide[:, :64], idx), wide[1:2, :64])        # a column slice: ld > cols
 
 
 def test_layout_edges_and_misc(dev):

@@ -5,13 +5,14 @@
 # usage: bash tools/build_variant.sh NAME "extra hipcc flags" file.hip [file.hip ...]
 #        bash tools/build_variant.sh --variants
 #          -> .ab_libs/variants.so: the default library plus the measured-and-rejected kernel forms that the default build
-#             leaves out (csrc/variants/{attention32,attention_pipe,gemm_alt}.hip and the 4-wave gemm_big instantiations,
-#             -DI2V_VARIANTS), selected there by I2V_ATTN32 / I2V_ATTN_PIPE / I2V_GEMM_ALT / I2V_GEMM_4W.
+#             leaves out (csrc/variants/{attention32,attention_pipe,gemm_alt,gemm_ws}.hip and the 4-wave gemm_big
+#             instantiations, -DI2V_VARIANTS), selected there by I2V_ATTN32 / I2V_ATTN_PIPE / I2V_GEMM_ALT / I2V_GEMM_4W /
+#             I2V_GEMM_WS.
 set -e
 cd "$(dirname "$0")/.."
 csrc=i2v-adapter-unofficial_amd/csrc
 if [ "$1" = "--variants" ]; then
-  name=variants; extra="-DI2V_VARIANTS"; set -- attention.hip gemm_big.hip variants/attention32.hip variants/attention_pipe.hip variants/gemm_alt.hip
+  name=variants; extra="-DI2V_VARIANTS"; set -- attention.hip gemm_big.hip gemm.hip variants/attention32.hip variants/attention_pipe.hip variants/gemm_alt.hip variants/gemm_ws.hip
 else
   name=$1; extra=$2; shift 2
 fi
