@@ -169,6 +169,62 @@ def plan_groups(n_pairs_total, rank, world, batch):
     return [idx[i: i + batch] for i in range(0, len(idx), batch)]
 
 
+def latent_parity(args, model, dev):
+    """`--latent-parity N`: N DDIM steps of this workload (config 2 by default) through the HIP pipeline (hipGraph replay, the
+    route the timed step runs) and through the CPU oracle's pipeline (pipe:629-700 restated, fp32) on the same weights, seeds
+    and condition latents; prints ONE JSON line with the max-abs / rms difference of the final LATENTS -- the quantity
+    north_star's tolerance is worded on.  ~1 minute of host time per step at 16 f x 512^2: kept out of the default run."""
+    import torch.nn.functional as F
+    import i2v_adapter_unofficial_amd as pkg
+    from oracle import blocks as oblocks
+    from oracle.pipeline_i2v_adapter import I2VAdapterPipeline as OraclePipeline
+    from oracle.unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel as OracleUNet
+    n_steps, frames, h_lat = args.latent_parity, args.frames, args.size // 8
+    with torch.device("meta"):
+        ou = OracleUNet(**SD15)
+    ou = ou.to_empty(device="cpu").float()
+    ou.load_state_dict({k: v.detach().float().cpu() for k, v in model.state_dict().items()})
+    ou.eval()
+    oblocks.Attention._sdpa = lambda self, q, k, v: F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(21)
+    h16 = lambda t: t.half().float()
+    pe, ne = h16(torch.randn(1, 77, 768, generator=g)), h16(torch.randn(1, 77, 768, generator=g))
+    cond = torch.randn(1, 4, h_lat, h_lat, generator=g)
+    total = 25
+    kw = dict(num_frames=frames, num_inference_steps=total, guidance_scale=7.5, blur_sigma=1.0,
+              frame_similarity_sample_ratio=(n_steps + 0.5) / total)          # get_timesteps: the LAST n_steps of the schedule
+    gens = lambda: dict(generator=torch.Generator().manual_seed(5), prior_mask_generator=torch.Generator().manual_seed(6),
+                        prior_noise_generator=torch.Generator().manual_seed(7))
+    pipe = pkg.I2VAdapterPipeline(unet=model)
+    with torch.no_grad():
+        got = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, condition_image_latents=cond, **kw, **gens()).frames
+        got = got.float().cpu()
+        t0 = time.time()
+        ref = OraclePipeline(ou)(pe, ne, cond, **kw, **gens()).frames
+        dt = time.time() - t0
+    d = got - ref
+    out = {"what": f"final latents after {n_steps} DDIM steps (CFG 7.5), {frames}f x {args.size}x{args.size}: HIP pipeline "
+                   "(hipGraph) vs the fp32 CPU oracle pipeline, same weights / seeds / condition latents",
+           "steps": n_steps, "max_abs_err": d.abs().max().item(), "rms_err": d.pow(2).mean().sqrt().item(),
+           "max_ref": ref.abs().max().item(), "rms_ref": ref.pow(2).mean().sqrt().item(),
+           "frame0_equals_condition": bool(torch.equal(got[:, 0], cond)), "oracle_seconds": dt, "oracle_threads": cores}
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def _profile_files(kind):
+    """profiles/r<N>_<kind>.json, newest round first."""
+    import re
+    out = []
+    for name in os.listdir(os.path.join(ROOT, "profiles")):
+        m = re.fullmatch(rf"r(\d+)_{kind}\.json", name)
+        if m:
+            out.append((int(m.group(1)), name))
+    return [n for _, n in sorted(out, reverse=True)]
+
+
 def run_windows(groups, steps, n_windows, n_tab, load_group, run_step, reset_step_index, sync, world, device):
     """The timed region, `n_windows` times: exactly `steps` steps for every group of this rank between barrier + sync on
     both sides, elapsed = MAX over ranks (an all-reduce of one double OUTSIDE the timed bracket).  Returns the list of
@@ -339,6 +395,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", default="", help="write the per-shape time table of the instrumented step here")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--latent-parity", type=int, default=0,
+                    help="N > 0: compare the final latents of N DDIM steps with the CPU oracle's pipeline and exit")
     ap.add_argument("--windows", type=int, default=5,
                     help="the K-step timed window is repeated this many times (each bracketed by barrier + synchronize); "
                          "the line reports the MEDIAN window, and min / max as `window_ms_per_step`")
@@ -388,6 +446,9 @@ def main():
     t_built = time.time()
     if args.train:
         return train_bench(args, model, ip, rank, world, dev)
+    if args.latent_parity > 0:
+        latent_parity(args, model, dev)
+        return 0
 
     # ---- this rank's samples (static block partition, no per-step collective)
     F, h_lat, B = args.frames, args.size // 8, args.batch
@@ -478,29 +539,35 @@ def main():
             # HBM-side bytes per launch of that class: PMC counters cannot be read from inside the process, so this is
             # the committed result of the separate rocprofv3 --pmc passes over this same command
             # (tools/pmc_traffic.sh -> profiles/r2_traffic.json), valid for the default workload only
-            tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
-            if os.path.exists(tpath) and (F, args.size, ip, B) == (16, 512, False, 1):
-                with open(tpath) as f:
-                    tj = json.load(f)
-                tcls = tj.get("classes", {})
-                if tj.get("source_stamp") != source_stamp():
-                    roof["traffic_source"] = (f"profiles/r3_traffic.json was measured on kernel sources "
-                                              f"{tj.get('source_stamp')}, this library is {source_stamp()}: not attached")
-                elif dom in tcls:
-                    roof["traffic"] = tcls[dom]["bytes_per_launch"]
-                    roof["traffic_source"] = ("profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                              "over this command, same kernel sources)")
-            # fractions of the ceilings MEASURED on this chip (tools/ceilings.hip -> profiles/r3_ceilings.json), next to
-            # the vendor peaks the `frac` above uses
-            cpath = os.path.join(ROOT, "profiles", "r3_ceilings.json")
-            if os.path.exists(cpath):
-                with open(cpath) as f:
+            # the NEWEST profiles/r*_traffic.json measured on exactly this library's kernel sources (a kernel edit
+            # invalidates older files instead of silently dropping `traffic`: the reason is reported)
+            if (F, args.size, ip, B) == (16, 512, False, 1):
+                tfile, seen = None, []
+                for name in _profile_files("traffic"):
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        tj = json.load(f)
+                    seen.append(f"{name}: {tj.get('source_stamp')}")
+                    if tj.get("source_stamp") == source_stamp() and dom in tj.get("classes", {}):
+                        tfile = (name, tj)
+                        break
+                if tfile is not None:
+                    roof["traffic"] = tfile[1]["classes"][dom]["bytes_per_launch"]
+                    roof["traffic_source"] = (f"profiles/{tfile[0]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                              "command, same kernel sources)")
+                else:
+                    roof["traffic_source"] = (f"no profiles/r*_traffic.json was measured on this library's kernel sources "
+                                              f"({source_stamp()}); found {seen}: not attached")
+            # fractions of the ceilings MEASURED on this chip (tools/ceilings.hip -> profiles/r*_ceilings.json, newest),
+            # next to the vendor peaks the `frac` above uses
+            for name in _profile_files("ceilings"):
+                with open(os.path.join(ROOT, "profiles", name)) as f:
                     cj = json.load(f)
                 pm = cj.get("mfma_f16_tflops") if roof["bound"] == "mfma" else cj.get("hbm_copy_gbps")
                 if pm:
                     roof["peak_measured"] = pm
                     roof["frac_of_measured"] = roof["achieved"] / pm
-                    roof["peak_measured_source"] = "profiles/r3_ceilings.json (MFMA-saturating loop / stream copy, this pool)"
+                    roof["peak_measured_source"] = f"profiles/{name} (MFMA-saturating loop / stream copy, this pool)"
+                    break
 
     used_graph = graph is not None
     graph = None

@@ -1057,7 +1057,11 @@ __global__ __launch_bounds__(256) void adamw_prepare_kernel(const float* __restr
     *norm_sq = total;
     // inf or NaN, tested on the BITS (exponent all ones): this library is built with -fno-honor-nans, under which the compiler
     // rewrites !(|x| <= c) as |x| > c -- false for NaN (the first form of this test let a NaN gradient through)
-    const bool bad = (__builtin_bit_cast(uint32_t, total) & 0x7f800000u) == 0x7f800000u;
+    // (and on bits the optimiser cannot trace back to a float: it recognises the mask-and-compare as an fpclass test and, told
+    //  that NaNs do not exist, narrows it to "is infinite" -- measured: inf caught, NaN let through)
+    uint32_t bits = __builtin_bit_cast(uint32_t, total);
+    asm volatile("" : "+v"(bits));
+    const bool bad = (bits & 0x7f800000u) == 0x7f800000u;
     *found_inf = bad ? 1 : 0;
     if (!bad) *applied_steps += 1;
   }

@@ -301,6 +301,53 @@ def test_config2_full_size_forward_vs_oracle(dev, pair):
     print(f"config 2 full size: HIP err {err:.3e} at max|ref| {scale:.3e}")
 
 
+# ------------------------------------------------------------------------------------------------ training step, SD-1.5 width
+def test_training_step_full_width_vs_autograd(dev, pair):
+    """SURVEY 8 f4 at the width `bench.py --train` times: `UNetAdapterTrainer` on the SD-1.5-width UNet
+    (channels 320 / 640 / 1280 / 1280, head_dim 40 / 80 / 160, 16 spatial transformers with the adapter) at a small clip
+    (2 f x 256 x 256: latents 32 x 32) against torch autograd over the fp32 oracle: the loss of
+    train_image_to_video.py:848-856 (MSE without the first frame) and the gradient of all 16 x 3 trainable adapter tensors
+    (unet:979-1026).  Tolerances as on the reduced UNet (tests/test_training_gpu.py): loss 5e-3 rel, gradients 2e-2 of
+    their largest entry."""
+    from i2v_adapter_unofficial_amd.training import UNetAdapterTrainer
+    ou, hu = pair
+    frames, lat = 2, 32
+    g = torch.Generator().manual_seed(606)
+    sample = h(torch.randn(1, frames, 4, lat, lat, generator=g))
+    ctx = h(torch.randn(1, 77, 768, generator=g))
+    target = h(torch.randn(1, frames, 4, lat, lat, generator=g))
+    t = torch.tensor([481])
+    for prm in ou.parameters():
+        prm.requires_grad_(False)
+    train = {n: prm for n, prm in ou.named_parameters() if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n}
+    assert len(train) == 16 * 3
+    for prm in train.values():
+        prm.requires_grad_(True)
+        prm.grad = None
+    try:
+        pred = ou(sample, t, True, ctx).sample
+        mask = torch.ones_like(pred)
+        mask[:, 0] = 0
+        loss = ((pred.float() - target) ** 2 * mask).sum() / mask.sum()
+        loss.backward()
+        tr = UNetAdapterTrainer(hu)
+        y = tr.forward(sample.half().to(dev), t.to(dev), ctx.half().to(dev))
+        got_pred = y[..., :4].float().cpu().permute(0, 3, 1, 2).reshape(pred.shape)
+        compare(got_pred, pred.detach(), abs_tol=FWD_ABS_TOL, name="training forward, SD-1.5 width")
+        got_loss, grads = tr.backward(target.to(dev), loss_scale=2.0 ** 12)
+        assert abs(got_loss.item() - loss.item()) <= 5e-3 * abs(loss.item()), (got_loss.item(), loss.item())
+        assert set(grads) == set(train)
+        worst = 0.0
+        for name, prm in train.items():
+            err, scale = compare(grads[name], prm.grad, rel=2e-2, name=f"SD-1.5-width training step: d loss / d {name}")
+            worst = max(worst, err / scale)
+        print(f"full-width training step: loss {got_loss.item():.6f} vs {loss.item():.6f}, worst gradient error {worst:.2e} of max")
+    finally:
+        for prm in train.values():
+            prm.requires_grad_(False)
+            prm.grad = None
+
+
 # ------------------------------------------------------------------------------------------------ config 4: B samples per call
 def _batch_inputs(nb, frames, lat, seed=40):
     g = torch.Generator().manual_seed(seed)
@@ -345,6 +392,30 @@ def test_config4_samples_per_replay_match_single_sample_runs(dev, pair_ip, nb):
         assert (both[others[0]] - both[i]).abs().max().item() > 0.1       # the samples really differ
     # eager launches of the same call: bit-identical to the graph
     eager = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, idx, frames, use_graph=False)
+    assert torch.equal(eager, both)
+
+
+def test_config4_full_size_two_samples_per_replay(dev, pair_ip):
+    """BASELINE configs[3] at its FULL clip size in the driver-run suite: two (image, prompt) pairs per
+    graph replay at 16 f x 512 x 512 with the IP-Adapter on (CFG batch 4 x 16 frames, 262144-row GEMMs: other tile forms,
+    split-K plans and GroupNorm forms than the single-sample step).  Each sample of the two-sample call must equal the
+    same sample run alone up to fp16 rounding noise (pipe:582-587, 613-622: no cross-sample op), frame 0 must be the
+    condition latents exactly (pipe:699-700), the replay must be reproducible and equal to eager launches."""
+    hu = pair_ip[1]
+    frames, lat = 16, 64
+    inp = _batch_inputs(2, frames, lat, seed=44)
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+    both = _pipe_call(pipe, inp, [0, 1], frames)
+    assert both.shape == (2, frames, 4, lat, lat) and torch.isfinite(both).all()
+    assert torch.equal(both[:, 0].cpu(), inp["cond"])
+    assert torch.equal(both, _pipe_call(pipe, inp, [0, 1], frames)), "a cached replay of the same samples must be bit-identical"
+    for i in (0, 1):
+        alone = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, [i], frames)
+        err, scale = compare(both[i: i + 1], alone, rel=3e-3, name=f"config 4 at 16f x 512^2: sample {i} of 2 per replay vs alone")
+        print(f"config 4 full size: sample {i} in a 2-sample replay vs alone: {err:.3e} at max {scale:.3e}")
+    assert (both[0] - both[1]).abs().max().item() > 0.1                    # the samples really differ
+    del pipe
+    eager = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, [0, 1], frames, use_graph=False)
     assert torch.equal(eager, both)
 
 
