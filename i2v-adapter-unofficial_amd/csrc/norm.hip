@@ -1,5 +1,7 @@
 // GroupNorm(+SiLU) and LayerNorm(+positional embedding) on token-major fp16, fp32 statistics.  HBM-bound:
 // 16-byte vector loads over the (frames x H x W) token axis, wavefront shuffles for the row reductions.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -29,9 +31,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // pass 1: per (image, row-chunk, channel) partial (mean, M2) over the chunk's rows.  Inside a chunk the sums run over
 // data SHIFTED by the channel's value in the chunk's first row (a sample of the same distribution, so the shifted
 // values are of the size of the spread, not of the mean): mean = K + S1 / n, M2 = S2 - S1^2 / n.
+// gpartial != NULL (C <= GN_MAXC): additionally the chunk's per-GROUP partial (mean, M2) over rows x channels-of-the-group
+// (Chan merge of the group's channels, equal counts), [img][chunk][group][2]: what gn_apply_fused_kernel finalises itself.
+constexpr int GN_MAXC = 2560, GN_MAXG = 64;
 __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
-                                                       int c2, int hw, int rpc, float* __restrict__ partial) {
+                                                       int c2, int hw, int rpc, float* __restrict__ partial,
+                                                       float* __restrict__ gpartial = nullptr, int groups = 0) {
   __shared__ float red[256 * 16];
+  __shared__ float chan[2 * GN_MAXC];
   const int C = c1 + c2, nvec = C / 8;
   const int chunk = blockIdx.x, img = blockIdx.y, nchunk = gridDim.x;
   const int row_begin = chunk * rpc;
@@ -105,11 +112,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
       float* dst = partial + (((int64_t)img * nchunk + chunk) * C + col * 8) * 2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        dst[2 * e] = kshift[e] + s[e] * inv_n;                  // mean of this (chunk, channel)
-        dst[2 * e + 1] = fmaxf(q[e] - s[e] * s[e] * inv_n, 0.f);   // M2
+        const float mean_c = kshift[e] + s[e] * inv_n, m2_c = fmaxf(q[e] - s[e] * s[e] * inv_n, 0.f);
+        dst[2 * e] = mean_c;                  // mean of this (chunk, channel)
+        dst[2 * e + 1] = m2_c;                // M2
+        if (gpartial != nullptr) {
+          chan[2 * (col * 8 + e)] = mean_c;
+          chan[2 * (col * 8 + e) + 1] = m2_c;
+        }
       }
     }
     __syncthreads();
+  }
+  if (gpartial != nullptr && tid < groups) {
+    const int cpg = C / groups;
+    const float n = (float)(row_end - row_begin);
+    float mg = 0.f;
+    for (int c = 0; c < cpg; ++c) mg += chan[2 * (tid * cpg + c)];
+    mg /= (float)cpg;
+    float m2 = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+      const float dm = chan[2 * (tid * cpg + c)] - mg;
+      m2 += chan[2 * (tid * cpg + c) + 1] + n * dm * dm;
+    }
+    float* dst = gpartial + (((int64_t)img * nchunk + chunk) * groups + tid) * 2;
+    dst[0] = mg;
+    dst[1] = m2;
   }
 }
 
@@ -166,6 +193,43 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// pass 2 from the per-GROUP partials of gn_stats_kernel (cpg times fewer, contiguous loads): the clip-wide statistics of the
+// motion modules' entry norms and the folded norms still finalise in a launch of their own.
+__global__ __launch_bounds__(256) void gn_finalize_g_kernel(const float* __restrict__ gpartial, int nchunk, int C, int groups,
+                                                            int fps, int hw, int rpc, float eps, const f16* __restrict__ gamma,
+                                                            const f16* __restrict__ beta, float* __restrict__ coef) {
+  __shared__ float red[4];
+  const int sg = blockIdx.x, grp = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C / groups;
+  const int total = fps * nchunk;
+  const float cnt = (float)fps * (float)hw;          // rows; every row contributes cpg values
+  const float2* gp = reinterpret_cast<const float2*>(gpartial) + (int64_t)sg * fps * nchunk * groups + grp;
+  float s = 0.f;
+  for (int i = lane; i < total; i += 256) {
+    const int ch = i % nchunk;
+    const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc);
+    s += n_i * gp[(int64_t)i * groups].x;
+  }
+  const float mean = block_sum_256(s, red) / cnt;
+  float m2 = 0.f;
+  for (int i = lane; i < total; i += 256) {
+    const int ch = i % nchunk;
+    const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc) * (float)cpg;
+    const float2 v = gp[(int64_t)i * groups];
+    const float dm = v.x - mean;
+    m2 += v.y + n_i * dm * dm;
+  }
+  const float var = block_sum_256(m2, red) / (cnt * (float)cpg);
+  const float rstd = rsqrtf(var + eps);
+  for (int i = lane; i < fps * cpg; i += 256) {
+    const int c = grp * cpg + i % cpg, f = i / cpg;
+    const float ga = (float)gamma[c] * rstd;
+    float* dst = coef + ((int64_t)(sg * fps + f) * C + c) * 2;
+    dst[0] = ga;
+    dst[1] = (float)beta[c] - mean * ga;
+  }
+}
+
 // pass 3: y = silu?(x * a + b), optional (b, f, p) -> (b, p, f) row permutation on store.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
                                                        int c2, const float* __restrict__ coef, f16* __restrict__ y,
@@ -201,6 +265,94 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
       orow = ((int64_t)b * hw + row) * frames + f;
     }
     *reinterpret_cast<f16x8*>(y + orow * C + col * 8) = o;
+  }
+}
+
+// passes 2 + 3 in one launch for per-image statistics (frames_per_stat == 1: the resnet norms and the spatial transformers'
+// entry norms that are not folded): one workgroup per (row chunk, image) finalises the image's statistics ITSELF from the
+// per-group partials of gn_stats_kernel -- nchunk x groups pairs, a few KB: staged through LDS, Chan-merged in a fixed order
+// by one thread per group, turned into this thread's per-channel (scale, shift) registers -- and applies them to its rows.
+// The separate finalize launch (1024 workgroups chasing 320 strided partials each through two block reductions: 8.2 us a
+// call, 52 calls and 0.43 ms per step, profiles/r3_kernel_stats.txt) and the coefficient round trip disappear.
+__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
+                                                             int c2, const float* __restrict__ gpartial, int groups,
+                                                             const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                             float eps, f16* __restrict__ y, int hw, int rpc, int silu) {
+  extern __shared__ float gsm[];                 // [nchunk * groups * 2] partials, then [groups * 2] (mean, rstd)
+  const int C = c1 + c2, nvec = C / 8, nv1 = c1 / 8;
+  const int chunk = blockIdx.x, img = blockIdx.y, nchunk = gridDim.x;
+  const int tid = threadIdx.x;
+  const int cpg = C / groups;
+  float* stat = gsm + nchunk * groups * 2;
+  for (int i = tid; i < nchunk * groups * 2; i += 256) gsm[i] = gpartial[(int64_t)img * nchunk * groups * 2 + i];
+  __syncthreads();
+  if (tid < groups) {
+    float sum = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc);
+      sum += n_i * gsm[(ch * groups + tid) * 2];
+    }
+    const float mean = sum / (float)hw;
+    float m2 = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc) * (float)cpg;
+      const float dm = gsm[(ch * groups + tid) * 2] - mean;
+      m2 += gsm[(ch * groups + tid) * 2 + 1] + n_i * dm * dm;
+    }
+    stat[2 * tid] = mean;
+    stat[2 * tid + 1] = rsqrtf(m2 / ((float)hw * (float)cpg) + eps);
+  }
+  __syncthreads();
+  const int row_begin = chunk * rpc, row_end = min(hw, row_begin + rpc);
+  const int cols_per_pass = nvec < 256 ? nvec : 256;
+  const int rows_par = 256 / cols_per_pass;
+  const int col_lane = tid % cols_per_pass, row_lane = tid / cols_per_pass;
+  if (row_lane >= rows_par) return;
+  for (int col0 = 0; col0 < nvec; col0 += cols_per_pass) {
+    const int col = col0 + col_lane;
+    if (col >= nvec) continue;
+    const f16x8 ga = ld_global_16B(gamma + col * 8), be = ld_global_16B(beta + col * 8);
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (col * 8 + e) / cpg;
+      a[e] = (float)ga[e] * stat[2 * g + 1];
+      b[e] = (float)be[e] - stat[2 * g] * a[e];
+    }
+    const f16* base;
+    int64_t ld;
+    int coff;
+    if (col < nv1) {
+      base = x1 + (int64_t)img * hw * c1;
+      ld = c1;
+      coff = col * 8;
+    } else {
+      base = x2 + (int64_t)img * hw * c2;
+      ld = c2;
+      coff = (col - nv1) * 8;
+    }
+    f16* yb = y + (int64_t)img * hw * C + col * 8;
+    auto one = [&](const f16x8 v, int r) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (float)v[e] * a[e] + b[e];
+        if (silu) t = silu_f(t);
+        o[e] = (f16)t;
+      }
+      *reinterpret_cast<f16x8*>(yb + (int64_t)r * C) = o;
+    };
+    int r = row_begin + row_lane;
+    for (; r + 3 * rows_par < row_end; r += 4 * rows_par) {     // four rows' loads in flight per thread
+      const f16* src = base + (int64_t)r * ld + coff;
+      const f16x8 v0 = ld_global_16B(src), v1 = ld_global_16B(src + (int64_t)rows_par * ld),
+                  v2 = ld_global_16B(src + 2 * (int64_t)rows_par * ld), v3 = ld_global_16B(src + 3 * (int64_t)rows_par * ld);
+      one(v0, r);
+      one(v1, r + rows_par);
+      one(v2, r + 2 * rows_par);
+      one(v3, r + 3 * rows_par);
+    }
+    for (; r < row_end; r += rows_par) one(ld_global_16B(base + (int64_t)r * ld + coff), r);
   }
 }
 
@@ -637,7 +789,9 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int64_t i2v_groupnorm_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels) {
   const int64_t nchunk = i2v_cdiv(hw, gn_rows_per_chunk(n_img, hw));
-  return ((int64_t)n_img * nchunk * channels * 2 + (int64_t)n_img * channels * 2) * (int64_t)sizeof(float);
+  // per-(image, chunk, channel) partials, per-(image, channel) coefficients, per-(image, chunk, group <= 64) partials
+  return ((int64_t)n_img * nchunk * channels * 2 + (int64_t)n_img * channels * 2 + (int64_t)n_img * nchunk * GN_MAXG * 2) *
+         (int64_t)sizeof(float);
 }
 
 extern "C" int i2v_groupnorm_fold_f16(const i2v_gn_params* pp, const void* w, int64_t ldw, const void* bias, int32_t n_out,
@@ -661,11 +815,20 @@ extern "C" int i2v_groupnorm_fold_f16(const i2v_gn_params* pp, const void* w, in
   const int nchunk = (int)i2v_cdiv(p.hw, rpc);
   float* partial = reinterpret_cast<float*>(p.workspace);
   float* coef = partial + (int64_t)p.n_img * nchunk * C * 2;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, reinterpret_cast<const f16*>(p.x), p.c1,
-                     reinterpret_cast<const f16*>(p.x2), p.c2, p.hw, rpc, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, partial, nchunk, C,
-                     p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
-                     reinterpret_cast<const f16*>(p.beta), coef);
+  if (p.groups <= GN_MAXG && C <= GN_MAXC) {
+    float* gpartial = coef + (int64_t)p.n_img * C * 2;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, reinterpret_cast<const f16*>(p.x), p.c1,
+                       reinterpret_cast<const f16*>(p.x2), p.c2, p.hw, rpc, partial, gpartial, p.groups);
+    hipLaunchKernelGGL(gn_finalize_g_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, gpartial, nchunk, C,
+                       p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
+                       reinterpret_cast<const f16*>(p.beta), coef);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, reinterpret_cast<const f16*>(p.x), p.c1,
+                       reinterpret_cast<const f16*>(p.x2), p.c2, p.hw, rpc, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, partial, nchunk, C,
+                       p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
+                       reinterpret_cast<const f16*>(p.beta), coef);
+  }
   hipLaunchKernelGGL(gn_fold_kernel, dim3(n_out, p.n_img / p.frames_per_stat), dim3(256), 0, s, coef, p.frames_per_stat, C,
                      reinterpret_cast<const f16*>(w), ldw, reinterpret_cast<const f16*>(bias), n_out,
                      reinterpret_cast<f16*>(w_out), reinterpret_cast<f16*>(bias_out));
@@ -711,10 +874,31 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   float* coef = partial + (int64_t)p.n_img * nchunk * C * 2;
   const f16* x1 = reinterpret_cast<const f16*>(p.x);
   const f16* x2 = reinterpret_cast<const f16*>(p.x2);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, partial, nchunk, C,
-                     p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
-                     reinterpret_cast<const f16*>(p.beta), coef);
+  // per-image statistics: two launches (statistics with per-group partials; finalise + apply), see gn_apply_fused_kernel
+  static const int fused_off = getenv("I2V_GN_FUSED") ? (atoi(getenv("I2V_GN_FUSED")) == 0) : 0;
+  const size_t fused_lds = ((size_t)nchunk * p.groups * 2 + (size_t)p.groups * 2) * sizeof(float);
+  if (!fused_off && p.frames_per_stat == 1 && !p.out_perm && p.groups <= GN_MAXG && C <= GN_MAXC && fused_lds <= 48 * 1024) {
+    float* gpartial = coef + (int64_t)p.n_img * C * 2;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial, gpartial,
+                       p.groups);
+    hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(nchunk, p.n_img), dim3(256), fused_lds, s, x1, p.c1, x2, p.c2, gpartial, p.groups,
+                       reinterpret_cast<const f16*>(p.gamma), reinterpret_cast<const f16*>(p.beta), p.eps,
+                       reinterpret_cast<f16*>(p.y), p.hw, rpc, p.silu);
+    return i2v_check_launch("i2v_groupnorm_f16(fused finalize)");
+  }
+  if (!fused_off && p.groups <= GN_MAXG && C <= GN_MAXC) {
+    float* gpartial = coef + (int64_t)p.n_img * C * 2;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial, gpartial,
+                       p.groups);
+    hipLaunchKernelGGL(gn_finalize_g_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, gpartial, nchunk, C,
+                       p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
+                       reinterpret_cast<const f16*>(p.beta), coef);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, partial, nchunk, C,
+                       p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
+                       reinterpret_cast<const f16*>(p.beta), coef);
+  }
   const int64_t total = (int64_t)p.n_img * p.hw * (C / 8);
   const int blocks = (int)(i2v_cdiv(total, 256) < 4096 ? i2v_cdiv(total, 256) : 4096);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, x1, p.c1, x2, p.c2, coef,

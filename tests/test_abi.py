@@ -69,8 +69,9 @@ def test_bad_arguments_return_error_codes_without_a_gpu(lib):
     p = lib.GemmParams()
     assert h.i2v_gemm_f16(C.byref(p), None) == -1
     assert h.i2v_attention_f16(None, None) == -1 and h.i2v_layernorm_f16(None, None) == -1
-    # 2 images x 300 pixels: 16-row chunks (19 of them) of per-channel (sum, sumsq) + per-(image, channel) (scale, shift)
-    assert h.i2v_groupnorm_workspace_bytes(2, 300, 64) == (2 * 19 * 64 * 2 + 2 * 64 * 2) * 4
+    # 2 images x 300 pixels: 16-row chunks (19 of them) of per-channel (mean, M2) + per-(image, channel) (scale, shift) +
+    # per-(image, chunk, group <= 64) (mean, M2)
+    assert h.i2v_groupnorm_workspace_bytes(2, 300, 64) == (2 * 19 * 64 * 2 + 2 * 64 * 2 + 2 * 19 * 64 * 2) * 4
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch):
