@@ -163,6 +163,7 @@ SIGNATURES = {
                                 C.c_float, _P, C.c_float, _P]),
     "i2v_adamw_guarded_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, _P, C.c_int32, _P, _P, _P, _P]),
+    "i2v_axpby_f32": (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int64, _P]),
     "i2v_select_row_f16": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
     "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, _P]),

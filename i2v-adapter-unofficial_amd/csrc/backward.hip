@@ -1337,6 +1337,20 @@ extern "C" int i2v_sumsq_f32(const float* x, int64_t n, float* out, i2v_stream_t
   return i2v_check_launch("i2v_sumsq_f32");
 }
 
+// y = a y + b x over a flat fp32 bucket: gradient accumulation (a = 1, b = 1 / accumulation steps) and the EMA of the trained
+// weights (a = decay, b = 1 - decay)
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float a, float b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a * y[i] + b * x[i];
+}
+
+extern "C" int i2v_axpby_f32(float* y, const float* x, float a, float b, int64_t n, i2v_stream_t stream) {
+  I2V_CHECK_ARG(y && x && n > 0, "i2v_axpby_f32: bad arguments");
+  const int64_t blk = i2v_cdiv(n, 256);
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)(blk < 4096 ? blk : 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x,
+                     a, b, n);
+  return i2v_check_launch("i2v_axpby_f32");
+}
+
 extern "C" int i2v_adamw_guarded_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                      float beta1, float beta2, float eps, float weight_decay, float grad_coef, float max_norm,
                                      float* partials, int32_t n_partials, float* norm_sq, int32_t* applied_steps,

@@ -41,17 +41,16 @@ __device__ __forceinline__ f32x4 mfma16x16x32(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// erf GELU: 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the fp16
-// output rounding): one v_rcp, one v_exp and five FMAs instead of libm erff's ~40 instructions in the GEMM epilogue.
-// Arranged as gelu(x) = max(x, 0) - |x| h(|x|) with h = 0.5 erfc(|x| / sqrt 2) = 0.5 poly(t) exp(-x^2 / 2): the
-// constants (1/sqrt 2 into p, 0.5 into the coefficients, log2 e / 2 into the exp2 argument) are folded, |x| and the
-// negations are free source modifiers, and there is no sign select: 11 plain VALU + rcp + exp2 per value (the GEGLU
-// epilogue of a K = 320 GEMM spends as long in this function as in its MFMAs).
-// -DI2V_GELU_POLY (A/B switch): transcendental-free form.  gelu(x) = max(x, 0) - f(min(|x|, 4.5)) with
-// f(t) = t (1 - Phi(t)) fitted by a degree-10 polynomial (weighted least squares iterated to near-minimax, /tmp-free:
-// tools/fit_gelu.py): max |error| 5.4e-5 over all x in fp32 Horner form -- 10 FMAs + min + max + sub against 11 VALU +
-// v_rcp + v_exp above.  A degree low enough to matter (<= 7) leaves > 5e-4, i.e. more than the fp16 rounding of the result.
-#ifdef I2V_GELU_POLY
+// erf GELU: 0.5 x (1 + erf(x / sqrt 2)), arranged as gelu(x) = max(x, 0) - f(|x|) with f(t) = t (1 - Phi(t)) (|x| and the
+// negations are free source modifiers, no sign select).  Two forms of f:
+//  * default since round 4: transcendental-free -- f(min(t, 4.5)) as a degree-10 polynomial (weighted
+//    least squares iterated to near-minimax, tools/fit_gelu.py), max |error| 5.4e-5 over all x in fp32 Horner form (below the
+//    fp16 rounding of any result above 0.06; f(t > 4.5) < 1.6e-5): 10 FMAs + min + max + sub.  A degree low enough to be
+//    much cheaper (<= 7) leaves > 5e-4.  Same-box A/B of the whole step: 51.49 -> 51.22 ms (profiles/r4_ab_runs.txt).
+//  * -DI2V_GELU_ERF: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): 0.5 erfc(t / sqrt 2) = 0.5 poly(1 / (1 + p t))
+//    exp(-t^2 / 2) with the constants folded -- 11 plain VALU + v_rcp + v_exp per value (a transcendental issues in 7.5
+//    cycles against 2 - 2.5 for an f32 FMA, tools/valu_rate.hip).
+#ifndef I2V_GELU_ERF
 __device__ __forceinline__ float gelu_erf(float x) {
   const float t = fminf(fabsf(x), 4.5f);
   float p = -1.249767080e-05f;

@@ -947,3 +947,14 @@ def adamw_guarded_step(param, grad, exp_avg, exp_avg_sq, *, lr, betas, eps, weig
                                          float(max_norm), _p(partials), partials.numel(), _p(norm_sq), _p(applied_steps),
                                          _p(found_inf), _stream()), "i2v_adamw_guarded_f32")
     return param
+
+
+def axpby(y, x, a, b):
+    """y = a y + b x in place over flat fp32 tensors (i2v_axpby_f32: gradient accumulation, EMA of the trained weights)."""
+    lib = _lib.load()
+    _req(y, "y", dtype=torch.float32)
+    _req(x, "x", dtype=torch.float32)
+    if not y.is_contiguous() or not x.is_contiguous() or y.numel() != x.numel():
+        raise ValueError("axpby: two contiguous fp32 tensors of equal size expected")
+    _lib.check(lib.i2v_axpby_f32(_p(y), _p(x), float(a), float(b), y.numel(), _stream()), "i2v_axpby_f32")
+    return y

@@ -582,8 +582,19 @@ class AdapterOptimizer:
     folded into the update's gradient coefficient), takes the global norm and applies the update with two kernels, then
     writes the fp16 parameters back.  No per-parameter launches, no host round trip for the clip coefficient."""
 
-    def __init__(self, unet, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, process_group=None):
+    def __init__(self, unet, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, process_group=None,
+                 gradient_accumulation_steps=1, use_ema=False, ema_decay=0.9999):
+        """gradient_accumulation_steps: `accelerator.accumulate` (train_image_to_video.py:486, 785) -- `step` adds each
+        micro-batch's gradients / N into the bucket and updates on every N-th call.  use_ema: an exponential moving average of
+        the TRAINED parameters in a fourth flat bucket (`--use_ema`, :673-677, 888-889; diffusers EMAModel's schedule: decay_t =
+        min(ema_decay, (1 + t) / (10 + t)) with t = updates - 1, 0 on the first).  (The reference builds its EMA over a
+        `UNet2DConditionModel`'s parameter list and steps it with the motion UNet's, :674-677 vs :889 -- lists that do not match;
+        the EMA here covers the parameters that train, read back with `ema_state_dict()`.)"""
         self.unet, self.group = unet, process_group
+        self.accum_steps, self._micro = int(gradient_accumulation_steps), 0
+        if self.accum_steps < 1:
+            raise ValueError("gradient_accumulation_steps must be >= 1")
+        self.use_ema, self.ema_decay, self.ema_updates = bool(use_ema), float(ema_decay), 0
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.names = [n for n, _ in unet.named_parameters()
                       if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n]                   # unet:1001-1006
@@ -604,6 +615,8 @@ class AdapterOptimizer:
         self.applied_steps = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.found_inf = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.step_count = 0            # steps requested (applied + skipped)
+        self._micro_grad = torch.zeros_like(self.master) if self.accum_steps > 1 else None
+        self.ema = self.master.clone() if self.use_ema else None
 
     def last_step_skipped(self) -> bool:
         """did the last `step` find inf / NaN gradients and leave everything unchanged?  (one host read; the trainer halves
@@ -623,9 +636,32 @@ class AdapterOptimizer:
             return dist.get_world_size(self.group)
         return 1
 
+    def ema_state_dict(self):
+        """{name: fp32 EMA tensor} of the trained parameters (what `ema_unet.copy_to(unet.parameters())` would load,
+        train_image_to_video.py:904-907, 946-947)."""
+        if self.ema is None:
+            raise ValueError("use_ema=False")
+        return {n: self.ema[off: off + cnt].view_as(prm).clone() for n, prm, (off, cnt) in
+                ((n, prm, self.offsets[n]) for n, prm in zip(self.names, self.params))}
+
     @torch.no_grad()
     def step(self, grads):
-        self.fill_gradients(grads)
+        """one micro-batch's gradients.  Returns True when an optimiser step was taken (accelerate's `sync_gradients`), False
+        when the gradients were only accumulated."""
+        if self.accum_steps > 1:
+            # accumulate(): the N micro-batch losses are averaged, i.e. every gradient enters with weight 1 / N
+            bucket, self.grad = self.grad, self._micro_grad
+            self.fill_gradients(grads)
+            self.grad = bucket
+            if self._micro == 0:
+                self.grad.zero_()
+            K.axpby(self.grad, self._micro_grad, 1.0, 1.0 / self.accum_steps)
+            self._micro += 1
+            if self._micro < self.accum_steps:
+                return False
+            self._micro = 0
+        else:
+            self.fill_gradients(grads)
         world = self.reduce_gradients()
         self.step_count += 1
         # one call: fixed-order gradient norm (identical on every rank: the clip coefficients cannot drift apart), overflow
@@ -638,3 +674,10 @@ class AdapterOptimizer:
         for n, prm in zip(self.names, self.params):
             off, cnt = self.offsets[n]
             prm.copy_(self.master[off: off + cnt].view_as(prm))   # (on the parameter itself: its version counter moves)
+        if self.use_ema:
+            # (a step skipped for inf / NaN gradients leaves the masters as they were: the EMA then averages the same value)
+            self.ema_updates += 1
+            t = max(0, self.ema_updates - 1)
+            decay = 0.0 if t <= 0 else min(self.ema_decay, (1.0 + t) / (10.0 + t))
+            K.axpby(self.ema, self.master, decay, 1.0 - decay)
+        return True

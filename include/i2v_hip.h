@@ -442,6 +442,11 @@ int i2v_adamw_guarded_f32(float* param, const float* grad, float* exp_avg, float
                           float* partials, int32_t n_partials, float* norm_sq, int32_t* applied_steps, int32_t* found_inf,
                           i2v_stream_t stream);
 
+/* y = a y + b x over n fp32 values: gradient accumulation over micro-batches (`accelerator.accumulate`,
+ * train_image_to_video.py:486, 785: a = 1, b = 1 / gradient_accumulation_steps) and the exponential moving average of the
+ * trained weights (`--use_ema`, :673-677, 888-889: a = decay, b = 1 - decay). */
+int i2v_axpby_f32(float* y, const float* x, float a, float b, int64_t n, i2v_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

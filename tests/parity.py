@@ -4,12 +4,13 @@ weights, seeded synthetic inputs, the comparison helper with the sta
 
 Tolerance of the fp16 path (stated once, used everywhere): the HIP path stores activations in fp16 (eps = 9.8e-4)
 and accumulates / normalises in fp32; against the fp32 CPU oracle run on the SAME fp16-rounded weights and inputs
-an output must satisfy   max|hip - oracle| <= REL_TOL * max|oracle|.  The bounds are <= 3x the errors MEASURED on
-MI355X in round 2 (profiles/r2_parity_errors.jsonl: every compare() of the GPU suite):
+an output must satisfy   max|hip - oracle| <= REL_TOL * max|oracle|.  The bounds were <= 3x the errors MEASURED on
+MI355X in round 2 (profiles/r2_parity_errors.jsonl: every compare() of the GPU suite) and are <= ~2x since round 4
+(profiles/r4_parity_errors.jsonl; the results are deterministic for a given binary):
   single modules (transformer block / T2D / motion module / resnet / down block): measured 3.8e-4 .. 1.02e-3
-      -> REL_TOL_MODULE = 3e-3   (the lower end is the rounding of the fp16 output alone: eps / 2 = 4.9e-4)
-  whole UNet forward (reduced and SD-1.5 width): measured 1.1e-3 .. 1.7e-3 -> REL_TOL_UNET = 4.5e-3
-  9-step CFG DDIM trajectory: measured 1.6e-3 of max|latent| -> REL_TOL_TRAJECTORY = 5e-3
+      -> REL_TOL_MODULE = 2e-3   (the lower end is the rounding of the fp16 output alone: eps / 2 = 4.9e-4)
+  whole UNet forward (reduced and SD-1.5 width): measured 1.0e-3 .. 1.3e-3 of max -> REL_TOL_UNET = 3e-3
+  9-step CFG DDIM trajectory: measured 1.6e-3 of max|latent| -> REL_TOL_TRAJECTORY = 3.3e-3
   single kernels: 3e-3 (tests/test_kernels_gpu.py).
 The reference's own fp16 GPU path, emulated by oracle/fp16_emulation.py, measures 1.6e-3 .. 1.9e-3 on the same UNet
 forwards: the HIP path must not exceed it by more than 25 % (tests/test_full_width_gpu.py).
@@ -23,9 +24,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-REL_TOL_MODULE = 3e-3
-REL_TOL_UNET = 4.5e-3
-REL_TOL_TRAJECTORY = 5e-3
+# (r4: every bound <= ~2x the error measured on MI355X, profiles/r4_parity_errors.jsonl)
+REL_TOL_MODULE = 2e-3
+REL_TOL_UNET = 3e-3
+REL_TOL_TRAJECTORY = 3.3e-3
 # SD-1.5 + AnimateDiff motion adapter + I2V-Adapter topology (unet:703-726 defaults with cross_attention_dim = 768):
 # the model bench.py times (BASELINE configs[1..4])
 SD15 = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),

@@ -25,8 +25,9 @@ pytestmark = pytest.mark.gpu
 
 # asserted bounds: max-abs error of one full-width CFG forward against the fp32 oracle (max|ref| ~ 1.3), and the factor
 # by which the HIP error may exceed the fp16-emulated reference's own error
-FWD_ABS_TOL = 6.0e-3
-MODULE_REL_TOL = 2.0e-3
+# (r4: <= 2x the measured errors -- forwards 1.9e-3 .. 2.14e-3, modules <= 6.5e-4 of max; profiles/r4_parity_errors.jsonl)
+FWD_ABS_TOL = 4.2e-3
+MODULE_REL_TOL = 1.4e-3
 
 
 def pkg():
@@ -185,7 +186,7 @@ def test_full_width_sharp_attention(dev, kind, c, hw, frames, gain):
                     return_dict=False)[0]
         else:
             ref, got = o(x, num_frames=frames)[0], m(x.half().to(dev), num_frames=frames)[0]
-    compare(got, ref, rel=MODULE_REL_TOL * gain, name=f"sharp attention {kind} C={c} gain={gain}")
+    compare(got, ref, rel=3.5e-4 * gain, name=f"sharp attention {kind} C={c} gain={gain}")
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(320, 320, 64), (960, 320, 32), (2560, 1280, 8), (1280, 1280, 16)])
@@ -297,7 +298,7 @@ def test_config2_full_size_forward_vs_oracle(dev, pair):
     with torch.no_grad():
         got = hu(inp["sample"].to(dev), inp["t"].to(dev), True, inp["ctx"].to(dev)).sample
     assert got.shape == (2, 16, 4, 64, 64)
-    err, scale = compare(got, ref, abs_tol=FWD_ABS_TOL * 1.5, name="config 2 full-size UNet forward (16f x 512^2)")
+    err, scale = compare(got, ref, abs_tol=4.0e-3, name="config 2 full-size UNet forward (16f x 512^2)")
     print(f"config 2 full size: HIP err {err:.3e} at max|ref| {scale:.3e}")
 
 
@@ -308,7 +309,7 @@ def test_training_step_full_width_vs_autograd(dev, pair):
     (2 f x 256 x 256: latents 32 x 32) against torch autograd over the fp32 oracle: the loss of
     train_image_to_video.py:848-856 (MSE without the first frame) and the gradient of all 16 x 3 trainable adapter tensors
     (unet:979-1026).  Tolerances as on the reduced UNet (tests/test_training_gpu.py): loss 5e-3 rel, gradients 2e-2 of
-    their largest entry."""
+    their largest entry (measured: <= 1.7e-3; asserted 4e-3)."""
     from i2v_adapter_unofficial_amd.training import UNetAdapterTrainer
     ou, hu = pair
     frames, lat = 2, 32
@@ -339,7 +340,7 @@ def test_training_step_full_width_vs_autograd(dev, pair):
         assert set(grads) == set(train)
         worst = 0.0
         for name, prm in train.items():
-            err, scale = compare(grads[name], prm.grad, rel=2e-2, name=f"SD-1.5-width training step: d loss / d {name}")
+            err, scale = compare(grads[name], prm.grad, rel=4e-3, name=f"SD-1.5-width training step: d loss / d {name}")
             worst = max(worst, err / scale)
         print(f"full-width training step: loss {got_loss.item():.6f} vs {loss.item():.6f}, worst gradient error {worst:.2e} of max")
     finally:
@@ -386,8 +387,8 @@ def test_config4_samples_per_replay_match_single_sample_runs(dev, pair_ip, nb):
     assert torch.equal(both, again), "a cached graph replay of the same samples must be bit-identical"
     for i in idx:
         alone = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, [i], frames)
-        # measured 8.3e-4 .. 9.8e-4 of max (two trajectories of independent fp16 rounding noise), bound 3x
-        compare(both[i: i + 1], alone, rel=3e-3, name=f"config 4: sample {i} of {nb} per call vs alone")
+        # measured 8.3e-4 .. 9.8e-4 of max (two trajectories of independent fp16 rounding noise), bound 2x
+        compare(both[i: i + 1], alone, rel=2e-3, name=f"config 4: sample {i} of {nb} per call vs alone")
         others = [j for j in idx if j != i]
         assert (both[others[0]] - both[i]).abs().max().item() > 0.1       # the samples really differ
     # eager launches of the same call: bit-identical to the graph
@@ -411,7 +412,7 @@ def test_config4_full_size_two_samples_per_replay(dev, pair_ip):
     assert torch.equal(both, _pipe_call(pipe, inp, [0, 1], frames)), "a cached replay of the same samples must be bit-identical"
     for i in (0, 1):
         alone = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, [i], frames)
-        err, scale = compare(both[i: i + 1], alone, rel=3e-3, name=f"config 4 at 16f x 512^2: sample {i} of 2 per replay vs alone")
+        err, scale = compare(both[i: i + 1], alone, rel=2e-3, name=f"config 4 at 16f x 512^2: sample {i} of 2 per replay vs alone")
         print(f"config 4 full size: sample {i} in a 2-sample replay vs alone: {err:.3e} at max {scale:.3e}")
     assert (both[0] - both[1]).abs().max().item() > 0.1                    # the samples really differ
     del pipe

@@ -4,7 +4,7 @@ parameters (unet:979-1026: i2v_adapter.to_q / to_out) and the gradient it passes
 reference's loss (train_image_to_video.py:848-856: MSE without the first frame of each clip).
 
 Kernel-level cases first (attention backward incl. the kv_group reduction of dK0 / dV0, LayerNorm / GEGLU backward, the
-transposes and sums), then the block.  Tolerance: 5e-3 of the largest reference gradient entry (fp16 operands, fp32
+transposes and sums), then the block.  Tolerance: 2.5e-3 (r4: 2x the measured) of the largest reference gradient entry (fp16 operands, fp32
 accumulation; the P / dS operands of the attention backward are fp16 like the forward's P)."""
 import pytest
 import torch
@@ -12,7 +12,7 @@ import torch
 from tests.parity import compare, randomize_adapter_out_, round_fp16_
 
 pytestmark = pytest.mark.gpu
-GRAD_REL_TOL = 5.0e-3
+GRAD_REL_TOL = 2.5e-3     # measured 2.5e-4 .. 1.2e-3 of the largest reference gradient entry
 
 
 def pkg():
@@ -441,7 +441,7 @@ def test_unet_training_step_vs_autograd(dev, ip):
     assert set(grads) == set(train)
     worst = 0.0
     for name, prm in train.items():
-        err, scale = compare(grads[name], prm.grad, rel=2e-2, name=f"UNet step: d loss / d {name}")
+        err, scale = compare(grads[name], prm.grad, rel=1.2e-2, name=f"UNet step: d loss / d {name}")
         worst = max(worst, err / scale)
     print(f"UNet training step: loss {got_loss.item():.6f} vs {loss.item():.6f}, worst gradient error {worst:.2e} of max")
 
@@ -579,3 +579,47 @@ def test_training_steps_do_not_grow_memory(dev):
     assert len(set(sizes[2:])) == 1, f"operand memo keeps growing: {sizes}"
     assert len(set(mem[2:])) == 1, f"allocated bytes keep growing: {mem}"
     assert all(l == l for l in losses) and losses[-1] != losses[0], "the steps must actually move the weights"
+
+
+def test_gradient_accumulation_and_ema(dev):
+    """`accelerator.accumulate` (train_image_to_video.py:486, 785) and `--use_ema` (:673-677, 888-889) on the flat buckets: N
+    micro-batches accumulate into one update that equals torch's step on the MEAN gradient; the EMA follows diffusers
+    EMAModel's schedule decay_t = min(decay, (1 + t) / (10 + t)), t = updates - 1 (0 on the first update)."""
+    from i2v_adapter_unofficial_amd.training import AdapterOptimizer
+    p = pkg()
+    m = p.I2VAdapterTransformerBlock(64, 4, 16, cross_attention_dim=32)
+
+    class Holder(torch.nn.Module):
+        def __init__(self, blk):
+            super().__init__()
+            self.encoder_hid_proj = None
+            self.blocks = torch.nn.ModuleList([blk])
+    hold = Holder(m).to(dev).half()
+    ref_params = [torch.nn.Parameter(prm.detach().float().cpu().clone()) for n, prm in hold.named_parameters()
+                  if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n]
+    ref_opt = torch.optim.AdamW(ref_params, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    opt = AdapterOptimizer(hold, lr=1e-3, max_grad_norm=1.0, gradient_accumulation_steps=3, use_ema=True, ema_decay=0.95)
+    ema_ref = [prm.detach().clone() for prm in ref_params]
+    g = torch.Generator().manual_seed(9)
+    updates = 0
+    for it in range(12):
+        grads = {n: torch.randn(prm.shape, generator=g) * 0.05 for n, prm in zip(opt.names, ref_params)}
+        for prm, n in zip(ref_params, opt.names):
+            prm.grad = grads[n] / 3 if prm.grad is None else prm.grad + grads[n] / 3
+        stepped = opt.step({n: v.to(dev) for n, v in grads.items()})
+        assert stepped == (it % 3 == 2)
+        if stepped:
+            torch.nn.utils.clip_grad_norm_(ref_params, 1.0)
+            ref_opt.step()
+            ref_opt.zero_grad(set_to_none=True)
+            updates += 1
+            t = max(0, updates - 1)
+            d = 0.0 if t <= 0 else min(0.95, (1.0 + t) / (10.0 + t))
+            for e, prm in zip(ema_ref, ref_params):
+                e.mul_(d).add_(prm.detach(), alpha=1.0 - d)
+    assert updates == 4 and opt.applied_steps.item() == 4
+    ema = opt.ema_state_dict()
+    for n, prm, e in zip(opt.names, ref_params, ema_ref):
+        off, cnt = opt.offsets[n]
+        compare(opt.master[off: off + cnt].view_as(prm), prm, rel=1e-5, name=f"accumulated AdamW master {n}")
+        compare(ema[n], e, rel=1e-5, name=f"EMA {n}")
