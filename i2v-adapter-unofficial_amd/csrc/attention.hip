@@ -71,6 +71,7 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
   constexpr int NS2 = KVT / 32;        // k-steps of the PV product
   constexpr int KCH = DQK / 8;         // 16-byte chunks per K row
   constexpr int VCH = KVT / 8;         // 16-byte chunks per V^T row
+  static_assert((KVT * KCH) % 256 == 0, "the K tile must be whole 16-byte chunks per thread");
   constexpr int NKC = (KVT * KCH) / 256;                // K chunks per thread
   constexpr int NVC = (DPV * VCH + 255) / 256;          // V^T chunks per thread (last pass may be partial)
   __shared__ __attribute__((aligned(16))) f16 sKb[2][KVT * KS];   // two stages: one barrier per key tile
@@ -407,9 +408,23 @@ int launch_q(const i2v_attn_params& p, hipStream_t s) {
   static const int kvt_env = getenv("I2V_ATTN_KVT") ? atoi(getenv("I2V_ATTN_KVT")) : 0;
   if (qt_env == 1 || qt_env == 2) qt = qt_env;
   int kvt = 64;   // 128-key tiles (half the barriers per key) measured 2-4 % slower: the loop is VALU-bound, not sync-bound
-  if (kvt_env == 64 || (kvt_env == 128 && DQK <= 64)) kvt = kvt_env;
+  // the 77 text tokens (+ padding) fit ONE 96-key tile: a single trip through the key loop -- no second barrier round trip --
+  // and 42 MFMAs / 24 exponentials per 32 queries instead of the 56 / 32 of two 64-key tiles (these launches are 8192
+  // workgroups of almost nothing but prologue: 99.6 us at 64 x 64 for 168 MB of Q + O)
+  // (head_dim 40 .. 64 only: 96 keys x DQK / 8 chunks must be a multiple of the 256 threads)
+  if (DQK == 64 && p.lk > 64 && p.lk <= 96) kvt = 96;
+  if (kvt_env == 64 || (kvt_env == 128 && DQK <= 64) || (kvt_env == 96 && DQK == 64)) kvt = kvt_env;
   const dim3 block(256);
   const dim3 grid((unsigned)i2v_cdiv(p.lq, 64 * qt), (unsigned)p.heads, (unsigned)p.batch_q);
+  if constexpr (DQK == 64) {
+    if (kvt == 96) {
+      if (qt == 2)
+        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, 96, SPARE>), grid, block, 0, s, p, scale_log2);
+      else
+        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, 96, SPARE>), grid, block, 0, s, p, scale_log2);
+      return i2v_check_launch("i2v_attention_f16");
+    }
+  }
   if constexpr (DQK <= 64) {
     if (kvt == 128) {
       if (qt == 2)

@@ -422,6 +422,14 @@ def _variants_env(**switches):
     lib = os.path.join(root, ".ab_libs", "variants.so")
     if not os.path.exists(lib):
         pytest.skip("variant kernels are not in the default build: bash tools/build_variant.sh --variants")
+    # a variants library built before the last ABI change (it is not rebuilt by __graft_entry__.build()) is stale, not wrong
+    import ctypes
+    import i2v_adapter_unofficial_amd as pkg
+    handle = ctypes.CDLL(lib)
+    missing = [n for n in pkg._lib.SIGNATURES if not hasattr(handle, n)]
+    if missing or handle.i2v_abi_version() != pkg._lib.ABI_VERSION:
+        pytest.skip(f".ab_libs/variants.so is older than include/i2v_hip.h (missing {missing[:3]}): rebuild it with "
+                    "bash tools/build_variant.sh --variants")
     return dict(os.environ, I2V_LIB_PATH=lib, **switches)
 
 
