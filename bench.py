@@ -139,7 +139,10 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev, n_forwards=3):
                        f"{h_lat * 8}x{h_lat * 8}: {dt:.1f} s ({', '.join(f'{v:.1f}' for v in times)}) on {cores} threads of a "
                        f"{os.cpu_count()}-thread host (torch {torch.__version__}); a step is that forward plus "
                        "negligible elementwise work")}
+    # the maximum over 524 288 outputs is an extreme-value statistic: equivalent rounding patterns (e.g. another GELU form)
+    # move it by +- 15 % (1.9 .. 2.3e-3) while the RMS stays put -- both are reported
     parity = {"max_abs_err": err, "max_abs_ref": scale, "rel": err / max(scale, 1e-30),
+              "rms_err": (got - ref).pow(2).mean().sqrt().item(), "rms_ref": ref.pow(2).mean().sqrt().item(),
               "what": ("HIP UNet forward of the CFG batch [latents ; latents] x [negative ; positive prompt], routed as the "
                        "timed step routes it, vs the fp32 CPU oracle forward timed above (same weights, same inputs)")}
     return base, parity
