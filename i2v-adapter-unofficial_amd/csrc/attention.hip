@@ -59,10 +59,16 @@ __device__ __forceinline__ uint32_t pack_rn(float a, float b) {
 #ifndef I2V_ATTN_XCD_REMAP
 #define I2V_ATTN_XCD_REMAP 1
 #endif
-template <int DQK, int DPV, int QT, int KVT, bool SPARE>
+// WALK (single-key-tile problems only: the 77 text tokens): the workgroup stages K / V^T ONCE and walks `qbw` consecutive
+// 64 QT-query blocks.  Those launches were 8192 workgroups of 42 MFMAs each behind ~800 VALU instructions of set-up per wave
+// (descriptors, staging offsets, the tail mask, 64-bit addresses: 19.6 VALU per MFMA, a VALU-bound kernel,
+// profiles/r4_pmc_summary.txt); the set-up is now paid once per qbw blocks.  A template parameter: the long-sequence kernels
+// keep their single trip (and their register allocation).
+template <int DQK, int DPV, int QT, int KVT, bool SPARE, bool WALK = false>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(DQK == 64 && DPV == 48 && QT == 2 && KVT == 64 ? 4 : 1)))
-void attn_kernel(const i2v_attn_params p, const float scale_log2) {
+__attribute__((amdgpu_waves_per_eu(DQK == 64 && DPV == 48 && QT == 2 && KVT == 64 && !WALK ? 4 : 1)))
+void attn_kernel(const i2v_attn_params p, const float scale_log2, const int qbw_arg) {
+  const int qbw = WALK ? qbw_arg : 1;
   constexpr int KS = DQK + 8;          // K LDS row stride (halfs)
   constexpr int VS = KVT + 8;          // V^T LDS row stride (halfs)
   constexpr int KSTEPS = DQK / 32;     // k-steps of the QK^T product
@@ -74,8 +80,10 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
   static_assert((KVT * KCH) % 256 == 0, "the K tile must be whole 16-byte chunks per thread");
   constexpr int NKC = (KVT * KCH) / 256;                // K chunks per thread
   constexpr int NVC = (DPV * VCH + 255) / 256;          // V^T chunks per thread (last pass may be partial)
-  __shared__ __attribute__((aligned(16))) f16 sKb[2][KVT * KS];   // two stages: one barrier per key tile
-  __shared__ __attribute__((aligned(16))) f16 sVb[2][DPV * VS];
+  // two stages: one barrier per key tile (WALK: the one tile there is needs one stage)
+  constexpr int NSTG = WALK ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) f16 sKb[NSTG][KVT * KS];
+  __shared__ __attribute__((aligned(16))) f16 sVb[NSTG][DPV * VS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
@@ -107,7 +115,8 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
   }
   const int bkv = bq / p.kv_group;
   const int d = p.head_dim, lq = p.lq, lk = p.lk;
-  const int q0 = qb * (64 * QT) + wave * (16 * QT);
+  const int qb_first = qb * qbw;
+  int q0 = qb_first * (64 * QT) + wave * (16 * QT);     // first query row of this wave in the current block
 
   const f16* __restrict__ Q = reinterpret_cast<const f16*>(p.q) + (int64_t)bq * p.q_batch_stride + h * d;
   const f16* __restrict__ Kg = reinterpret_cast<const f16*>(p.k) + (int64_t)bkv * p.k_batch_stride + h * d;
@@ -118,35 +127,48 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
   // (loading them BEHIND the first K / V^T tile's loads -- one round trip instead of two -- measured nothing on the 77-token
   //  text attention, 85 vs 86 us, and cost the d = 40 kernel 6 more spilled registers)
   f16x8 qf[QT][KSTEPS];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int row = q0 + qt * 16 + l15;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      const int dd = 32 * s + 8 * g;
-      f16x8 v = zero8();
-      if (row < lq && dd < d) v = ld_global_16B(Q + (int64_t)row * p.q_row_stride + dd);
-      // fold scale * log2(e) into Q once, so that the QK^T accumulator already holds base-2 logits
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * scale_log2);
-      qf[qt][s] = v;
-    }
-  }
-
   f32x4 o[DT][QT];
-#pragma unroll
-  for (int i = 0; i < DT; ++i)
-#pragma unroll
-    for (int j = 0; j < QT; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // negm[j] = -(running max of query column j) in all four registers: it is the INITIAL ACCUMULATOR of the QK^T MFMA
   // chain, so the chain ends with s - m and the softmax needs neither a multiply nor a subtraction per score
   f32x4 negm[QT];
   float lrow[QT];
+  // WALK: the NEXT block's rows are requested (raw, qraw) before this block is computed, so their round trip runs under
+  // its MFMAs, softmax and stores instead of in front of the next block (one block per ~7 us and workgroup without it)
+  f16x8 qraw[QT][KSTEPS];
+  auto fetch_q = [&](int q0f) {
 #pragma unroll
-  for (int j = 0; j < QT; ++j) {
-    negm[j] = f32x4{0.f, 0.f, 0.f, 0.f};   // finite: the first tile always takes the rescale path (sets the true max)
-    lrow[j] = 0.f;
-  }
+    for (int qt = 0; qt < QT; ++qt) {
+      const int row = q0f + qt * 16 + l15;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int dd = 32 * s + 8 * g;
+        qraw[qt][s] = (row < lq && dd < d) ? ld_global_16B(Q + (int64_t)row * p.q_row_stride + dd) : zero8();
+      }
+    }
+  };
+  auto load_q = [&]() {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        f16x8 v = qraw[qt][s];
+        // fold scale * log2(e) into Q once, so that the QK^T accumulator already holds base-2 logits
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * scale_log2);
+        qf[qt][s] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < QT; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      negm[j] = f32x4{0.f, 0.f, 0.f, 0.f};   // finite: the first tile always takes the rescale path (sets the true max)
+      lrow[j] = 0.f;
+    }
+  };
+  fetch_q(q0);
 
   // ---- K / V^T staging: everything that does not depend on the tile index is hoisted (per-thread source pointers,
   //      LDS offsets, validity of the chunk inside head_dim); registers of chunks outside head_dim stay 0 (or 1.0
@@ -180,7 +202,7 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
     const bool real = row < DPV && !(SPARE && row == d);
     v_lds[i] = real ? row * VS + 8 * c : (tid % DPV) * VS + KVT;
   }
-  if (SPARE && tid < 2 * VCH) {   // masked keys carry P = 0, so 1.0 for every key is right
+  if (SPARE && tid < NSTG * VCH) {   // masked keys carry P = 0, so 1.0 for every key is right
     f16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
@@ -344,56 +366,66 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2) {
     }
   };
 
-  for (int t = 0; t + 1 < ntiles; ++t) process(std::false_type{}, std::true_type{}, t);
-  if (partial)
-    process(std::true_type{}, std::false_type{}, ntiles - 1);
-  else
-    process(std::false_type{}, std::false_type{}, ntiles - 1);
-
-  // ---- normalise and store: lane holds O[query l15][d = 16 i + 4 g + r]
-  f16* __restrict__ O = reinterpret_cast<f16*>(p.o) + (int64_t)bq * p.o_batch_stride + h * d;
-#pragma unroll
-  for (int j = 0; j < QT; ++j) {
-    float lt;
-    if (SPARE) {
-      // the sum sits in O^T row d: tile d >> 4, lane group (d & 15) >> 2, register d & 3
-      float cand = 0.f;
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (i == (d >> 4) && r == (d & 3)) cand = o[i][j][r];
-      lt = __shfl(cand, (((d & 15) >> 2) << 4) | l15, 64);
-    } else {
-      lt = lrow[j];
-      lt += __shfl_xor(lt, 16, 64);
-      lt += __shfl_xor(lt, 32, 64);
+  for (int qi = 0; qi < qbw; ++qi) {
+    if (WALK) {
+      if ((qb_first + qi) * (64 * QT) >= lq) break;      // workgroup-uniform
+      q0 = (qb_first + qi) * (64 * QT) + wave * (16 * QT);
     }
-    const float inv = 1.0f / lt;
-    const int row = q0 + j * 16 + l15;
-    if (row >= lq) continue;
-    // training forward: log2-sum-exp of the row = running reference + log2(sum of P against it) (v_log_f32 is log2); the four
-    // lane groups of a query hold the same reference, lane group 0 writes
-    if (p.lse != nullptr && g == 0)
-      p.lse[((int64_t)bq * p.heads + h) * lq + row] = __builtin_amdgcn_logf(lt) - negm[j][0];
+    load_q();
+    if (WALK && qi + 1 < qbw) fetch_q(q0 + 64 * QT);     // (rows >= lq: zeros, never used)
+    for (int t = 0; t + 1 < ntiles; ++t) process(std::false_type{}, std::true_type{}, t);
+    if (partial)
+      process(std::true_type{}, std::false_type{}, ntiles - 1);
+    else
+      process(std::false_type{}, std::false_type{}, ntiles - 1);
+
+    // ---- normalise and store: lane holds O[query l15][d = 16 i + 4 g + r]
+    f16* __restrict__ O = reinterpret_cast<f16*>(p.o) + (int64_t)bq * p.o_batch_stride + h * d;
 #pragma unroll
-    for (int i = 0; i < DT; ++i) {
-      const int dd = i * 16 + 4 * g;
-      if (dd >= d) continue;
-      f16* dst = O + (int64_t)row * p.o_row_stride + dd;
-      f16x4 ov;
-      if (p.accumulate) {
-        const f16x4 prev = *reinterpret_cast<const f16x4*>(dst);
+    for (int j = 0; j < QT; ++j) {
+      float lt;
+      if (SPARE) {
+        // the sum sits in O^T row d: tile d >> 4, lane group (d & 15) >> 2, register d & 3
+        float cand = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (f16)((float)prev[r] + p.acc_scale * o[i][j][r] * inv);
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (i == (d >> 4) && r == (d & 3)) cand = o[i][j][r];
+        lt = __shfl(cand, (((d & 15) >> 2) << 4) | l15, 64);
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[i][j][r] * inv);
+        lt = lrow[j];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
       }
-      *reinterpret_cast<f16x4*>(dst) = ov;
+      const float inv = 1.0f / lt;
+      const int row = q0 + j * 16 + l15;
+      if (row >= lq) continue;
+      // training forward: log2-sum-exp of the row = running reference + log2(sum of P against it) (v_log_f32 is log2); the four
+      // lane groups of a query hold the same reference, lane group 0 writes
+      if (p.lse != nullptr && g == 0)
+        p.lse[((int64_t)bq * p.heads + h) * lq + row] = __builtin_amdgcn_logf(lt) - negm[j][0];
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const int dd = i * 16 + 4 * g;
+        if (dd >= d) continue;
+        f16* dst = O + (int64_t)row * p.o_row_stride + dd;
+        f16x4 ov;
+        if (p.accumulate) {
+          const f16x4 prev = *reinterpret_cast<const f16x4*>(dst);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = (f16)((float)prev[r] + p.acc_scale * o[i][j][r] * inv);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[i][j][r] * inv);
+        }
+        *reinterpret_cast<f16x4*>(dst) = ov;
+      }
     }
   }
 }
+
+inline bool al(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 template <int DQK, int DPV, bool SPARE>
 int launch_q(const i2v_attn_params& p, hipStream_t s) {
@@ -415,29 +447,45 @@ int launch_q(const i2v_attn_params& p, hipStream_t s) {
   if (DQK == 64 && p.lk > 64 && p.lk <= 96) kvt = 96;
   if (kvt_env == 64 || (kvt_env == 128 && DQK <= 64) || (kvt_env == 96 && DQK == 64)) kvt = kvt_env;
   const dim3 block(256);
-  const dim3 grid((unsigned)i2v_cdiv(p.lq, 64 * qt), (unsigned)p.heads, (unsigned)p.batch_q);
+  const int nqb = (int)i2v_cdiv(p.lq, 64 * qt);
+  // one key tile covers the whole sequence (the text / image-prompt tokens): walk several query blocks per workgroup so that
+  // about 1024 workgroups remain (see WALK)
+  static const int walk_off = getenv("I2V_ATTN_WALK") ? (atoi(getenv("I2V_ATTN_WALK")) == 0) : 0;
+  int qbw = 1;
+  if (!walk_off && p.lk <= kvt) {
+    const int64_t wgs = (int64_t)nqb * p.heads * p.batch_q;
+    qbw = (int)(wgs / 1024);
+    if (qbw > 8) qbw = 8;
+    if (qbw > nqb) qbw = nqb;
+    if (qbw < 1) qbw = 1;
+  }
+  // (measured and removed: O staged through a per-wave LDS slab and stored as 16-byte row chunks instead of the accumulator
+  //  layout's 8-byte pieces -- 77.7 vs 73.6 us; a head-major layout of q / o (80-byte rows contiguous) -- 72.7 vs 73.6 us;
+  //  with 4 keys instead of 77 the launch still takes 56 us against 24 us for a copy of Q to O: what is left is the per-block
+  //  instruction count of the single-tile path, tools/attn77_probe.py)
+  const bool walk = qbw > 1;
+  const dim3 grid((unsigned)i2v_cdiv(nqb, qbw), (unsigned)p.heads, (unsigned)p.batch_q);
+#define I2V_ATTN_LAUNCH(QTV, KVTV)                                                                                       \
+  do {                                                                                                                   \
+    if (walk)                                                                                                            \
+      hipLaunchKernelGGL((attn_kernel<DQK, DPV, QTV, KVTV, SPARE, true>), grid, block, 0, s, p, scale_log2, qbw);        \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((attn_kernel<DQK, DPV, QTV, KVTV, SPARE, false>), grid, block, 0, s, p, scale_log2, 1);         \
+  } while (0)
   if constexpr (DQK == 64) {
     if (kvt == 96) {
-      if (qt == 2)
-        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, 96, SPARE>), grid, block, 0, s, p, scale_log2);
-      else
-        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, 96, SPARE>), grid, block, 0, s, p, scale_log2);
+      if (qt == 2) I2V_ATTN_LAUNCH(2, 96); else I2V_ATTN_LAUNCH(1, 96);
       return i2v_check_launch("i2v_attention_f16");
     }
   }
   if constexpr (DQK <= 64) {
     if (kvt == 128) {
-      if (qt == 2)
-        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, 128, SPARE>), grid, block, 0, s, p, scale_log2);
-      else
-        hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, 128, SPARE>), grid, block, 0, s, p, scale_log2);
+      if (qt == 2) I2V_ATTN_LAUNCH(2, 128); else I2V_ATTN_LAUNCH(1, 128);
       return i2v_check_launch("i2v_attention_f16");
     }
   }
-  if (qt == 2)
-    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 2, 64, SPARE>), grid, block, 0, s, p, scale_log2);
-  else
-    hipLaunchKernelGGL((attn_kernel<DQK, DPV, 1, 64, SPARE>), grid, block, 0, s, p, scale_log2);
+  if (qt == 2) I2V_ATTN_LAUNCH(2, 64); else I2V_ATTN_LAUNCH(1, 64);
+#undef I2V_ATTN_LAUNCH
   return i2v_check_launch("i2v_attention_f16");
 }
 
@@ -445,8 +493,6 @@ template <int DQK, int DPV>
 int launch_d(const i2v_attn_params& p, hipStream_t s) {
   return p.head_dim < DPV ? launch_q<DQK, DPV, true>(p, s) : launch_q<DQK, DPV, false>(p, s);
 }
-
-inline bool al(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
 
