@@ -894,6 +894,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ x, 
   if (rl == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// out[c] += sum_r a[r][c] b[r][c]: the gain gradient of a LayerNorm / GroupNorm (d gamma = sum dy o xhat)
+__global__ __launch_bounds__(256) void colsum_prod_kernel(const f16* __restrict__ a, int64_t lda, const f16* __restrict__ b,
+                                                          int64_t ldb, float* __restrict__ out, int64_t rows, int cols,
+                                                          int64_t rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + rl; r < r1; r += 4) s += (float)a[r * lda + c] * (float)b[r * ldb + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // g[m][c] = coef (y[m][c] - t[m][c]) for tokens of frames >= 1, 0 for the first frame of every clip
 __global__ __launch_bounds__(256) void mse_grad_kernel(const f16* __restrict__ y, const f16* __restrict__ t,
                                                        f16* __restrict__ gout, int64_t n_img, int L, int C, int frames,
@@ -1280,6 +1295,16 @@ extern "C" int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t ro
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)i2v_cdiv(cols, 64), (unsigned)i2v_cdiv(rows, rpb)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(x), ldx, out, rows, cols, rpb);
   return i2v_check_launch("i2v_colsum_f32");
+}
+
+extern "C" int i2v_colsum_prod_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int32_t cols,
+                                   i2v_stream_t stream) {
+  I2V_CHECK_ARG(a && b && out && rows > 0 && cols > 0 && lda >= cols && ldb >= cols, "i2v_colsum_prod_f32: bad arguments");
+  const int64_t rpb = 256;
+  hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)i2v_cdiv(cols, 64), (unsigned)i2v_cdiv(rows, rpb)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(a), lda, reinterpret_cast<const f16*>(b),
+                     ldb, out, rows, cols, rpb);
+  return i2v_check_launch("i2v_colsum_prod_f32");
 }
 
 extern "C" int i2v_masked_mse_grad_f16(const void* y, const void* target, void* grad, int64_t n_img, int32_t tokens,

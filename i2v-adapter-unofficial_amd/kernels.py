@@ -807,6 +807,20 @@ def colsum(x, out=None):
     return out
 
 
+def colsum_prod(a, b, out=None):
+    """fp32 [cols] += sum over the rows of a o b (fp16 matrices of one shape): the gain gradient of a norm."""
+    lib = _lib.load()
+    a, lda = _mat(a, "a")
+    b, ldb = _mat(b, "b")
+    if a.shape != b.shape:
+        raise ValueError(f"colsum_prod: {tuple(a.shape)} vs {tuple(b.shape)}")
+    if out is None:
+        out = torch.zeros((a.shape[1],), dtype=torch.float32, device=a.device)
+    _req(out, "out", dtype=torch.float32)
+    _lib.check(lib.i2v_colsum_prod_f32(_p(a), lda, _p(b), ldb, _p(out), a.shape[0], a.shape[1], _stream()), "i2v_colsum_prod_f32")
+    return out
+
+
 def masked_mse_grad(y, target, frames, coef):
     """seed gradient of the training loss (train_image_to_video.py:848-856): coef * (y - target) on the tokens of every
     frame but the first of each clip, 0 there.  y, target fp16 [n_img, tokens, C] contiguous."""

@@ -331,14 +331,33 @@ class Transformer2DTrainer:
         return K.add(dx, g), grads
 
 
+def _unit_affine(c, device):
+    """(ones, zeros) fp16 [c]: a norm kernel run with them returns x-hat, the factor of the gain gradient."""
+    key = (c, str(device))
+    hit = _unit_affine.cache.get(key)
+    if hit is None:
+        hit = _unit_affine.cache[key] = (torch.ones((c,), dtype=f16, device=device), torch.zeros((c,), dtype=f16, device=device))
+    return hit
+
+
+_unit_affine.cache = {}
+
+
 class MotionModuleTrainer:
     """TransformerTemporalModel: clip-wide GroupNorm -> proj_in -> [LN + PE -> self-attention over the frames of
-    a pixel -> + residual] x 2 -> LN -> GEGLU FF -> proj_out -> + residual, on rows in (batch, pixel, frame) order."""
+    a pixel -> + residual] x 2 -> LN -> GEGLU FF -> proj_out -> + residual, on rows in (batch, pixel, frame) order.
 
-    def __init__(self, mm):
+    train_weights=True is `--update_motion_modules` (train_image_to_video.py:452, 669 -> unet:984-999 with
+    freeze_animatediff=False: every parameter of every motion module trains): `backward` then also returns the gradient of
+    all 26 tensors of the module keyed by their state-dict names.  Weight gradients are dY^T X GEMMs over the channel-major
+    copies (`wgrad`), bias / shift gradients column sums, gain gradients sum dY o x-hat (`K.colsum_prod`); the normalised
+    inputs are recomputed from the kept layer inputs instead of being stored."""
+
+    def __init__(self, mm, train_weights=False):
         if len(mm.transformer_blocks) != 1:
             raise NotImplementedError("one temporal block per motion module (AnimateDiff v1.5)")
         self.m = mm
+        self.train_weights = bool(train_weights)
 
     @torch.no_grad()
     def forward(self, x, num_frames):
@@ -364,22 +383,51 @@ class MotionModuleTrainer:
         h = K.gemm(n3, ff["w1"], ff["b1"])
         y = K.geglu(h)
         t3 = K.gemm(y, ff["w2"], ff["b2"], residual=t)
-        self.saved = (x, stages, t, h)
+        self.saved = (x, stages, t, h, t3 if self.train_weights else None)
         return K.gemm(t3, p["wo"], p["bo"], residual=x.view(-1, c), store=I2V_STORE_ROWPERM, frames=F, hw=hw).view(n, hh, ww, c)
 
     @torch.no_grad()
-    def backward(self, g, num_frames):
+    def backward(self, g, num_frames, loss_scale=1.0):
+        """d / d input; with train_weights also {state-dict name: fp32 gradient / loss_scale} as the second value."""
         m, p = self.m, self.m.packed()
         blk = m.transformer_blocks[0]
         q, ff = blk.packed(), blk.ff.packed()
-        x, stages, t2, h = self.saved
+        x, stages, t2, h, t3 = self.saved
         n, hh, ww, c = x.shape
         hw, clips, F = hh * ww, n // num_frames, num_frames
         n_pixels = clips * hw
+        tw = self.train_weights
+        inv = 1.0 / float(loss_scale)
+        grads = {}
+        ones, zeros = _unit_affine(c, x.device)
+
+        def linear(name, dy, xin, bias=True):
+            grads[f"{name}.weight"] = wgrad(dy, xin) * inv
+            if bias:
+                grads[f"{name}.bias"] = K.colsum(dy) * inv
+
+        def norm(name, dy, xhat):
+            grads[f"{name}.weight"] = K.colsum_prod(dy, xhat) * inv
+            grads[f"{name}.bias"] = K.colsum(dy) * inv
+
         gp = K.permute_rows(g.view(-1, c), clips, F, hw, True)
+        if tw:
+            linear("proj_out", gp, t3)
         dt = K.gemm(gp, _t(p["wo"]))                                                  # dL/dt3
         dy = K.gemm(dt, _t(ff["w2"]))
-        dn3 = K.gemm(K.geglu_bwd(h, dy), _t(ff["w1"]))
+        dh = K.geglu_bwd(h, dy)
+        if tw:
+            linear("transformer_blocks.0.ff.net.2", dt, K.geglu(h))
+            n3 = K.layernorm(t2, q["g3"], q["b3"], blk.eps)
+            inner = dh.shape[1] // 2
+            # the packed projection interleaves (value_i, gate_i) rows (`pack_geglu`); the reference keeps [values ; gates]
+            unpack = lambda t_: torch.cat([t_[0::2], t_[1::2]], dim=0)
+            grads["transformer_blocks.0.ff.net.0.proj.weight"] = unpack(wgrad(dh, n3)) * inv
+            grads["transformer_blocks.0.ff.net.0.proj.bias"] = unpack(K.colsum(dh)) * inv
+            assert grads["transformer_blocks.0.ff.net.0.proj.weight"].shape[0] == 2 * inner
+        dn3 = K.gemm(dh, _t(ff["w1"]))
+        if tw:
+            norm("transformer_blocks.0.norm3", dn3, K.layernorm(t2, ones, zeros, blk.eps))
         dt = K.layernorm_bwd(t2, dn3, q["g3"], blk.eps, add=dt)
         for i in (2, 1):
             t_in, qk, v, o = stages[i - 1]
@@ -388,11 +436,27 @@ class MotionModuleTrainer:
                                          head_dim=blk.dim_head, scale=blk.dim_head ** -0.5)
             dnl = K.gemm(dq, _t(q[f"wqk{i}"]), a2=dk)                            # [dq | dk] [Wq ; Wk]
             dnl = K.gemm(dv, _t(q[f"wv{i}"]), residual=dnl, out=dnl)
+            if tw:
+                a = f"transformer_blocks.0.attn{i}"
+                linear(f"{a}.to_out.0", dt, o)
+                nl = K.layernorm(t_in, q[f"g{i}"], q[f"b{i}"], blk.eps, pe=q["pe"], pe_period=F)
+                linear(f"{a}.to_q", dq, nl, bias=False)
+                linear(f"{a}.to_k", dk, nl, bias=False)
+                linear(f"{a}.to_v", dv, nl, bias=False)
+                norm(f"transformer_blocks.0.norm{i}", dnl, K.layernorm(t_in, ones, zeros, blk.eps))
             dt = K.layernorm_bwd(t_in, dnl, q[f"g{i}"], blk.eps, add=dt)
         dnp = K.gemm(dt, _t(p["wi"]))
         dn = K.permute_rows(dnp, clips, F, hw, False).view(n, hh, ww, c)
+        if tw:
+            cin = x.shape[3]
+            o1, z1 = _unit_affine(cin, x.device)
+            nrm = K.groupnorm(x, p["g"], p["b"], m.groups, 1e-6, frames_per_stat=F)
+            linear("proj_in", dt, K.permute_rows(nrm.view(-1, cin), clips, F, hw, True))
+            norm("norm", dn.view(-1, cin), K.groupnorm(x, o1, z1, m.groups, 1e-6, frames_per_stat=F).view(-1, cin))
         dx = K.groupnorm_bwd(x, dn, p["g"], p["b"], m.groups, 1e-6, frames_per_stat=F)
-        return K.add(dx, g)
+        self.saved = None
+        dx = K.add(dx, g)
+        return (dx, grads) if tw else dx
 
 
 class DownsampleTrainer:
@@ -434,9 +498,12 @@ class UNetAdapterTrainer:
     d loss / d {i2v_adapter.to_q.weight, to_out.0.weight, to_out.0.bias} of all spatial blocks (unet:979-1026) as un-scaled
     fp32 tensors keyed by their state-dict names."""
 
-    def __init__(self, unet):
+    def __init__(self, unet, update_motion_modules=False):
+        """update_motion_modules: `--update_motion_modules` (train_image_to_video.py:452, 669): the 21 motion modules train
+        too (unet:984-999 with freeze_animatediff=False) and `backward` also returns their parameters' gradients."""
         from .blocks import DownBlockMotion, UpBlockMotion  # noqa: F401  (attention-free blocks: resnet -> motion)
         self.unet = unet
+        self.update_motion_modules = bool(update_motion_modules)
         names = {m: n for n, m in unet.named_modules()}
         self.tape_layout = []          # (kind, trainer, extra) in forward order; built once, replayed per step
         self._mk = dict(resnet=ResnetTrainer, t2d=Transformer2DTrainer, motion=MotionModuleTrainer, down=DownsampleTrainer,
@@ -447,7 +514,8 @@ class UNetAdapterTrainer:
     def _tr(self, kind, module):
         t = self._trainers.get(module)
         if t is None:
-            t = self._trainers[module] = self._mk[kind](module)
+            kw = dict(train_weights=self.update_motion_modules) if kind == "motion" else {}
+            t = self._trainers[module] = self._mk[kind](module, **kw)
         return t
 
     @torch.no_grad()
@@ -479,7 +547,7 @@ class UNetAdapterTrainer:
             if motion is not None:
                 mm = self._tr("motion", motion)
                 x = mm.forward(x, F)
-                tape.append(("motion", mm, None))
+                tape.append(("motion", mm, self._names[motion]))
             return x
 
         push(x)
@@ -502,7 +570,7 @@ class UNetAdapterTrainer:
             tape.append(("t2d", a, self._names[attn]))
             mm = self._tr("motion", motion)
             x = mm.forward(x, F)
-            tape.append(("motion", mm, None))
+            tape.append(("motion", mm, self._names[motion]))
             x = layer(x, resnet, None, None)
         for blk in u.up_blocks:
             attns = getattr(blk, "attentions", [None] * len(blk.resnets))
@@ -568,7 +636,12 @@ class UNetAdapterTrainer:
                 for k, v in pg.items():
                     grads[f"{extra}.transformer_blocks.0.{k}"] = v
             elif kind == "motion":
-                g = tr.backward(g, F)
+                if self.update_motion_modules:
+                    g, pg = tr.backward(g, F, loss_scale)
+                    for k, v in pg.items():
+                        grads[f"{extra}.{k}"] = v
+                else:
+                    g = tr.backward(g, F)
             else:
                 g = tr.backward(g)
         self.saved = None
@@ -583,8 +656,9 @@ class AdapterOptimizer:
     writes the fp16 parameters back.  No per-parameter launches, no host round trip for the clip coefficient."""
 
     def __init__(self, unet, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, process_group=None,
-                 gradient_accumulation_steps=1, use_ema=False, ema_decay=0.9999):
-        """gradient_accumulation_steps: `accelerator.accumulate` (train_image_to_video.py:486, 785) -- `step` adds each
+                 gradient_accumulation_steps=1, use_ema=False, ema_decay=0.9999, update_motion_modules=False):
+        """update_motion_modules: the motion modules' parameters join the buckets (`--update_motion_modules`,
+        train_image_to_video.py:452, 669; unet:984-999).  gradient_accumulation_steps: `accelerator.accumulate` (train_image_to_video.py:486, 785) -- `step` adds each
         micro-batch's gradients / N into the bucket and updates on every N-th call.  use_ema: an exponential moving average of
         the TRAINED parameters in a fourth flat bucket (`--use_ema`, :673-677, 888-889; diffusers EMAModel's schedule: decay_t =
         min(ema_decay, (1 + t) / (10 + t)) with t = updates - 1, 0 on the first).  (The reference builds its EMA over a
@@ -596,8 +670,10 @@ class AdapterOptimizer:
             raise ValueError("gradient_accumulation_steps must be >= 1")
         self.use_ema, self.ema_decay, self.ema_updates = bool(use_ema), float(ema_decay), 0
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.update_motion_modules = bool(update_motion_modules)
         self.names = [n for n, _ in unet.named_parameters()
-                      if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n]                   # unet:1001-1006
+                      if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n                    # unet:1001-1006
+                      or (self.update_motion_modules and ".motion_modules." in n)]                   # unet:984-999
         params = dict(unet.named_parameters())
         self.params = [params[n] for n in self.names]
         self.offsets, off = {}, 0

@@ -457,7 +457,8 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
         return model
 
     def freeze_unet_params(self, freeze_animatediff=True) -> None:
-        """unet:979-1026 (bookkeeping only: this build is inference-only)."""
+        """unet:979-1026: the adapter's to_q / to_out train; with freeze_animatediff=False (`--update_motion_modules`) every
+        motion-module parameter too.  (training.UNetAdapterTrainer / AdapterOptimizer take the same switch.)"""
         for p in self.parameters():
             p.requires_grad = False
         for name, p in self.named_parameters():

@@ -395,6 +395,10 @@ int i2v_geglu_bwd_f16(const void* h, int64_t ldh, const void* dy, int64_t lddy, 
 int i2v_geglu_f16(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t rows, int32_t inner, i2v_stream_t stream);
 /* out[c] += sum_r x[r][c], fp32 (the bias gradient of a Linear; the caller zeroes out before the first call). */
 int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t rows, int32_t cols, i2v_stream_t stream);
+/* out[c] += sum_r a[r][c] b[r][c], fp32: the gain gradient of a LayerNorm / GroupNorm, d gamma = sum dy o xhat -- the
+ * motion modules' norms train under `--update_motion_modules` (train_image_to_video.py:452, 669; unet:984-999). */
+int i2v_colsum_prod_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int32_t cols,
+                        i2v_stream_t stream);
 /* Seed gradient of the training loss (train_image_to_video.py:848-856: MSE summed over every frame but the first of each
  * clip, divided by the number of unmasked elements): grad[img][l][c] = coef (y - target) for img % frames != 0, else 0;
  * coef = 2 * loss_scale / count is the caller's.  y, target, grad fp16 [n_img, tokens, channels]. */

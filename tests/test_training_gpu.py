@@ -373,6 +373,45 @@ def test_motion_module_backward(dev, frames):
             name=f"TransformerTemporalModel backward F={frames}")
 
 
+@pytest.mark.parametrize("frames", [4, 16])
+def test_motion_module_weight_gradients(dev, frames):
+    """`--update_motion_modules` (train_image_to_video.py:452, 669; unet:984-999): the gradient of every one of the 26
+    tensors of a motion module -- GroupNorm, proj_in, three LayerNorms, q / k / v / out of both temporal attentions, the
+    GEGLU feed-forward, proj_out -- against torch autograd on the fp32 oracle, plus the column-sum-of-products kernel."""
+    from oracle.blocks import TransformerTemporalModel as O
+    from i2v_adapter_unofficial_amd.training import MotionModuleTrainer
+    K = pkg().kernels
+    kw = dict(num_attention_heads=4, attention_head_dim=16, in_channels=64, norm_num_groups=16, attention_bias=False,
+              activation_fn="geglu", positional_embeddings="sinusoidal", num_positional_embeddings=32)
+    o, m = _pair(O, pkg().blocks.TransformerTemporalModel, dev, 43, **kw)
+    for prm in o.parameters():
+        prm.requires_grad_(True)
+    g = torch.Generator().manual_seed(44)
+    n, hw = 2 * frames, 8
+    x = h(torch.randn(n, 64, hw, hw, generator=g)).requires_grad_()
+    dy = h(torch.randn(n, 64, hw, hw, generator=g))
+    out = o(x, num_frames=frames)[0]
+    out.backward(dy)
+    tr = MotionModuleTrainer(m, train_weights=True)
+    tr.forward(_nchw_to_tok(x.detach()).half().to(dev), frames)
+    scale = 4.0
+    dx, grads = tr.backward((_nchw_to_tok(dy) * scale).half().to(dev), frames, loss_scale=scale)
+    compare(dx, _nchw_to_tok(x.grad) * scale, rel=GRAD_REL_TOL, name=f"motion module (training weights) d input F={frames}")
+    ref = {k: v.grad for k, v in o.named_parameters()}
+    assert set(grads) == set(ref) and len(ref) == 26, sorted(set(grads) ^ set(ref))
+    for k in sorted(ref):
+        assert grads[k].dtype == torch.float32 and grads[k].shape == ref[k].shape, k
+        compare(grads[k], ref[k], rel=GRAD_REL_TOL, name=f"motion module F={frames}: d / d {k}")
+    # the kernel under the gain gradients on a ragged shape (rows not a multiple of its 256-row blocks, 70 columns of 72)
+    a = h(torch.randn(1000, 72, generator=g)).to(dev).half()
+    b = h(torch.randn(1000, 72, generator=g)).to(dev).half()
+    got = K.colsum_prod(a[:, :70], b[:, :70])
+    want = (a[:, :70].double() * b[:, :70].double()).sum(0)
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-4)
+    with pytest.raises(ValueError):
+        K.colsum_prod(a, b[:, :70])
+
+
 def test_transformer2d_backward(dev):
     from oracle.i2v_adapter import I2VAdapterTransformer2DModel as O
     from i2v_adapter_unofficial_amd.training import Transformer2DTrainer
@@ -402,8 +441,8 @@ def test_transformer2d_backward(dev):
 
 
 # ---------------------------------------------------------------------------------------------- the whole training step
-@pytest.mark.parametrize("ip", [False, True])
-def test_unet_training_step_vs_autograd(dev, ip):
+@pytest.mark.parametrize("ip,motion", [(False, False), (True, False), (False, True)])
+def test_unet_training_step_vs_autograd(dev, ip, motion):
     """The reference's step (train_image_to_video.py:839-884) on the reduced UNet (SD-1.5 topology, narrow channels): forward
     with enable_cross_frame_attn=True, loss = MSE without the first frame, backward through every layer -- the gradient of
     ALL 16 x 3 trainable adapter tensors (unet:979-1026) and the loss against torch autograd on the fp32 oracle UNet."""
@@ -416,10 +455,14 @@ def test_unet_training_step_vs_autograd(dev, ip):
     for prm in ou.parameters():
         prm.requires_grad_(False)
     ou.freeze_unet_params() if hasattr(ou, "freeze_unet_params") else None
-    train = {n: prm for n, prm in ou.named_parameters() if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n}
+    # motion=True: `--update_motion_modules` -> freeze_unet_params(freeze_animatediff=False) (unet:984-999): + 21 x 26 tensors
+    train = {n: prm for n, prm in ou.named_parameters() if ".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n
+             or (motion and ".motion_modules." in n)}
     for prm in train.values():
         prm.requires_grad_(True)
-    assert len(train) == 16 * 3
+    assert len(train) == 16 * 3 + (21 * 26 if motion else 0)
+    hu.freeze_unet_params(freeze_animatediff=not motion)
+    assert {n for n, prm in hu.named_parameters() if prm.requires_grad} == set(train)
     inp = small_unet_inputs(b=2, f=4, hw=16)
     t = torch.tensor([481, 481])
     g = torch.Generator().manual_seed(78)
@@ -432,7 +475,7 @@ def test_unet_training_step_vs_autograd(dev, ip):
     loss = ((pred.float() - target) ** 2 * mask).sum() / mask.sum()
     loss.backward()
 
-    tr = UNetAdapterTrainer(hu)
+    tr = UNetAdapterTrainer(hu, update_motion_modules=motion)
     y = tr.forward(inp["sample"].half().to(dev), t.to(dev), inp["ctx"].half().to(dev), added_cond_kwargs=added_d)
     got_pred = y[..., :4].float().cpu().permute(0, 3, 1, 2).reshape(pred.shape)
     compare(got_pred, pred, rel=6e-3, name="training forward of the reduced UNet")
@@ -444,6 +487,47 @@ def test_unet_training_step_vs_autograd(dev, ip):
         err, scale = compare(grads[name], prm.grad, rel=1.2e-2, name=f"UNet step: d loss / d {name}")
         worst = max(worst, err / scale)
     print(f"UNet training step: loss {got_loss.item():.6f} vs {loss.item():.6f}, worst gradient error {worst:.2e} of max")
+
+
+def test_update_motion_modules_optimizer_step(dev):
+    """`--update_motion_modules`: the optimiser's buckets cover the adapter AND the motion modules (unet:984-1006), one step
+    moves every such parameter by at most lr (1 + weight decay |p|) (AdamW's first step is lr sign(g)), leaves every frozen
+    parameter bit-identical, and the next forward runs on the new weights (the packed / transposed operand copies follow
+    the parameters' version counters)."""
+    from tests.parity import hip_unet_from_oracle, oracle_small_unet, small_unet_inputs
+    from i2v_adapter_unofficial_amd.training import AdapterOptimizer, UNetAdapterTrainer
+    hu = hip_unet_from_oracle(oracle_small_unet(seed=79), dev)
+    hu.freeze_unet_params(freeze_animatediff=False)
+    lr = 1e-3
+    opt = AdapterOptimizer(hu, lr=lr, max_grad_norm=1.0, update_motion_modules=True)
+    assert set(opt.names) == {n for n, prm in hu.named_parameters() if prm.requires_grad}
+    assert len(opt.names) == 16 * 3 + 21 * 26
+    before = {n: prm.detach().clone() for n, prm in hu.named_parameters()}
+    inp = small_unet_inputs(b=2, f=4, hw=16)
+    t = torch.tensor([300, 300]).to(dev)
+    target = torch.randn(inp["sample"].shape, generator=torch.Generator().manual_seed(80)).to(dev)
+    tr = UNetAdapterTrainer(hu, update_motion_modules=True)
+    y0 = tr.forward(inp["sample"].half().to(dev), t, inp["ctx"].half().to(dev)).clone()
+    _, grads = tr.backward(target, loss_scale=2.0 ** 10)
+    assert opt.step(grads) and not opt.last_step_skipped()
+    moved = 0
+    for n, prm in hu.named_parameters():
+        d = (prm.detach().float() - before[n].float()).abs()
+        if n in opt.offsets:
+            bound = lr * (1.0 + 1e-2 * before[n].float().abs()) + 9.8e-4 * before[n].float().abs()    # + one fp16 rounding
+            assert (d <= bound * 1.001 + 1e-7).all(), n
+            moved += int(d.max().item() > 0)
+        else:
+            assert d.max().item() == 0.0, f"frozen parameter {n} moved"
+    assert moved >= 0.9 * len(opt.names), moved
+    y1 = tr.forward(inp["sample"].half().to(dev), t, inp["ctx"].half().to(dev))
+    assert (y1.float() - y0.float()).abs().max().item() > 0
+    tr.backward(target, loss_scale=2.0 ** 10)
+    # the fp32 masters moved DOWN the gradient: sum g . (p_new - p_old) < 0 over the adapter and over the motion modules
+    for part in (".i2v_adapter.", ".motion_modules."):
+        dot = sum((grads[n].double().reshape(-1) * (opt.master[o: o + c].double() - before[n].double().reshape(-1))).sum().item()
+                  for n, (o, c) in opt.offsets.items() if part in n)
+        assert dot < 0, (part, dot)
 
 
 def test_adamw_clip_matches_torch(dev):
