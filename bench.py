@@ -328,7 +328,8 @@ def train_bench(args, model, ip, rank, world, dev):
     ctx = torch.randn(1, 77, 768, generator=g).half().to(dev)
     added = {"image_embeds": torch.randn(1, 1024, generator=g).half().to(dev)} if ip else None
     t = torch.tensor([481], device=dev)
-    trainer, opt = UNetAdapterTrainer(model), AdapterOptimizer(model, lr=1e-5)
+    umm = bool(args.update_motion_modules)
+    trainer, opt = UNetAdapterTrainer(model, update_motion_modules=umm), AdapterOptimizer(model, lr=1e-5, update_motion_modules=umm)
 
     def step():
         trainer.forward(x, t, ctx, added_cond_kwargs=added)
@@ -362,6 +363,7 @@ def train_bench(args, model, ip, rank, world, dev):
                                     "first frame, backward through the frozen UNet, all-reduce of the adapter gradients, "
                                     f"clip + AdamW), SD-1.5 width, {F}f x {args.size}x{args.size}, IP {'on' if ip else 'off'}, one clip "
                                     "per rank; NOT the BASELINE metric"),
+                       "update_motion_modules": umm,
                        "trainable_parameters": n_train, "allreduce_bytes_per_step": 4 * n_train if world > 1 else 0,
                        "loss_first": float(loss0), "loss_last": float(loss), "finite": bool(torch.isfinite(loss).item())},
             "roofline": None, "cpu_baseline": None}), flush=True)
@@ -407,6 +409,8 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="time the ADAPTER TRAINING STEP instead (SURVEY 8 f4: forward + backward + one all-reduce of the "
                          "adapter gradients + clip + AdamW; one clip per rank per step) -- not the BASELINE metric")
+    ap.add_argument("--update-motion-modules", action="store_true",
+                    help="with --train: the 21 motion modules train too (train_image_to_video.py:452, 669)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-rank plumbing on a box WITHOUT GPUs: launcher, rendezvous, gloo group, flat "
                          "weight broadcast, pair sharding, timed loop with a stub step, MAX all-reduce, JSON line "
