@@ -90,6 +90,19 @@ class TAttnParams(C.Structure):
     ]
 
 
+class MotionAttnParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("gamma", C.c_void_p),
+        ("shift", C.c_void_p), ("ld_shift", C.c_int64),
+        ("w_qkv", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("rows", C.c_int64),
+        ("channels", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("frames", C.c_int32),
+        ("eps", C.c_float), ("scale", C.c_float),
+    ]
+
+
 class GnParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("c1", C.c_int32),
@@ -126,6 +139,9 @@ SIGNATURES = {
     "i2v_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmParams)]),
     "i2v_attention_f16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "i2v_temporal_attention_f16": (C.c_int, [C.POINTER(TAttnParams), _P]),
+    "i2v_motion_attn_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "i2v_motion_attn_pack_rows": (C.c_int32, [C.c_int32, C.c_int32]),
+    "i2v_motion_attn_f16": (C.c_int, [C.POINTER(MotionAttnParams), _P]),
     "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_groupnorm_f16": (C.c_int, [C.POINTER(GnParams), _P]),
     "i2v_groupnorm_fold_f16": (C.c_int, [C.POINTER(GnParams), _P, C.c_int64, _P, C.c_int32, _P, _P, _P]),

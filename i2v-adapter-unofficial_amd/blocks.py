@@ -552,6 +552,9 @@ class SinusoidalPositionalEmbedding(nn.Module):
             self.pe.copy_(self._table(self.embed_dim, self.max_seq_length).to(self.pe.dtype))
 
 
+FUSED_MOTION_ATTN = os.environ.get("I2V_MOTION_FUSED", "1") != "0"
+
+
 class TemporalTransformerBlock(HipModule):
     """BasicTransformerBlock(double_self_attention=True, positional_embeddings="sinusoidal") of A9, on tokens in
     (b, pixel, frame) order: LN(+pe) -> fused q|k GEMM + V^T GEMM -> temporal attention -> out-proj (+residual),
@@ -596,6 +599,10 @@ class TemporalTransformerBlock(HipModule):
             p[f"f_wv{i}"], p[f"f_sv{i}"], p[f"f_cv{i}"] = fold_layernorm(attn.to_v.weight, None, norm.weight, norm.bias)
             p[f"f_pev{i}"] = (pe @ attn.to_v.weight.detach().float().T).T.to(f16).contiguous()       # [C, max_len]
         p["f_ff"] = self.ff.fold_norm(self.norm3)
+        # the fused LayerNorm + q / k / v + attention kernel's weights (per head, rows padded to 16)
+        for i, attn in enumerate((self.attn1, self.attn2), 1):
+            p[f"wqkv{i}"] = K.pack_motion_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, self.heads)
+        self._ma_tables = {}          # (site, frames) -> (gamma fp32, beta + pe[frame] fp32), made on first use
         return p
 
     def _fold_ok(self, t, frames):
@@ -625,7 +632,16 @@ class TemporalTransformerBlock(HipModule):
         c = self.dim
         fold_attn, fold_ff = self._fold_ok(t, frames)
         overlap = t.shape[0] <= streams.MAX_ROWS       # q|k beside V^T on two streams where neither fills the chip
+        fused = FUSED_MOTION_ATTN and K.motion_attn_supported(t.shape[0], c, self.heads, self.dim_head, frames)
         for i in (1, 2):
+            if fused:      # LayerNorm + pe, q / k / v and the attention over the frames in one launch (64^2 level of SD-1.5)
+                tab = self._ma_tables.get((i, frames))
+                if tab is None:
+                    tab = self._ma_tables[(i, frames)] = K.motion_attn_tables(p[f"g{i}"], p[f"b{i}"], p["pe"], frames)
+                o = K.motion_attn(t, tab[0], tab[1], p[f"wqkv{i}"], heads=self.heads, head_dim=self.dim_head, frames=frames,
+                                  eps=self.eps)
+                t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)
+                continue
             n = None if fold_attn else K.layernorm(t, p[f"g{i}"], p[f"b{i}"], self.eps, pe=p["pe"], pe_period=frames)
             with streams.fork(overlap, t.device) as fk:
                 with fk.side():

@@ -1,0 +1,327 @@
+// Fused attention sub-block of the motion module (TransformerTemporalModel -> BasicTransformerBlock with
+// double self-attention over the FRAMES of one pixel, unet:232-244 / 413-425 / 607-619):
+//     n = LayerNorm(t) + pe[frame];   q, k, v = n Wq^T, n Wk^T, n Wv^T;   o = softmax(q k^T / sqrt(d)) v      per pixel and head
+// in ONE launch: t is read once, o is written once.  Un-fused this was four launches at the 64^2 level (q|k GEMM 105 us, V^T
+// GEMM 59 us, temporal attention 74 us: q, k and V^T -- 250 MB -- written and read back) for 80 GFLOP.
+//
+// Rows are in (batch, pixel, frame) order, so with 16 frames a 16-row MFMA tile IS one pixel's sequence.  A workgroup of 8
+// waves owns 128 rows (8 pixels) at a time: their LayerNorm-ed rows sit in LDS once (80 KB, 16-byte chunks XOR-swizzled by the
+// row so the 16 rows of a fragment read land on distinct banks), wave w owns head w.  No intermediate leaves the registers:
+//   * q and k are projected TRANSPOSED, D[channel][frame] = W_tile (A operand, straight from global: each wave streams only its
+//     own head's rows of W) x n^T (B operand from LDS).  In the accumulator layout lane l then holds channels 4 (l >> 4) + r of
+//     frame l & 15 -- which is exactly the A / B operand layout of v_mfma_f32_16x16x16_f16 with the CHANNEL as contraction
+//     index: S^T[key][query] = sum_c K[key][c] Q[query][c] takes the converted accumulators as they are.
+//   * softmax over the keys = over the 4 accumulator rows of a lane and the 4 lane groups (two lane-xor steps); the fp16
+//     P^T[key][query] is again in B-operand layout, now with the KEY as contraction index.
+//   * v is projected NON-transposed, D[key frame][channel]: its accumulators are the A operand V^T[channel][key] of
+//     O^T[channel][query] = sum_key V^T[channel][key] P^T[key][query].
+// head_dim 40 is padded to 48 per q / k / v by zero rows in the packed weights (i2v_motion_attn_pack_rows), which are stored in
+// FRAGMENT order -- [head][q|k|v][K step][16-row tile][lane][8] -- so that a wave's load instruction reads 1 KB of whole lines
+// (row-major, an instruction touched 16 rows x 64 B: with those loads a workgroup took 67k cycles per tile, without any 50k).
+//
+// What the in-kernel stamps (tools/motion_attn_probe.py, -DI2V_MA_STAMPS) showed and the structure answers:
+//   * the two waves of a SIMD (w and w + 4) do not share the matrix pipe evenly -- the older one runs its three passes in 25k
+//     cycles, the younger needs 38k, and alternating s_setprio per K step made both slower (121 -> 145 us) -- so no wave waits
+//     for another inside a tile: the workgroup is persistent over its tiles with TWO panels, a wave that has finished tile i
+//     normalises its 16 rows of tile i + 1 into the other panel straight away, and there is one barrier per tile;
+//   * the LayerNorm phase was a quarter of the tile (12k of 50k cycles: an HBM round trip, then 11 VALU operations per element):
+//     the next tile's rows are fetched into registers before the v pass and arrive under it, gamma and (beta + pe[frame]) come
+//     as fp32 tables (no conversions, one add less): 6.5 operations per element.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma16x16x16(f16x4 a, f16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+
+// buffer_load_dwordx4 ... offen lds: 16 bytes per lane, global -> LDS at (wave-uniform LDS base) + 16 * lane (a plain function
+// on purpose, as in gemm_big.hip: called directly from the kernel template, the builtin makes hipcc drop the launch stub)
+__device__ __forceinline__ void ma_dma16(__amdgpu_buffer_rsrc_t rsrc, f16* lds_wave_base, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+constexpr int MA_PIX = 8;              // pixels per tile (x 16 frames = 128 rows)
+constexpr int MA_F = 16;               // frames per pixel: one MFMA tile
+constexpr int MA_PD = 3;               // weight fragments in flight (K steps ahead)
+constexpr int MA_AD = 4;               // panel fragments in flight (reads ahead of the MFMAs that take them)
+
+template <int C, int D, int H>
+__global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_attn_params p, const float scale_log2, const int ntiles,
+                                                             long long* __restrict__ stamps) {
+  constexpr int DT = (D + 15) / 16, DP = 16 * DT, KS = C / 32, NJ = C / 64;
+  static_assert(C % 64 == 0 && H == 8, "one wave per head, 8 lanes x C / 64 chunks per row in the LayerNorm pass");
+  extern __shared__ __attribute__((aligned(16))) f16 panels[];       // 2 x [128][C], chunk index ^= row & 7
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: SGPR)
+  const int g = lane >> 4, l15 = lane & 15, sub = lane & 7;
+  const f16* __restrict__ X = reinterpret_cast<const f16*>(p.x);
+  const float* __restrict__ gamma = reinterpret_cast<const float*>(p.gamma);
+  const float* __restrict__ shift = reinterpret_cast<const float*>(p.shift);
+#ifdef I2V_MA_STAMPS
+  long long stamp[8];
+#define MA_STAMP(k) stamp[k] = __builtin_amdgcn_s_memtime()
+#else
+#define MA_STAMP(k)
+#endif
+
+  // ---- LayerNorm (+ positional table) of the wave's 16 rows into a panel: 8 lanes per row, two groups of 8 rows.  The raw rows
+  // come by LDS-DMA into the wave's own 10 KB of the panel (16 rows x 640 B, in [group][chunk column][lane] order) and are
+  // normalised in place: read whole into registers, then written to their swizzled places -- no register holds a row while the
+  // DMA is in flight under the v pass of the previous tile (held in registers there, they spilled: 259 dwords, 121 -> 230 us).
+  auto fetch_rows = [&](const int tile, f16* panel) {
+    const f16* base = X + ((int64_t)tile * (MA_PIX * MA_F) + 16 * wave) * p.ldx;        // (wave-uniform)
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)((15 * p.ldx + C) * 2), 0x00020000);
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        ma_dma16(rs, panel + 16 * wave * C + (half * NJ + j) * 512, (unsigned)(((8 * half + (lane >> 3)) * p.ldx + (sub + 8 * j) * 8) * 2));
+  };
+  auto normalise_rows = [&](f16* panel) {
+    f16x8 xv[2][NJ];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xv[half][j] = *reinterpret_cast<const f16x8*>(panel + 16 * wave * C + ((half * NJ + j) * 64 + lane) * 8);
+    // (the tables are loop invariants: without the opaque copies of their addresses the compiler keeps all 120 registers of
+    // them live through the three passes of every tile -- 207 spilled dwords)
+    const float* gp = gamma;
+    const float* sp = shift;
+    asm volatile("" : "+s"(gp), "+s"(sp));
+    f32x4 ga[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      ga[j][0] = *reinterpret_cast<const f32x4*>(gp + (sub + 8 * j) * 8);
+      ga[j][1] = *reinterpret_cast<const f32x4*>(gp + (sub + 8 * j) * 8 + 4);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = 16 * wave + 8 * half + (lane >> 3);
+      const float* sh = sp + (int64_t)(8 * half + (lane >> 3)) * p.ld_shift;      // (tiles start at frame 0: frame = row & 15)
+      f32x4 sv[NJ][2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        sv[j][0] = *reinterpret_cast<const f32x4*>(sh + (sub + 8 * j) * 8);
+        sv[j][1] = *reinterpret_cast<const f32x4*>(sh + (sub + 8 * j) * 8 + 4);
+      }
+      float v[NJ][8];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[j][e] = (float)xv[half][j][e];
+          s += v[j][e];
+        }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      const float mean = s / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[j][e] -= mean;
+          q = fmaf(v[j][e], v[j][e], q);
+        }
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      q += __shfl_xor(q, 4, 64);
+      const float rstd = rsqrtf(q / (float)C + p.eps);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = sub + 8 * j;
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)fmaf(v[j][e] * rstd, ga[j][e >> 2][e & 3], sv[j][e >> 2][e & 3]);
+        *reinterpret_cast<f16x8*>(panel + row * C + ((ch ^ (row & 7)) * 8)) = o;
+      }
+    }
+  };
+
+  // ---- wave = head: projections with a panel as one operand and the head's weight fragments (global) as the other
+  // (buffer loads: lane offset in ONE register, the fragment's place in the scalar offset -- as flat loads the 90 fragment
+  // addresses of a tile are loop invariants that the compiler hoists as 64-bit pairs: 180 registers, spilled)
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_qkv), 0, H * 3 * DP * C * 2, 0x00020000);
+  const int w_lane = lane * 16, w_wave = wave * (3 * DP * C * 2);
+  const int sw = l15 & 7;
+  f32x4 acc[MA_PIX][DT];
+  auto project = [&](const f16* panel, const int part, auto transposed) {
+    constexpr bool TR = decltype(transposed)::value;
+    const int wp = w_wave + part * (DP * C * 2);          // bytes; (DP C = KS DT 512 halfs per part) + (s DT + t) 1024
+    auto ldw = [&](const int s, const int t) {
+      return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, wp + (s * DT + t) * 1024, 0));
+    };
+    const f16* alane = panel + l15 * C;                  // + (16 pix) C + (((4 s + g) ^ (l15 & 7)) * 8)
+    f16x8 wf[MA_PD][DT];
+#pragma unroll
+    for (int pix = 0; pix < MA_PIX; ++pix)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) acc[pix][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < MA_PD - 1; ++s)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wf[s][t] = ldw(s, t);
+    constexpr int AD = MA_AD, NI = KS * MA_PIX;
+    auto lda = [&](const int i) {
+      return *reinterpret_cast<const f16x8*>(alane + 16 * (i % MA_PIX) * C + (((4 * (i / MA_PIX) + g) ^ sw) * 8));
+    };
+    f16x8 af[AD + 1];
+#pragma unroll
+    for (int i = 0; i < AD; ++i) af[i] = lda(i);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int s = i / MA_PIX, pix = i % MA_PIX;
+      if (pix == 0 && s + MA_PD - 1 < KS) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) wf[(s + MA_PD - 1) % MA_PD][t] = ldw(s + MA_PD - 1, t);
+      }
+      if (i + AD < NI) af[(i + AD) % (AD + 1)] = lda(i + AD);
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+        acc[pix][t] = TR ? mfma16x16x32(wf[s % MA_PD][t], af[i % (AD + 1)], acc[pix][t])
+                         : mfma16x16x32(af[i % (AD + 1)], wf[s % MA_PD][t], acc[pix][t]);
+      __builtin_amdgcn_sched_barrier(0);      // (unfenced, the scheduler hoists every load of the pass to its top: 947 spills)
+    }
+  };
+  auto to_half = [](const f32x4 a) { return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]}; };
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;        // (workgroup-uniform)
+  MA_STAMP(0);
+  fetch_rows(tile, panels);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  normalise_rows(panels);
+  MA_STAMP(1);
+  __syncthreads();
+  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    const f16* panel = panels + (it & 1) * (MA_PIX * MA_F * C);
+    const int next = tile + (int)gridDim.x;
+    MA_STAMP(2);
+
+    // q^T [channel][frame]
+    f16x4 qh[MA_PIX][DT];
+    project(panel, 0, std::true_type{});
+#pragma unroll
+    for (int pix = 0; pix < MA_PIX; ++pix)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) qh[pix][t] = to_half(acc[pix][t]);
+    MA_STAMP(3);
+
+    // k^T, then S^T[key][query] and the softmax over the keys
+    f16x4 ph[MA_PIX];
+    project(panel, 1, std::true_type{});
+#pragma unroll
+    for (int pix = 0; pix < MA_PIX; ++pix) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < DT; ++t) sacc = mfma16x16x16(to_half(acc[pix][t]), qh[pix][t], sacc);
+      float sv[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv[r] = sacc[r] * scale_log2;
+        mx = fmaxf(mx, sv[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv[r] = __builtin_amdgcn_exp2f(sv[r] - mx);
+        ls += sv[r];
+      }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      const float inv = 1.0f / ls;
+      ph[pix] = f16x4{(f16)(sv[0] * inv), (f16)(sv[1] * inv), (f16)(sv[2] * inv), (f16)(sv[3] * inv)};
+    }
+    MA_STAMP(4);
+
+    // (the other panel was last read in the previous iteration, which every wave has left through the barrier below)
+    // the next tile's rows leave HBM now and land (in the other panel, which nobody reads any more) under the v pass.  No wait
+    // of their own: loads return in order, and the v pass below has waited for weight fragments it requested after them.
+    f16* other = panels + ((it + 1) & 1) * (MA_PIX * MA_F * C);
+    if (next < ntiles) fetch_rows(next, other);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // v [key][channel], O^T[channel][query], stored as o[query row][head channels]
+    project(panel, 2, std::false_type{});
+    MA_STAMP(5);
+    f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
+#pragma unroll
+    for (int pix = 0; pix < MA_PIX; ++pix)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const f32x4 o = mfma16x16x16(to_half(acc[pix][t]), ph[pix], f32x4{0.f, 0.f, 0.f, 0.f});
+        const int ch = 16 * t + 4 * g;
+        if (ch < D) *reinterpret_cast<f16x4*>(O + (int64_t)(16 * pix + l15) * p.ldo + ch) = to_half(o);
+      }
+    MA_STAMP(6);
+    if (next < ntiles) normalise_rows(other);
+    MA_STAMP(7);
+#ifdef I2V_MA_STAMPS
+    if (stamps != nullptr && lane == 0 && it < 4) {
+      long long* st = stamps + (((int64_t)blockIdx.x * 4 + it) * H + wave) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) st[k] = stamp[k];
+    }
+#endif
+    __syncthreads();
+  }
+#undef MA_STAMP
+}
+
+template <int C, int D, int H>
+int launch_ma(const i2v_motion_attn_params& p, hipStream_t s) {
+  const size_t lds = 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16);
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  if (!attr_ok) I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_motion_attn_f16: %zu bytes of LDS refused", lds);
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
+  const int ntiles = (int)(p.rows / (MA_PIX * MA_F));
+  // one workgroup per CU (160 KB of LDS each), every workgroup the same number of tiles where the count allows it
+  const int per = (ntiles + cus - 1) / cus;
+  const int grid = (ntiles + per - 1) / per;
+  long long* stamps = nullptr;
+#ifdef I2V_MA_STAMPS
+  stamps = getenv("I2V_MA_STAMP_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("I2V_MA_STAMP_PTR"), nullptr, 0)) : nullptr;
+#endif
+  hipLaunchKernelGGL((motion_attn_kernel<C, D, H>), dim3((unsigned)grid), dim3(64 * H), lds, s, p, p.scale * 1.4426950408889634f,
+                     ntiles, stamps);
+  return i2v_check_launch("i2v_motion_attn_f16");
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int32_t i2v_motion_attn_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t frames) {
+  return rows > 0 && rows % (MA_PIX * MA_F) == 0 && rows / (MA_PIX * MA_F) < (1 << 24) && channels == 320 && heads == 8 &&
+         head_dim == 40 && frames == MA_F;
+}
+
+extern "C" int32_t i2v_motion_attn_pack_rows(int32_t heads, int32_t head_dim) { return heads * 3 * ((head_dim + 15) / 16) * 16; }
+
+extern "C" int i2v_motion_attn_f16(const i2v_motion_attn_params* pp, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_motion_attn_f16: null params");
+  const i2v_motion_attn_params& p = *pp;
+  I2V_CHECK_ARG(p.x && p.gamma && p.shift && p.w_qkv && p.out, "i2v_motion_attn_f16: null pointer");
+  I2V_CHECK_ARG(i2v_motion_attn_supported(p.rows, p.channels, p.heads, p.head_dim, p.frames),
+                "i2v_motion_attn_f16: rows %lld channels %d heads %d head_dim %d frames %d is not a fused shape "
+                "(i2v_motion_attn_supported)", (long long)p.rows, p.channels, p.heads, p.head_dim, p.frames);
+  I2V_CHECK_ARG(p.ldx >= p.channels && p.ldx % 8 == 0 && p.ldo >= p.channels && p.ldo % 4 == 0 && p.ld_shift >= p.channels &&
+                p.ld_shift % 4 == 0, "i2v_motion_attn_f16: row strides");
+  I2V_CHECK_ARG(al16(p.x) && al16(p.gamma) && al16(p.shift) && al16(p.w_qkv) && al16(p.out),
+                "i2v_motion_attn_f16: pointers must be 16-byte aligned");
+  return launch_ma<320, 40, 8>(p, reinterpret_cast<hipStream_t>(stream));
+}

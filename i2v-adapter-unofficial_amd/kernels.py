@@ -330,6 +330,64 @@ def temporal_attention(q, k, vt, *, n_pixels, frames, heads, head_dim, scale=Non
     return out
 
 
+def motion_attn_supported(rows, channels, heads, head_dim, frames):
+    """is the fused LayerNorm + q / k / v + temporal attention kernel implemented for this shape?"""
+    return bool(_lib.load().i2v_motion_attn_supported(rows, channels, heads, head_dim, frames))
+
+
+def pack_motion_qkv(wq, wk, wv, heads):
+    """`w_qkv` of i2v_motion_attn_f16: per head its rows of Wq, Wk, Wv, each zero-padded to a multiple of 16 rows, in
+    MFMA-fragment order [heads][3][C / 32][pad16(d) / 16][lane = 16 (k chunk) + row][8] (returned as [rows, C])."""
+    c_out, c_in = wq.shape
+    d = c_out // heads
+    dp = (d + 15) // 16 * 16
+    w = torch.zeros((heads, 3, dp, c_in), dtype=f16, device=wq.device)
+    for i, t in enumerate((wq, wk, wv)):
+        w[:, i, :d] = t.detach().to(f16).view(heads, d, c_in)
+    if heads * 3 * dp != _lib.load().i2v_motion_attn_pack_rows(heads, d):
+        raise RuntimeError("pack_motion_qkv: row count differs from i2v_motion_attn_pack_rows")
+    w = w.view(heads, 3, dp // 16, 16, c_in // 32, 4, 8).permute(0, 1, 4, 2, 5, 3, 6)      # [h, part, s, t, g, l15, 8]
+    return w.contiguous().view(heads * 3 * dp, c_in)
+
+
+def motion_attn_tables(gamma, beta, pe, frames):
+    """(gamma fp32 [C], shift fp32 [frames, C] = beta + pe[frame]): the LayerNorm constants of i2v_motion_attn_f16."""
+    return (gamma.detach().float().contiguous(),
+            (beta.detach().float()[None, :] + pe.detach().float()[:frames]).contiguous())
+
+
+def motion_attn(x, gamma32, shift32, w_qkv, *, heads, head_dim, frames, eps, scale=None, out=None):
+    """o = temporal attention over the `frames` rows of each pixel of LayerNorm(x) + pe, q / k / v projected inside
+    (i2v_motion_attn_f16); x [rows, C] in (batch, pixel, frame) order, (gamma32, shift32) from `motion_attn_tables`,
+    w_qkv from `pack_motion_qkv`."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    rows, c = x.shape
+    _req(w_qkv, "w_qkv")
+    for name, t in (("gamma32", gamma32), ("shift32", shift32)):
+        _req(t, name, dtype=torch.float32)
+    if c != heads * head_dim or tuple(gamma32.shape) != (c,) or tuple(shift32.shape) != (frames, c) or not shift32.is_contiguous():
+        raise ValueError(f"motion_attn: C {c} vs heads {heads} x head_dim {head_dim}, gamma {tuple(gamma32.shape)}, "
+                         f"shift {tuple(shift32.shape)} (expected [{frames}, {c}])")
+    if tuple(w_qkv.shape) != (lib.i2v_motion_attn_pack_rows(heads, head_dim), c) or not w_qkv.is_contiguous():
+        raise ValueError(f"motion_attn: w_qkv is {tuple(w_qkv.shape)} (pack_motion_qkv)")
+    if out is None:
+        out = torch.empty((rows, c), dtype=f16, device=x.device)
+    out, ldo = _mat(out, "out")
+    if tuple(out.shape) != (rows, c):
+        raise ValueError(f"motion_attn: out is {tuple(out.shape)}")
+    p = _lib.MotionAttnParams()
+    p.x, p.ldx = _p(x), ldx
+    p.gamma = _p(gamma32)
+    p.shift, p.ld_shift = _p(shift32), c
+    p.w_qkv = _p(w_qkv)
+    p.out, p.ldo = _p(out), ldo
+    p.rows, p.channels, p.heads, p.head_dim, p.frames = rows, c, heads, head_dim, frames
+    p.eps, p.scale = float(eps), float(head_dim) ** -0.5 if scale is None else float(scale)
+    _lib.check(lib.i2v_motion_attn_f16(C.byref(p), _stream()), "i2v_motion_attn_f16")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- norms
 def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_stat=1, out_perm=False, frames=0):
     """GroupNorm (+SiLU) of a token-major image batch x [N, H, W, C1] (optionally concatenated with x2 along C).

@@ -199,6 +199,37 @@ typedef struct i2v_tattn_params {
 int i2v_temporal_attention_f16(const i2v_tattn_params* p, i2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The whole attention sub-block of a motion module's temporal transformer block in one launch:
+ *     n = LayerNorm(x) * gamma + beta + pe[row % frames];  q, k, v = n Wq^T, n Wk^T, n Wv^T (no bias);
+ *     out[rows of pixel][head h] = softmax(q_h k_h^T * scale) v_h over the `frames` rows of each pixel
+ * for rows in (batch, pixel, frame) order -- `norm1 -> attn1` / `norm2 -> attn2` of the BasicTransformerBlock inside
+ * diffusers TransformerTemporalModel up to (not including) to_out (unet:232-244, 413-425, 607-619), which
+ * the caller applies with i2v_gemm_f16 (+ residual).  LayerNorm output, q, k, v and P are rounded to fp16 where the
+ * un-fused kernels store them; statistics, logits, softmax and accumulation in fp32.
+ * gamma: fp32 [channels]; shift: fp32 [frames][channels] = beta[c] + pe[frame][c] (the LayerNorm shift and the sinusoidal
+ * table of SURVEY A10 pre-added: both are constants of the module).
+ * w_qkv: per head its rows of Wq, Wk, Wv, each zero-padded to P = pad16(head_dim) rows, stored in MFMA-fragment order:
+ * fp16 [heads][3][channels / 32][P / 16][64][8] with element [h][part][s][t][l][j] = W_part[h * head_dim + 16 t + (l & 15)]
+ * [32 s + 8 (l >> 4) + j]  (i2v_motion_attn_pack_rows(heads, head_dim) * channels elements in all).
+ * Implemented for the SD-1.5 64^2 level: i2v_motion_attn_supported(...) != 0 (channels 320, 8 heads of 40, 16 frames,
+ * rows a multiple of 128); any other shape returns I2V_ERR_INVALID_ARG and callers use the un-fused kernels.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_motion_attn_params {
+  const void* x; int64_t ldx;           /* fp16 [rows, channels] */
+  const void* gamma;                    /* fp32 [channels] */
+  const void* shift; int64_t ld_shift;  /* fp32 [frames, channels] */
+  const void* w_qkv;
+  void* out; int64_t ldo;               /* fp16 [rows, channels] */
+  int64_t rows;
+  int32_t channels, heads, head_dim, frames;
+  float eps, scale;
+} i2v_motion_attn_params;
+
+int32_t i2v_motion_attn_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t frames);
+int32_t i2v_motion_attn_pack_rows(int32_t heads, int32_t head_dim);
+int i2v_motion_attn_f16(const i2v_motion_attn_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) on token-major fp16: statistics in fp32.
  *   stat group = (frames_per_stat consecutive images) x (all pixels) x (C / groups channels)
  *   frames_per_stat = 1: ResnetBlock2D norm1/norm2, Transformer2D norm, conv_norm_out

@@ -555,6 +555,47 @@ def test_temporal_attention_large_logits(dev, npix, frames, heads, d, amp):
     close(out.view(npix, frames, c), ref, rel=6e-4 * amp * amp, name="temporal attention, large logits")
 
 
+@pytest.mark.parametrize("npix,amp,strided", [(8, 1.0, False), (1000, 1.0, True), (256, 3.0, False), (8 * 771, 1.0, False)])
+def test_motion_attention_sub_block_fused(dev, npix, amp, strided):
+    """i2v_motion_attn_f16: LayerNorm + positional table, q / k / v projections and the attention over the 16 frames of a
+    pixel in one launch (channels 320, 8 heads of 40: the SD-1.5 64^2 level) against fp32 torch on the same fp16-rounded
+    operands, and against the un-fused kernels it replaces (LayerNorm -> q|k GEMM, V GEMM -> temporal attention)."""
+    k = K()
+    c, heads, d, frames, eps = 320, 8, 40, 16, 1e-5
+    rows = npix * frames
+    assert k.motion_attn_supported(rows, c, heads, d, frames) and not k.motion_attn_supported(rows + 16, c, heads, d, frames)
+    assert not k.motion_attn_supported(rows, 640, 8, 80, frames) and not k.motion_attn_supported(rows, c, heads, d, 8)
+    g = torch.Generator().manual_seed(npix)
+    ld = c + 64 if strided else c
+    xb = h(torch.randn(rows, ld, generator=g) * 1.5 + 0.3)
+    x = xb[:, :c]
+    gamma, beta = h(1 + 0.2 * torch.randn(c, generator=g)), h(0.1 * torch.randn(c, generator=g))
+    pe = h(torch.randn(32, c, generator=g))
+    wq, wk, wv = (h(torch.randn(c, c, generator=g) * amp * c ** -0.5) for _ in range(3))
+    wv = wv / amp
+    n = h(F.layer_norm(x, (c,), gamma, beta, eps) + pe[:frames].repeat(npix, 1))         # (the kernel rounds n to fp16)
+    q, kk, v = h(n @ wq.T), h(n @ wk.T), h(n @ wv.T)
+    ref = _attn_ref(q.view(npix, frames, c), kk.view(npix, frames, c), v.view(npix, frames, c), heads, 1).reshape(rows, c)
+    D = lambda t: t.half().to(dev)
+    w = k.pack_motion_qkv(D(wq), D(wk), D(wv), heads)
+    assert tuple(w.shape) == (8 * 3 * 48, c)
+    xd = D(xb)[:, :c]
+    g32, s32 = k.motion_attn_tables(D(gamma), D(beta), D(pe), frames)
+    assert g32.dtype == s32.dtype == torch.float32 and tuple(s32.shape) == (frames, c)
+    out = k.motion_attn(xd, g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps)
+    close(out, ref, rel=3e-3 * amp * amp, name="fused motion attention vs fp32 torch")
+    # the kernels it replaces, on the same device operands
+    nl = k.layernorm(xd.contiguous(), D(gamma), D(beta), eps, pe=D(pe), pe_period=frames)
+    qk = k.gemm(nl, D(torch.cat([wq, wk], 0)))
+    vv = k.gemm(nl, D(wv))
+    old = k.temporal_attention(qk[:, :c], qk[:, c:], k.transpose_tokens(vv, frames), n_pixels=npix, frames=frames, heads=heads,
+                               head_dim=d)
+    close(out, old, rel=1.5e-3 * amp * amp, name="fused motion attention vs the un-fused kernels")
+    assert torch.equal(out, k.motion_attn(xd, g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps))
+    with pytest.raises(Exception, match="not a fused shape"):
+        k.motion_attn(xd[:rows - 16], g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps)
+
+
 @pytest.mark.parametrize("n,hh,ww,c1,c2,groups,fps,silu,perm", [
     (4, 8, 8, 32, 0, 8, 1, True, False), (2, 16, 16, 320, 0, 32, 1, True, False),
     (4, 8, 8, 64, 0, 32, 4, False, True), (2, 20, 20, 64, 32, 32, 1, True, False),
