@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/i2v_hip.h"
 
 typedef _Float16 f16;
@@ -104,6 +106,28 @@ __device__ __forceinline__ float lane_xor32_max(float x) {
   unsigned a = __builtin_bit_cast(unsigned, x), b = a;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+
+// sums over lanes l ^ 16 / l ^ 32 the same way (see lane_xor16_max for why these are inline assembly)
+__device__ __forceinline__ float lane_xor16_sum(float x) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float lane_xor32_sum(float x) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// sum over the 8 lanes l ^ {0..7} on the VALU (DPP: two quad permutes and the mirror of a half row), not three LDS round trips
+__device__ __forceinline__ float sum_lanes8(float x) {
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});       // quad_perm [1, 0, 3, 2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
+  x += dpp(x, std::integral_constant<int, 0x141>{});      // row_half_mirror: lane i <-> 7 - i of each 8
+  return x;
 }
 
 // XCD-aware block remap (guide T1, bijective form): blocks b and b+8 share an XCD/L2, so give each XCD a

@@ -117,9 +117,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
           v[j][e] = (float)xv[half][j][e];
           s += v[j][e];
         }
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
+      s = sum_lanes8(s);
       const float mean = s / (float)C;
       float q = 0.f;
 #pragma unroll
@@ -129,9 +127,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
           v[j][e] -= mean;
           q = fmaf(v[j][e], v[j][e], q);
         }
-      q += __shfl_xor(q, 1, 64);
-      q += __shfl_xor(q, 2, 64);
-      q += __shfl_xor(q, 4, 64);
+      q = sum_lanes8(q);
       const float rstd = rsqrtf(q / (float)C + p.eps);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -228,16 +224,14 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
         sv[r] = sacc[r] * scale_log2;
         mx = fmaxf(mx, sv[r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = lane_xor32_max(lane_xor16_max(mx));
       float ls = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         sv[r] = __builtin_amdgcn_exp2f(sv[r] - mx);
         ls += sv[r];
       }
-      ls += __shfl_xor(ls, 16, 64);
-      ls += __shfl_xor(ls, 32, 64);
+      ls = lane_xor32_sum(lane_xor16_sum(ls));
       const float inv = 1.0f / ls;
       ph[pix] = f16x4{(f16)(sv[0] * inv), (f16)(sv[1] * inv), (f16)(sv[2] * inv), (f16)(sv[3] * inv)};
     }
@@ -254,14 +248,31 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
     project(panel, 2, std::false_type{});
     MA_STAMP(5);
     f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
+    // Lane (g, l15) holds channels 16 t + 4 g .. + 3 of frame l15: 8 bytes.  v_permlane16_swap pairs the lane groups g, g ^ 1 so
+    // that even groups end with 8 consecutive channels of tile 0 and odd groups with 8 of tile 1 -- one 16-byte store per lane
+    // for two tiles (as 8-byte stores the output cost 6.5k of a tile's 50k cycles: the stores are issue-bound).
+    static_assert(DT == 3 && D == 40, "store pattern of three 16-channel tiles holding 40 channels");
 #pragma unroll
-    for (int pix = 0; pix < MA_PIX; ++pix)
+    for (int pix = 0; pix < MA_PIX; ++pix) {
+      u32x2 oh[DT];
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const f32x4 o = mfma16x16x16(to_half(acc[pix][t]), ph[pix], f32x4{0.f, 0.f, 0.f, 0.f});
-        const int ch = 16 * t + 4 * g;
-        if (ch < D) *reinterpret_cast<f16x4*>(O + (int64_t)(16 * pix + l15) * p.ldo + ch) = to_half(o);
+      for (int t = 0; t < DT; ++t)
+        oh[t] = __builtin_bit_cast(u32x2, to_half(mfma16x16x16(to_half(acc[pix][t]), ph[pix], f32x4{0.f, 0.f, 0.f, 0.f})));
+      u32x2 a = oh[0], b = oh[1], c2 = oh[2], d2 = oh[2];
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                   "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+                   : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(c2[0]), "+v"(d2[0]), "+v"(c2[1]), "+v"(d2[1]));
+      f16* orow = O + (int64_t)(16 * pix + l15) * p.ldo;
+      const u32x4 v01 = {a[0], a[1], b[0], b[1]};                  // even g: tile 0 channels 4 g .. + 7; odd g: tile 1 channels 4 (g - 1) ..
+      const u32x4 v2 = {c2[0], c2[1], d2[0], d2[1]};               // g = 0: tile 2 channels 0 .. 7 (32 .. 39 of the head)
+#ifdef I2V_MA_NOSTORE
+      if (p.ldo < 0)
+#endif
+      {
+        *reinterpret_cast<u32x4*>(orow + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g)) = v01;
+        if (g == 0) *reinterpret_cast<u32x4*>(orow + 32) = v2;
       }
+    }
     MA_STAMP(6);
     if (next < ntiles) normalise_rows(other);
     MA_STAMP(7);
@@ -319,7 +330,7 @@ extern "C" int i2v_motion_attn_f16(const i2v_motion_attn_params* pp, i2v_stream_
   I2V_CHECK_ARG(i2v_motion_attn_supported(p.rows, p.channels, p.heads, p.head_dim, p.frames),
                 "i2v_motion_attn_f16: rows %lld channels %d heads %d head_dim %d frames %d is not a fused shape "
                 "(i2v_motion_attn_supported)", (long long)p.rows, p.channels, p.heads, p.head_dim, p.frames);
-  I2V_CHECK_ARG(p.ldx >= p.channels && p.ldx % 8 == 0 && p.ldo >= p.channels && p.ldo % 4 == 0 && p.ld_shift >= p.channels &&
+  I2V_CHECK_ARG(p.ldx >= p.channels && p.ldx % 8 == 0 && p.ldo >= p.channels && p.ldo % 8 == 0 && p.ld_shift >= p.channels &&
                 p.ld_shift % 4 == 0, "i2v_motion_attn_f16: row strides");
   I2V_CHECK_ARG(al16(p.x) && al16(p.gamma) && al16(p.shift) && al16(p.w_qkv) && al16(p.out),
                 "i2v_motion_attn_f16: pointers must be 16-byte aligned");

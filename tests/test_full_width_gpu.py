@@ -144,9 +144,23 @@ def test_full_width_motion_module(dev, c, hw, frames):
               num_positional_embeddings=32)
     o, m = _module_pair(pkg().TransformerTemporalModel, O, kw, dev, seed=c + hw + 1)
     x = h(torch.randn(2 * frames, c, hw, hw, generator=torch.Generator().manual_seed(c + 1)))
+    from i2v_adapter_unofficial_amd import blocks, kernels as K
+    fused_shape = K.motion_attn_supported(2 * frames * hw * hw, c, 8, c // 8, frames)
+    assert fused_shape == (c == 320 and frames == 16)       # the 64^2-level shape of SD-1.5 runs i2v_motion_attn_f16
     with torch.no_grad():
-        compare(m(x.half().to(dev), num_frames=frames)[0], o(x, num_frames=frames)[0], rel=MODULE_REL_TOL,
-                name=f"full-width motion module C={c} {hw}x{hw} F={frames}")
+        ref = o(x, num_frames=frames)[0]
+        got = m(x.half().to(dev), num_frames=frames)[0]
+        compare(got, ref, rel=MODULE_REL_TOL, name=f"full-width motion module C={c} {hw}x{hw} F={frames}")
+        if fused_shape:      # the same module on the un-fused kernels (I2V_MOTION_FUSED=0): both against the oracle, and close
+            assert blocks.FUSED_MOTION_ATTN
+            blocks.FUSED_MOTION_ATTN = False
+            try:
+                plain = m(x.half().to(dev), num_frames=frames)[0]
+            finally:
+                blocks.FUSED_MOTION_ATTN = True
+            compare(plain, ref, rel=MODULE_REL_TOL, name=f"full-width motion module, un-fused attention sub-block C={c}")
+            compare(got, plain, rel=MODULE_REL_TOL, name=f"motion module fused vs un-fused C={c}")
+            assert not torch.equal(got, plain)               # (different roundings: the two paths really differ)
 
 
 @pytest.mark.parametrize("kind,c,hw,frames,gain", [("t2d", 320, 32, 16, 4.0), ("t2d", 1280, 8, 16, 3.0), ("motion", 320, 32, 16, 4.0),
