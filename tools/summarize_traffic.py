@@ -18,6 +18,8 @@ def classify(name):
         return "conv3x3" if m.group(3) == "1" else "gemm"
     if "splitk_reduce" in name:
         return "splitk_reduce"
+    if "motion_attn" in name:
+        return "motion_attn"
     if "tattn" in name:
         return "temporal_attention"
     if "attn_kernel" in name:
