@@ -927,6 +927,33 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const f16* __restrict__ y
   }
 }
 
+// the same seed from an fp32 prediction and an fp32 target (F.mse_loss(model_pred.float(), target.float()),
+// train_image_to_video.py:848): only the emitted gradient is fp16; rowsq[m] = sum_c (y - t)^2 of the unmasked rows (0 on the
+// first frame of a clip) is the loss's numerator, summed by the caller in a fixed order
+__global__ __launch_bounds__(256) void mse_grad_f32_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                           f16* __restrict__ gout, float* __restrict__ rowsq, int64_t n_img, int L,
+                                                           int C, int frames, float coef) {
+  const int64_t rows = n_img * L;
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < rows; row += (int64_t)gridDim.x * 256) {
+    const bool first = ((row / L) % frames) == 0;
+    float sq = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(y + row * C + c0), a1 = *reinterpret_cast<const f32x4*>(y + row * C + c0 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(t + row * C + c0), b1 = *reinterpret_cast<const f32x4*>(t + row * C + c0 + 4);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = first ? 0.f : a0[e] - b0[e], d1 = first ? 0.f : a1[e] - b1[e];
+        sq = fmaf(d0, d0, fmaf(d1, d1, sq));
+        o[e] = (f16)(coef * d0);
+        o[4 + e] = (f16)(coef * d1);
+      }
+      *reinterpret_cast<f16x8*>(gout + row * C + c0) = o;
+    }
+    rowsq[row] = sq;
+  }
+}
+
 // out = a + b (gradients meeting at a skip connection / a residual branch)
 __global__ __launch_bounds__(256) void add_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ out,
                                                   int64_t nvec) {
@@ -1316,6 +1343,16 @@ extern "C" int i2v_masked_mse_grad_f16(const void* y, const void* target, void* 
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(y),
                      reinterpret_cast<const f16*>(target), reinterpret_cast<f16*>(grad), n_img, tokens, channels, frames, coef);
   return i2v_check_launch("i2v_masked_mse_grad_f16");
+}
+
+extern "C" int i2v_masked_mse_grad_f32(const float* y, const float* target, void* grad, float* rowsq, int64_t n_img, int32_t tokens,
+                                       int32_t channels, int32_t frames, float coef, i2v_stream_t stream) {
+  I2V_CHECK_ARG(y && target && grad && rowsq && n_img > 0 && tokens > 0 && channels > 0 && channels % 8 == 0 && frames > 0 &&
+                    n_img % frames == 0 && al16(y) && al16(target) && al16(grad),
+                "i2v_masked_mse_grad_f32: bad arguments");
+  hipLaunchKernelGGL(mse_grad_f32_kernel, dim3(ew_grid(n_img * tokens)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, target,
+                     reinterpret_cast<f16*>(grad), rowsq, n_img, tokens, channels, frames, coef);
+  return i2v_check_launch("i2v_masked_mse_grad_f32");
 }
 
 extern "C" int i2v_add_f16(const void* a, const void* b, void* out, int64_t n, i2v_stream_t stream) {

@@ -893,6 +893,21 @@ def masked_mse_grad(y, target, frames, coef):
     return g
 
 
+def masked_mse_grad_f32(y, target, frames, coef):
+    """the same seed from an fp32 prediction and target [n_img, tokens, C] (train_image_to_video.py:848: the loss is taken in
+    fp32).  Returns (fp16 gradient, fp32 [n_img * tokens] row sums of (y - target)^2 over the unmasked rows)."""
+    lib = _lib.load()
+    _req(y, "y", dtype=torch.float32)
+    _req(target, "target", dtype=torch.float32)
+    if y.dim() != 3 or y.shape != target.shape or not y.is_contiguous() or not target.is_contiguous():
+        raise ValueError("masked_mse_grad_f32: y / target must be equal-shape contiguous [n_img, tokens, C]")
+    g = torch.empty(y.shape, dtype=f16, device=y.device)
+    rowsq = torch.empty((y.shape[0] * y.shape[1],), dtype=torch.float32, device=y.device)
+    _lib.check(lib.i2v_masked_mse_grad_f32(_p(y), _p(target), _p(g), _p(rowsq), y.shape[0], y.shape[1], y.shape[2], frames,
+                                           float(coef), _stream()), "i2v_masked_mse_grad_f32")
+    return g, rowsq
+
+
 def groupnorm_bwd(x, dy, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_stat=1):
     """input gradient of groupnorm(x [, x2], ...): dy [N, H, W, C1 + C2] -> dx [N, H, W, C1] (, dx2 [N, H, W, C2])."""
     lib = _lib.load()

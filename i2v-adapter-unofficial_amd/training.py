@@ -521,7 +521,7 @@ class UNetAdapterTrainer:
     @torch.no_grad()
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
         """sample (B, F, C, H, W) on the GPU; added_cond_kwargs={"image_embeds": ...} when the IP-Adapter is installed (the
-        reference's training step passes them, train_image_to_video.py:843); returns the prediction as tokens fp16
+        reference's training step passes them, train_image_to_video.py:843); returns the prediction as tokens fp32
         [B * F, H, W, 8] (4 channels + zeros)."""
         u = self.unet
         b, F, c, hh, ww = sample.shape
@@ -598,8 +598,9 @@ class UNetAdapterTrainer:
             return bb
 
         w_out = _memo.get("conv_out_pad8", (cw,), _pad_w)
+        # (fp32 out of the accumulators: the loss is F.mse_loss(model_pred.float(), target.float()), train_image_to_video.py:848)
         y = K.conv3x3(a, _memo.get("conv_out_pad8_packed", (cw,), lambda: pack_conv3x3(w_out)),
-                      _memo.get("conv_out_bias_pad8", (cb,), _pad_b))
+                      _memo.get("conv_out_bias_pad8", (cb,), _pad_b), out_f32=True)
         self.saved = dict(tape=tape, x_last=x, y=y, F=F, w_out=w_out)
         return y
 
@@ -611,12 +612,11 @@ class UNetAdapterTrainer:
         y, F = s["y"], s["F"]
         n, hh, ww, _ = y.shape
         b, c = n // F, target.shape[2]
-        tgt = K.nchw_to_tokens(target.to(device=y.device, dtype=torch.float32).reshape(n, c, hh, ww).contiguous(), 8)
+        tgt = torch.zeros((n, hh * ww, 8), dtype=torch.float32, device=y.device)          # fp32 target tokens, 4 + 4 zero channels
+        tgt[:, :, :c] = target.to(device=y.device, dtype=torch.float32).reshape(n, c, hh * ww).transpose(1, 2)
         count = float(b * (F - 1) * c * hh * ww)
-        seed = K.masked_mse_grad(y.view(n, hh * ww, 8), tgt.view(n, hh * ww, 8), F, 2.0 * loss_scale / count)
-        # loss = sum (coef (y - t))^2 / (coef^2 count): the row sums on the GPU, their total is plumbing
-        per_row = K.rowdot_heads(seed.view(-1, 8), seed.view(-1, 8), rows_per_batch=hh * ww, heads=1, head_dim=8)
-        loss = per_row.sum() * (count / (2.0 * loss_scale) ** 2)
+        seed, rowsq = K.masked_mse_grad_f32(y.view(n, hh * ww, 8), tgt, F, 2.0 * loss_scale / count)
+        loss = rowsq.sum() / count         # (the row sums on the GPU in fp32; their total is plumbing)
         g = K.conv3x3(seed.view(n, hh, ww, 8), conv_dgrad_weight(s["w_out"], cout_pad=8))
         g = K.groupnorm_bwd(s["x_last"], g, p["g_out"], p["be_out"], u.config.norm_num_groups, u.config.norm_eps, silu=True)
         grads, dskip = {}, {}

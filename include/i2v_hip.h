@@ -435,6 +435,11 @@ int i2v_colsum_prod_f32(const void* a, int64_t lda, const void* b, int64_t ldb, 
  * coef = 2 * loss_scale / count is the caller's.  y, target, grad fp16 [n_img, tokens, channels]. */
 int i2v_masked_mse_grad_f16(const void* y, const void* target, void* grad, int64_t n_img, int32_t tokens, int32_t channels,
                             int32_t frames, float coef, i2v_stream_t stream);
+/* The same seed from an fp32 prediction and an fp32 target -- F.mse_loss(model_pred.float(), target.float()),
+ * train_image_to_video.py:848 -- with grad in fp16 and rowsq[img * tokens + l] = sum_c (y - target)^2 (0 on masked rows): the
+ * loss is sum(rowsq) / count, summed by the caller in a fixed order. */
+int i2v_masked_mse_grad_f32(const float* y, const float* target, void* grad, float* rowsq, int64_t n_img, int32_t tokens,
+                            int32_t channels, int32_t frames, float coef, i2v_stream_t stream);
 /* GroupNorm (+SiLU) backward, input gradient only (native_group_norm_backward + silu_backward behind ResnetBlock2D norm1 /
  * norm2, Transformer2D norm, the motion modules' clip-wide norm and conv_norm_out; the norms are frozen): p describes the
  * FORWARD call (x [, x2], gamma, beta, n_img, hw, groups, frames_per_stat, eps, silu; y and out_perm unused), dy is the

@@ -323,7 +323,7 @@ def test_training_step_full_width_vs_autograd(dev, pair):
     (2 f x 256 x 256: latents 32 x 32) against torch autograd over the fp32 oracle: the loss of
     train_image_to_video.py:848-856 (MSE without the first frame) and the gradient of all 16 x 3 trainable adapter tensors
     (unet:979-1026) AND, as under `--update_motion_modules` (train_image_to_video.py:452, 669; unet:984-999), of all 21 x 26
-    motion-module tensors.  Tolerances as on the reduced UNet (tests/test_training_gpu.py): loss 5e-3 rel, gradients 2e-2 of
+    motion-module tensors.  Tolerances as on the reduced UNet (tests/test_training_gpu.py): loss 5e-4 rel (fp32 head: measured 6e-6), gradients 2e-2 of
     their largest entry (measured: <= 4.2e-3, the worst on a 1e-5-sized gradient; asserted 8e-3)."""
     from i2v_adapter_unofficial_amd.training import UNetAdapterTrainer
     ou, hu = pair
@@ -352,7 +352,7 @@ def test_training_step_full_width_vs_autograd(dev, pair):
         got_pred = y[..., :4].float().cpu().permute(0, 3, 1, 2).reshape(pred.shape)
         compare(got_pred, pred.detach(), abs_tol=FWD_ABS_TOL, name="training forward, SD-1.5 width")
         got_loss, grads = tr.backward(target.to(dev), loss_scale=2.0 ** 12)
-        assert abs(got_loss.item() - loss.item()) <= 5e-3 * abs(loss.item()), (got_loss.item(), loss.item())
+        assert abs(got_loss.item() - loss.item()) <= 5e-4 * abs(loss.item()), (got_loss.item(), loss.item())   # measured <= 7e-6
         assert set(grads) == set(train)
         worst = {".i2v_adapter.": 0.0, ".motion_modules.": 0.0}
         for name, prm in train.items():

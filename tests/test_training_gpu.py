@@ -210,6 +210,14 @@ def test_layernorm_geglu_backward_and_sums(dev):
     ref[0::4] = 0
     compare(gr, ref, rel=1e-3, name="masked MSE seed gradient")
     assert (gr[0] == 0).all() and (gr[4] == 0).all()
+    # the fp32 form (the loss of train_image_to_video.py:848 is taken on .float() operands): fp16 seed, fp32 row sums of squares
+    y32 = torch.randn(8, 16, 32, generator=g)
+    t32 = torch.randn(8, 16, 32, generator=g)
+    g32, rowsq = K.masked_mse_grad_f32(y32.to(dev), t32.to(dev), frames=4, coef=0.25)
+    d = (y32 - t32).double()
+    d[0::4] = 0
+    assert g32.dtype == torch.float16 and torch.equal(g32.float().cpu(), (0.25 * d.float()).half().float())
+    assert torch.allclose(rowsq.double().cpu().view(8, 16), (d * d).sum(-1), rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("dim,heads,L,frames,clips", [(320, 8, 256, 4, 2), (128, 4, 64, 2, 1)])
@@ -480,7 +488,7 @@ def test_unet_training_step_vs_autograd(dev, ip, motion):
     got_pred = y[..., :4].float().cpu().permute(0, 3, 1, 2).reshape(pred.shape)
     compare(got_pred, pred, rel=6e-3, name="training forward of the reduced UNet")
     got_loss, grads = tr.backward(target.to(dev), loss_scale=2.0 ** 12)
-    assert abs(got_loss.item() - loss.item()) <= 5e-3 * abs(loss.item()), (got_loss.item(), loss.item())
+    assert abs(got_loss.item() - loss.item()) <= 5e-4 * abs(loss.item()), (got_loss.item(), loss.item())   # measured <= 7e-6
     assert set(grads) == set(train)
     worst = 0.0
     for name, prm in train.items():
