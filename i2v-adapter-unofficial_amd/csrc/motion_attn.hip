@@ -21,7 +21,8 @@
 //
 // What the in-kernel stamps (tools/motion_attn_probe.py, -DI2V_MA_STAMPS) showed and the structure answers:
 //   * the two waves of a SIMD (w and w + 4) do not share the matrix pipe evenly -- the older one runs its three passes in 25k
-//     cycles, the younger needs 38k, and alternating s_setprio per K step made both slower (121 -> 145 us) -- so no wave waits
+//     cycles, the younger needs 38k; alternating s_setprio per K step made both slower (121 -> 145 us), raising the younger wave
+//     through the q pass evened them out (45k / 48k) at the same total: the SIMD's issue port is the bound -- so no wave waits
 //     for another inside a tile: the workgroup is persistent over its tiles with TWO panels, a wave that has finished tile i
 //     normalises its 16 rows of tile i + 1 into the other panel straight away, and there is one barrier per tile;
 //   * the LayerNorm phase was a quarter of the tile (12k of 50k cycles: an HBM round trip, then 11 VALU operations per element):
