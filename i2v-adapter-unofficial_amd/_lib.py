@@ -168,6 +168,8 @@ SIGNATURES = {
     "i2v_geglu_f16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int32, _P]),
     "i2v_colsum_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
     "i2v_colsum_prod_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
+    "i2v_colsum_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "i2v_colsum_det_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, _P]),
     "i2v_masked_mse_grad_f16": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
     "i2v_masked_mse_grad_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
     "i2v_groupnorm_bwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

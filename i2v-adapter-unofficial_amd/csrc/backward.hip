@@ -909,6 +909,35 @@ __global__ __launch_bounds__(256) void colsum_prod_kernel(const f16* __restrict_
   if (rl == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// The same sums with a run-to-run identical result (the atomics above make bias / gain gradients depend on block
+// scheduling): every 256-row block writes its partial, one thread per column adds the partials in block order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const f16* __restrict__ a, int64_t lda, const f16* __restrict__ b,
+                                                             int64_t ldb, float* __restrict__ partial, int64_t rows, int cols,
+                                                             int64_t rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < cols) {
+    if (b != nullptr)
+      for (int64_t r = r0 + rl; r < r1; r += 4) s += (float)a[r * lda + c] * (float)b[r * ldb + c];
+    else
+      for (int64_t r = r0 + rl; r < r1; r += 4) s += (float)a[r * lda + c];
+  }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols)
+    partial[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks,
+                                                           int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int i = 0; i < nblocks; ++i) s += partial[(int64_t)i * cols + c];
+  out[c] += s;
+}
+
 // g[m][c] = coef (y[m][c] - t[m][c]) for tokens of frames >= 1, 0 for the first frame of every clip
 __global__ __launch_bounds__(256) void mse_grad_kernel(const f16* __restrict__ y, const f16* __restrict__ t,
                                                        f16* __restrict__ gout, int64_t n_img, int L, int C, int frames,
@@ -1332,6 +1361,24 @@ extern "C" int i2v_colsum_prod_f32(const void* a, int64_t lda, const void* b, in
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(a), lda, reinterpret_cast<const f16*>(b),
                      ldb, out, rows, cols, rpb);
   return i2v_check_launch("i2v_colsum_prod_f32");
+}
+
+extern "C" int64_t i2v_colsum_workspace_bytes(int64_t rows, int32_t cols) {
+  return rows > 0 && cols > 0 ? i2v_cdiv(rows, 256) * (int64_t)cols * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int i2v_colsum_det_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int32_t cols,
+                                  void* workspace, i2v_stream_t stream) {
+  I2V_CHECK_ARG(a && out && workspace && rows > 0 && cols > 0 && lda >= cols && (b == nullptr || ldb >= cols) &&
+                    i2v_cdiv(rows, 256) < (1 << 30), "i2v_colsum_det_f32: bad arguments");
+  const int64_t rpb = 256, nb = i2v_cdiv(rows, rpb);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)i2v_cdiv(cols, 64), (unsigned)nb), dim3(256), 0, s,
+                     reinterpret_cast<const f16*>(a), lda, reinterpret_cast<const f16*>(b), ldb, reinterpret_cast<float*>(workspace),
+                     rows, cols, rpb);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)i2v_cdiv(cols, 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float*>(workspace), out, (int)nb, cols);
+  return i2v_check_launch("i2v_colsum_det_f32");
 }
 
 extern "C" int i2v_masked_mse_grad_f16(const void* y, const void* target, void* grad, int64_t n_img, int32_t tokens,

@@ -854,19 +854,32 @@ def geglu_bwd(h, dy):
     return dh
 
 
+_colsum_ws = {}
+
+
+def _colsum_workspace(lib, rows, cols, device):
+    """scratch of the fixed-order column sums, one per device, grown on demand (stream-ordered use)"""
+    need = lib.i2v_colsum_workspace_bytes(rows, cols)
+    ws = _colsum_ws.get(device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _colsum_ws[device] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=device)
+    return ws
+
+
 def colsum(x, out=None):
-    """fp32 [cols] += sum over the rows of fp16 x (bias gradient)."""
+    """fp32 [cols] += sum over the rows of fp16 x (bias gradient); block sums added in a fixed order: bit-reproducible."""
     lib = _lib.load()
     x, ldx = _mat(x, "x")
     if out is None:
         out = torch.zeros((x.shape[1],), dtype=torch.float32, device=x.device)
     _req(out, "out", dtype=torch.float32)
-    _lib.check(lib.i2v_colsum_f32(_p(x), ldx, _p(out), x.shape[0], x.shape[1], _stream()), "i2v_colsum_f32")
+    ws = _colsum_workspace(lib, x.shape[0], x.shape[1], x.device)
+    _lib.check(lib.i2v_colsum_det_f32(_p(x), ldx, None, 0, _p(out), x.shape[0], x.shape[1], _p(ws), _stream()), "i2v_colsum_det_f32")
     return out
 
 
 def colsum_prod(a, b, out=None):
-    """fp32 [cols] += sum over the rows of a o b (fp16 matrices of one shape): the gain gradient of a norm."""
+    """fp32 [cols] += sum over the rows of a o b (fp16 matrices of one shape): the gain gradient of a norm; fixed order."""
     lib = _lib.load()
     a, lda = _mat(a, "a")
     b, ldb = _mat(b, "b")
@@ -875,7 +888,8 @@ def colsum_prod(a, b, out=None):
     if out is None:
         out = torch.zeros((a.shape[1],), dtype=torch.float32, device=a.device)
     _req(out, "out", dtype=torch.float32)
-    _lib.check(lib.i2v_colsum_prod_f32(_p(a), lda, _p(b), ldb, _p(out), a.shape[0], a.shape[1], _stream()), "i2v_colsum_prod_f32")
+    ws = _colsum_workspace(lib, a.shape[0], a.shape[1], a.device)
+    _lib.check(lib.i2v_colsum_det_f32(_p(a), lda, _p(b), ldb, _p(out), a.shape[0], a.shape[1], _p(ws), _stream()), "i2v_colsum_det_f32")
     return out
 
 

@@ -430,6 +430,13 @@ int i2v_colsum_f32(const void* x, int64_t ldx, float* out, int64_t rows, int32_t
  * motion modules' norms train under `--update_motion_modules` (train_image_to_video.py:452, 669; unet:984-999). */
 int i2v_colsum_prod_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int32_t cols,
                         i2v_stream_t stream);
+/* Both sums with a result that does not depend on block scheduling (the two above add their 256-row block sums with fp32
+ * atomics): out[c] += sum_r a[r][c] (b == NULL) or sum_r a[r][c] b[r][c]; the block sums go to `workspace`
+ * (i2v_colsum_workspace_bytes(rows, cols) bytes) and are added in block order.  What the training step uses: every
+ * data-parallel rank and every rerun gets the same bias / gain gradients bit for bit. */
+int64_t i2v_colsum_workspace_bytes(int64_t rows, int32_t cols);
+int i2v_colsum_det_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int32_t cols,
+                       void* workspace, i2v_stream_t stream);
 /* Seed gradient of the training loss (train_image_to_video.py:848-856: MSE summed over every frame but the first of each
  * clip, divided by the number of unmasked elements): grad[img][l][c] = coef (y - target) for img % frames != 0, else 0;
  * coef = 2 * loss_scale / count is the caller's.  y, target, grad fp16 [n_img, tokens, channels]. */

@@ -204,6 +204,12 @@ def test_layernorm_geglu_backward_and_sums(dev):
     tt = K.transpose_tokens(t.half().to(dev), 77).float().cpu()
     assert tt.shape == (3, 48, 80) and torch.equal(tt[:, :, :77], t.view(3, 77, 48).transpose(1, 2)) and (tt[:, :, 77:] == 0).all()
     compare(K.colsum(dn.half().to(dev)), dn.sum(0), rel=1e-3, name="column sums")
+    big = h(torch.randn(70000, 72, generator=g))                # 274 row blocks: the order of their sums is fixed
+    bd = big.half().to(dev)
+    c1, c2 = K.colsum(bd[:, :70]), K.colsum(bd[:, :70])
+    assert torch.equal(c1, c2) and torch.allclose(c1.double().cpu(), big[:, :70].double().sum(0), rtol=1e-5, atol=1e-3)
+    p1, p2 = K.colsum_prod(bd[:, :70], bd[:, 2:]), K.colsum_prod(bd[:, :70], bd[:, 2:])
+    assert torch.equal(p1, p2) and torch.allclose(p1.double().cpu(), (big[:, :70].double() * big[:, 2:].double()).sum(0), rtol=1e-5, atol=1e-3)
     y, tg = h(torch.randn(8, 16, 32, generator=g)), h(torch.randn(8, 16, 32, generator=g))
     gr = K.masked_mse_grad(y.half().to(dev), tg.half().to(dev), frames=4, coef=0.25).float().cpu()
     ref = 0.25 * (y - tg)
@@ -270,7 +276,7 @@ def test_adapter_block_backward_vs_autograd(dev, dim, heads, L, frames, clips):
             name=f"d loss / d i2v_adapter.to_out.0.weight (C={dim})")
     compare(grads["i2v_adapter.to_out.0.bias"], train[2].grad, rel=GRAD_REL_TOL, name=f"d loss / d i2v_adapter.to_out.0.bias (C={dim})")
     again = tr.backward(seed.view(-1, dim), loss_scale=loss_scale)
-    assert all(torch.equal(grads[k], again[k]) for k in grads if k != "i2v_adapter.to_out.0.bias")   # (bias: fp32 atomics)
+    assert all(torch.equal(grads[k], again[k]) for k in grads)      # (the bias sums too: fixed-order block sums, no atomics)
 
 
 # ---------------------------------------------------------------------------------------------- the frozen layers around
