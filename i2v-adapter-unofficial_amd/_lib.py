@@ -103,6 +103,19 @@ class MotionAttnParams(C.Structure):
     ]
 
 
+class CrossAttnFusedParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("w_q", C.c_void_p),
+        ("ctx_frag", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("rows", C.c_int64), ("rows_per_ctx", C.c_int64),
+        ("channels", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("ctx_len", C.c_int32),
+        ("eps", C.c_float), ("scale", C.c_float),
+    ]
+
+
 class GnParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("c1", C.c_int32),
@@ -142,6 +155,10 @@ SIGNATURES = {
     "i2v_motion_attn_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "i2v_motion_attn_pack_rows": (C.c_int32, [C.c_int32, C.c_int32]),
     "i2v_motion_attn_f16": (C.c_int, [C.POINTER(MotionAttnParams), _P]),
+    "i2v_cross_attn_fused_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "i2v_cross_attn_fused_pack_rows": (C.c_int32, [C.c_int32, C.c_int32]),
+    "i2v_cross_attn_fused_ctx_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "i2v_cross_attn_fused_f16": (C.c_int, [C.POINTER(CrossAttnFusedParams), _P]),
     "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_groupnorm_f16": (C.c_int, [C.POINTER(GnParams), _P]),
     "i2v_groupnorm_fold_f16": (C.c_int, [C.POINTER(GnParams), _P, C.c_int64, _P, C.c_int32, _P, _P, _P]),

@@ -128,6 +128,7 @@ class ProjectedContext:
     def __init__(self, text, ip):
         self.text, self.ip = text, ip
         self.kv = {}                       # Attention module -> (k, vt, k_ip, vt_ip)
+        self.frag = {}                     # Attention module -> K / V as MFMA fragments (K.pack_ctx_fragments), made on first use
 
     @property
     def shape(self):
@@ -414,9 +415,8 @@ class Attention(HipModule):
             vtip = K.project_vt(ctx_ip.view(-1, dc), p["wv_ip"], ctx_ip.shape[1], out=o[3])
         return k, vt, kip, vtip
 
-    def _cross(self, q, ctx_text, ctx_ip, batch_q, lq, kv_group):
-        """softmax(q Kt^T) Vt (+ ip_scale * softmax(q Kip^T) Vip) for context tensors [Bc, L, D] (or a
-        ProjectedContext holding this layer's K / V^T)."""
+    def context_kv(self, ctx_text, ctx_ip):
+        """(k, vt, k_ip, vt_ip, text length, image-token length) of a context [Bc, L, D] or a ProjectedContext."""
         if isinstance(ctx_text, ProjectedContext):
             k, vt, kip, vtip = ctx_text.kv[self]
             lt = ctx_text.text.shape[1]
@@ -425,6 +425,24 @@ class Attention(HipModule):
             k, vt, kip, vtip = self.project_kv(ctx_text, ctx_ip)
             lt = ctx_text.shape[1]
             li = ctx_ip.shape[1] if ctx_ip is not None else 0
+        return k, vt, kip, vtip, lt, li
+
+    def context_fragments(self, ctx_text, kv):
+        """the text context's K / V of this layer as the fragments i2v_cross_attn_fused_f16 keeps in registers: cached on a
+        ProjectedContext (once per prompt; refreshed when its projections are rewritten in place), packed per call otherwise."""
+        k, vt, _kip, _vtip, lt, _li = kv
+        if not isinstance(ctx_text, ProjectedContext):
+            return K.pack_ctx_fragments(k, vt, self.heads, lt)
+        sig = (k.data_ptr(), k._version, vt.data_ptr(), vt._version)
+        hit = ctx_text.frag.get(self)
+        if hit is None or hit[0] != sig:
+            hit = ctx_text.frag[self] = (sig, K.pack_ctx_fragments(k, vt, self.heads, lt))
+        return hit[1]
+
+    def _cross(self, q, ctx_text, ctx_ip, batch_q, lq, kv_group, kv=None):
+        """softmax(q Kt^T) Vt (+ ip_scale * softmax(q Kip^T) Vip) for context tensors [Bc, L, D] (or a
+        ProjectedContext holding this layer's K / V^T); kv = a `context_kv` result already at hand."""
+        k, vt, kip, vtip, lt, li = kv if kv is not None else self.context_kv(ctx_text, ctx_ip)
         o = K.attention(q, k, vt, batch_q=batch_q, lq=lq, lk=lt, heads=self.heads, head_dim=self.dim_head,
                         kv_group=kv_group, scale=self.scale)
         if kip is not None and self.ip_num_tokens:

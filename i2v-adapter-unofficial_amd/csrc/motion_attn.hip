@@ -51,10 +51,28 @@ constexpr int MA_F = 16;               // frames per pixel: one MFMA tile
 constexpr int MA_PD = 3;               // weight fragments in flight (K steps ahead)
 constexpr int MA_AD = 4;               // panel fragments in flight (reads ahead of the MFMAs that take them)
 
-template <int C, int D, int H>
-__global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_attn_params p, const float scale_log2, const int ntiles,
+// what both entry points hand the kernel (the fields of i2v_motion_attn_params / i2v_cross_attn_fused_params)
+struct ma_args {
+  const void* x; int64_t ldx;
+  const void* gamma; const void* shift; int64_t ld_shift;
+  const void* w;
+  void* out; int64_t ldo;
+  float eps;
+  // CROSS only: the context's projected keys and values as MFMA fragments (i2v_cross_attn_fused_params.ctx_frag)
+  const void* ctx_frag;
+  int32_t lt; int32_t tiles_per_ctx;
+};
+
+constexpr int MA_KT = 5;               // CROSS: key tiles of 16 (<= 80 context tokens: the 77 of CLIP)
+
+// CROSS = false: the motion module's temporal self-attention described above.
+// CROSS = true: `norm2 -> attn2` of the spatial block (i2v:510-533) for a context that fits the registers -- LayerNorm, to_q, then
+//   per 16 queries S^T = K_ctx Q^T (15 MFMAs of 16x16x16 against key fragments that stay in registers for the whole tile), softmax
+//   over the <= 80 keys in the lane, O^T = V_ctx^T P^T (15 more): one pass over the panel instead of three, no q in memory.
+template <int C, int D, int H, bool CROSS>
+__global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, const float scale_log2, const int ntiles,
                                                              long long* __restrict__ stamps) {
-  constexpr int DT = (D + 15) / 16, DP = 16 * DT, KS = C / 32, NJ = C / 64;
+  constexpr int DT = (D + 15) / 16, DP = 16 * DT, KS = C / 32, NJ = C / 64, PARTS = CROSS ? 1 : 3;
   static_assert(C % 64 == 0 && H == 8, "one wave per head, 8 lanes x C / 64 chunks per row in the LayerNorm pass");
   extern __shared__ __attribute__((aligned(16))) f16 panels[];       // 2 x [128][C], chunk index ^= row & 7
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: SGPR)
@@ -144,8 +162,8 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
   // ---- wave = head: projections with a panel as one operand and the head's weight fragments (global) as the other
   // (buffer loads: lane offset in ONE register, the fragment's place in the scalar offset -- as flat loads the 90 fragment
   // addresses of a tile are loop invariants that the compiler hoists as 64-bit pairs: 180 registers, spilled)
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_qkv), 0, H * 3 * DP * C * 2, 0x00020000);
-  const int w_lane = lane * 16, w_wave = wave * (3 * DP * C * 2);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, H * PARTS * DP * C * 2, 0x00020000);
+  const int w_lane = lane * 16, w_wave = wave * (PARTS * DP * C * 2);
   const int sw = l15 & 7;
   f32x4 acc[MA_PIX][DT];
   auto project = [&](const f16* panel, const int part, auto transposed) {
@@ -187,6 +205,25 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
     }
   };
   auto to_half = [](const f32x4 a) { return f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]}; };
+  // Output row of one query: lane (g, l15) holds channels 16 t + 4 g .. + 3 of query l15, 8 bytes per tile.  v_permlane16_swap
+  // pairs the lane groups g, g ^ 1 so that even groups end with 8 consecutive channels of tile 0 and odd groups with 8 of tile 1
+  // -- one 16-byte store per lane for two tiles (as 8-byte stores the output cost 6.5k of a tile's 50k cycles: issue-bound).
+  static_assert(DT == 3 && D == 40, "store pattern of three 16-channel tiles holding 40 channels");
+  auto store_tiles = [&](f16* orow, const u32x2 (&oh)[DT]) {
+    u32x2 a = oh[0], b = oh[1], c2 = oh[2], d2 = oh[2];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                 "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+                 : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(c2[0]), "+v"(d2[0]), "+v"(c2[1]), "+v"(d2[1]));
+    const u32x4 v01 = {a[0], a[1], b[0], b[1]};                  // even g: tile 0 channels 4 g .. + 7; odd g: tile 1 channels 4 (g - 1) ..
+    const u32x4 v2 = {c2[0], c2[1], d2[0], d2[1]};               // g = 0: tile 2 channels 0 .. 7 (32 .. 39 of the head)
+#ifdef I2V_MA_NOSTORE
+    if (p.ldo < 0)
+#endif
+    {
+      *reinterpret_cast<u32x4*>(orow + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g)) = v01;
+      if (g == 0) *reinterpret_cast<u32x4*>(orow + 32) = v2;
+    }
+  };
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;        // (workgroup-uniform)
@@ -199,17 +236,88 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
   for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
     const f16* panel = panels + (it & 1) * (MA_PIX * MA_F * C);
     const int next = tile + (int)gridDim.x;
+    // (the other panel was last read in the previous iteration, which every wave has left through the barrier at its end)
+    f16* other = panels + ((it + 1) & 1) * (MA_PIX * MA_F * C);
     MA_STAMP(2);
+    if constexpr (CROSS) {      // one pass only: the next tile's rows leave HBM now and land under it (see below)
+      if (next < ntiles) fetch_rows(next, other);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // q^T [channel][frame]
     f16x4 qh[MA_PIX][DT];
     project(panel, 0, std::true_type{});
+    // (CROSS: softmax scale * log2 e goes into the fp16 q, as in i2v_attention_f16 -- 24 multiplies per tile instead of 160)
 #pragma unroll
     for (int pix = 0; pix < MA_PIX; ++pix)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) qh[pix][t] = to_half(acc[pix][t]);
+      for (int t = 0; t < DT; ++t) qh[pix][t] = to_half(CROSS ? acc[pix][t] * scale_log2 : acc[pix][t]);
     MA_STAMP(3);
 
+    if constexpr (CROSS) {
+      // ---- cross-attention against the resident context: key fragments K[key][channel] (A operand of S^T) and value
+      // fragments V^T[channel][key] (A operand of O^T), 8 bytes per lane each
+      const int ctx = tile / p.tiles_per_ctx;
+      // (packed by the caller in FRAGMENT order, zero beyond the context's length and the head's width: 30 loads of 512
+      // contiguous bytes per wave.  Gathered from row-major K / V^T -- 16 rows x 32 B per instruction -- they took 5.5k cycles
+      // of a 48k-cycle tile.)
+      const f16* cf = reinterpret_cast<const f16*>(p.ctx_frag) + ((int64_t)ctx * H + wave) * (2 * MA_KT * DT * 256) + lane * 4;
+      f16x4 kf[MA_KT][DT], vf[DT][MA_KT];
+#pragma unroll
+      for (int kt = 0; kt < MA_KT; ++kt)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          kf[kt][t] = *reinterpret_cast<const f16x4*>(cf + (kt * DT + t) * 256);
+          vf[t][kt] = *reinterpret_cast<const f16x4*>(cf + (MA_KT * DT + t * MA_KT + kt) * 256);
+        }
+      MA_STAMP(4);
+      MA_STAMP(5);
+      f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
+#pragma unroll
+      for (int pix = 0; pix < MA_PIX; ++pix) {
+        float sv[MA_KT][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < MA_KT; ++kt) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < DT; ++t) sacc = mfma16x16x16(kf[kt][t], qh[pix][t], sacc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // (contexts of 65 .. 80 tokens -- CLIP's 77 -- end in the last key tile: only its scores need the mask; a shorter
+            // one is masked in every tile by the same test, resolved per tile at run time)
+            const bool live = (kt < MA_KT - 1 && p.lt > 16 * (MA_KT - 1)) || 16 * kt + 4 * g + r < p.lt;
+            sv[kt][r] = live ? sacc[r] : -INFINITY;
+            mx = fmaxf(mx, sv[kt][r]);
+          }
+        }
+        mx = lane_xor32_max(lane_xor16_max(mx));
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MA_KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sv[kt][r] = __builtin_amdgcn_exp2f(sv[kt][r] - mx);
+            ls += sv[kt][r];
+          }
+        ls = lane_xor32_sum(lane_xor16_sum(ls));
+        const float inv = 1.0f / ls;                 // applied to O (12 values), not to P (20): P in (0, 1] as it is
+        f16x4 pk[MA_KT];
+#pragma unroll
+        for (int kt = 0; kt < MA_KT; ++kt) pk[kt] = f16x4{(f16)sv[kt][0], (f16)sv[kt][1], (f16)sv[kt][2], (f16)sv[kt][3]};
+        u32x2 oh[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < MA_KT; ++kt) o = mfma16x16x16(vf[t][kt], pk[kt], o);
+          oh[t] = __builtin_bit_cast(u32x2, to_half(o * inv));
+        }
+        store_tiles(O + (int64_t)(16 * pix + l15) * p.ldo, oh);
+      }
+      MA_STAMP(6);
+      if (next < ntiles) normalise_rows(other);
+    } else {
     // k^T, then S^T[key][query] and the softmax over the keys
     f16x4 ph[MA_PIX];
     project(panel, 1, std::true_type{});
@@ -238,10 +346,8 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
     }
     MA_STAMP(4);
 
-    // (the other panel was last read in the previous iteration, which every wave has left through the barrier below)
     // the next tile's rows leave HBM now and land (in the other panel, which nobody reads any more) under the v pass.  No wait
     // of their own: loads return in order, and the v pass below has waited for weight fragments it requested after them.
-    f16* other = panels + ((it + 1) & 1) * (MA_PIX * MA_F * C);
     if (next < ntiles) fetch_rows(next, other);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -249,33 +355,17 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
     project(panel, 2, std::false_type{});
     MA_STAMP(5);
     f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
-    // Lane (g, l15) holds channels 16 t + 4 g .. + 3 of frame l15: 8 bytes.  v_permlane16_swap pairs the lane groups g, g ^ 1 so
-    // that even groups end with 8 consecutive channels of tile 0 and odd groups with 8 of tile 1 -- one 16-byte store per lane
-    // for two tiles (as 8-byte stores the output cost 6.5k of a tile's 50k cycles: the stores are issue-bound).
-    static_assert(DT == 3 && D == 40, "store pattern of three 16-channel tiles holding 40 channels");
 #pragma unroll
     for (int pix = 0; pix < MA_PIX; ++pix) {
       u32x2 oh[DT];
 #pragma unroll
       for (int t = 0; t < DT; ++t)
         oh[t] = __builtin_bit_cast(u32x2, to_half(mfma16x16x16(to_half(acc[pix][t]), ph[pix], f32x4{0.f, 0.f, 0.f, 0.f})));
-      u32x2 a = oh[0], b = oh[1], c2 = oh[2], d2 = oh[2];
-      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
-                   "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
-                   : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(c2[0]), "+v"(d2[0]), "+v"(c2[1]), "+v"(d2[1]));
-      f16* orow = O + (int64_t)(16 * pix + l15) * p.ldo;
-      const u32x4 v01 = {a[0], a[1], b[0], b[1]};                  // even g: tile 0 channels 4 g .. + 7; odd g: tile 1 channels 4 (g - 1) ..
-      const u32x4 v2 = {c2[0], c2[1], d2[0], d2[1]};               // g = 0: tile 2 channels 0 .. 7 (32 .. 39 of the head)
-#ifdef I2V_MA_NOSTORE
-      if (p.ldo < 0)
-#endif
-      {
-        *reinterpret_cast<u32x4*>(orow + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g)) = v01;
-        if (g == 0) *reinterpret_cast<u32x4*>(orow + 32) = v2;
-      }
+      store_tiles(O + (int64_t)(16 * pix + l15) * p.ldo, oh);
     }
     MA_STAMP(6);
     if (next < ntiles) normalise_rows(other);
+    }
     MA_STAMP(7);
 #ifdef I2V_MA_STAMPS
     if (stamps != nullptr && lane == 0 && it < 4) {
@@ -289,18 +379,18 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const i2v_motion_at
 #undef MA_STAMP
 }
 
-template <int C, int D, int H>
-int launch_ma(const i2v_motion_attn_params& p, hipStream_t s) {
+template <int C, int D, int H, bool CROSS>
+int launch_ma(const ma_args& p, int64_t rows, float scale, hipStream_t s, const char* what) {
   const size_t lds = 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16);
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H, CROSS>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-  if (!attr_ok) I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_motion_attn_f16: %zu bytes of LDS refused", lds);
+  if (!attr_ok) I2V_FAIL(I2V_ERR_UNSUPPORTED, "%s: %zu bytes of LDS refused", what, lds);
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
     return n > 0 ? n : 256;
   }();
-  const int ntiles = (int)(p.rows / (MA_PIX * MA_F));
+  const int ntiles = (int)(rows / (MA_PIX * MA_F));
   // one workgroup per CU (160 KB of LDS each), every workgroup the same number of tiles where the count allows it
   const int per = (ntiles + cus - 1) / cus;
   const int grid = (ntiles + per - 1) / per;
@@ -308,9 +398,9 @@ int launch_ma(const i2v_motion_attn_params& p, hipStream_t s) {
 #ifdef I2V_MA_STAMPS
   stamps = getenv("I2V_MA_STAMP_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("I2V_MA_STAMP_PTR"), nullptr, 0)) : nullptr;
 #endif
-  hipLaunchKernelGGL((motion_attn_kernel<C, D, H>), dim3((unsigned)grid), dim3(64 * H), lds, s, p, p.scale * 1.4426950408889634f,
+  hipLaunchKernelGGL((motion_attn_kernel<C, D, H, CROSS>), dim3((unsigned)grid), dim3(64 * H), lds, s, p, scale * 1.4426950408889634f,
                      ntiles, stamps);
-  return i2v_check_launch("i2v_motion_attn_f16");
+  return i2v_check_launch(what);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -335,5 +425,40 @@ extern "C" int i2v_motion_attn_f16(const i2v_motion_attn_params* pp, i2v_stream_
                 p.ld_shift % 4 == 0, "i2v_motion_attn_f16: row strides");
   I2V_CHECK_ARG(al16(p.x) && al16(p.gamma) && al16(p.shift) && al16(p.w_qkv) && al16(p.out),
                 "i2v_motion_attn_f16: pointers must be 16-byte aligned");
-  return launch_ma<320, 40, 8>(p, reinterpret_cast<hipStream_t>(stream));
+  ma_args a = {};
+  a.x = p.x; a.ldx = p.ldx; a.gamma = p.gamma; a.shift = p.shift; a.ld_shift = p.ld_shift; a.w = p.w_qkv; a.out = p.out;
+  a.ldo = p.ldo; a.eps = p.eps;
+  return launch_ma<320, 40, 8, false>(a, p.rows, p.scale, reinterpret_cast<hipStream_t>(stream), "i2v_motion_attn_f16");
+}
+
+extern "C" int32_t i2v_cross_attn_fused_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t ctx_len,
+                                                  int64_t rows_per_ctx) {
+  return rows > 0 && rows % (MA_PIX * MA_F) == 0 && rows / (MA_PIX * MA_F) < (1 << 24) && channels == 320 && heads == 8 &&
+         head_dim == 40 && ctx_len >= 1 && ctx_len <= 16 * MA_KT && rows_per_ctx > 0 && rows_per_ctx % (MA_PIX * MA_F) == 0 &&
+         rows % rows_per_ctx == 0;
+}
+
+extern "C" int32_t i2v_cross_attn_fused_pack_rows(int32_t heads, int32_t head_dim) { return heads * ((head_dim + 15) / 16) * 16; }
+
+extern "C" int64_t i2v_cross_attn_fused_ctx_elems(int32_t n_ctx, int32_t heads, int32_t head_dim) {
+  return (int64_t)n_ctx * heads * 2 * MA_KT * ((head_dim + 15) / 16) * 256;
+}
+
+extern "C" int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* pp, i2v_stream_t stream) {
+  I2V_CHECK_ARG(pp != nullptr, "i2v_cross_attn_fused_f16: null params");
+  const i2v_cross_attn_fused_params& p = *pp;
+  I2V_CHECK_ARG(p.x && p.gamma && p.beta && p.w_q && p.ctx_frag && p.out, "i2v_cross_attn_fused_f16: null pointer");
+  I2V_CHECK_ARG(i2v_cross_attn_fused_supported(p.rows, p.channels, p.heads, p.head_dim, p.ctx_len, p.rows_per_ctx),
+                "i2v_cross_attn_fused_f16: rows %lld channels %d heads %d head_dim %d ctx_len %d rows_per_ctx %lld is not a fused shape "
+                "(i2v_cross_attn_fused_supported)", (long long)p.rows, p.channels, p.heads, p.head_dim, p.ctx_len,
+                (long long)p.rows_per_ctx);
+  I2V_CHECK_ARG(p.ldx >= p.channels && p.ldx % 8 == 0 && p.ldo >= p.channels && p.ldo % 8 == 0, "i2v_cross_attn_fused_f16: row strides");
+  I2V_CHECK_ARG(al16(p.x) && al16(p.gamma) && al16(p.beta) && al16(p.w_q) && al16(p.out) && al16(p.ctx_frag),
+                "i2v_cross_attn_fused_f16: pointers must be 16-byte aligned");
+  ma_args a = {};
+  a.x = p.x; a.ldx = p.ldx; a.gamma = p.gamma; a.shift = p.beta; a.ld_shift = 0; a.w = p.w_q; a.out = p.out; a.ldo = p.ldo;
+  a.eps = p.eps;
+  a.ctx_frag = p.ctx_frag; a.lt = p.ctx_len;
+  a.tiles_per_ctx = (int32_t)(p.rows_per_ctx / (MA_PIX * MA_F));
+  return launch_ma<320, 40, 8, true>(a, p.rows, p.scale, reinterpret_cast<hipStream_t>(stream), "i2v_cross_attn_fused_f16");
 }

@@ -10,6 +10,7 @@ frame-0 rows are gathered once per clip, K0 / V0^T are projected once, and the a
 query frame of a clip onto the same K0 / V0^T (kv_group = F).  The adapter's to_q shares one GEMM with attn1's
 to_q | to_k, and both out-projections (+ both biases + the residual) are one dual-source GEMM.
 """
+import os
 from typing import Optional
 
 import torch
@@ -69,6 +70,9 @@ class I2VAdapterModule(PretrainedMixin, nn.Module):
         pass
 
 
+FUSED_TEXT_ATTN = os.environ.get("I2V_TEXT_FUSED", "1") != "0"
+
+
 class I2VAdapterTransformerBlock(HipModule):
     """i2v:356-565 (layer-norm branch)."""
 
@@ -124,6 +128,9 @@ class I2VAdapterTransformerBlock(HipModule):
             p["w_q2"] = w16(self.attn2.to_q.weight)
             p["w_o2"], p["b_o2"] = w16(self.attn2.to_out[0].weight), w16(self.attn2.to_out[0].bias)
             p["f_q2"] = fold_layernorm(self.attn2.to_q.weight, None, self.norm2.weight, self.norm2.bias)
+            # the fused LayerNorm + to_q + text cross-attention kernel's operands (64^2 level of SD-1.5, no image tokens)
+            p["wq2_frag"] = K.pack_cross_q(self.attn2.to_q.weight, self.heads)
+            p["g2_f32"], p["b2_f32"] = self.norm2.weight.detach().float().contiguous(), self.norm2.bias.detach().float().contiguous()
         # LayerNorm folded into the consuming projections (i2v:444-445 -> q | k | q_adapter and V^T; i2v:510 -> attn2.to_q;
         # i2v:539 -> GEGLU): operands (W o gamma, row sums, W beta + b) of the LayerNorm-folded GEMM
         p["f_qkq"] = fold_layernorm(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), None,
@@ -216,17 +223,27 @@ class I2VAdapterTransformerBlock(HipModule):
         if cfg_expand:
             x, n_img = K.duplicate_batch(x), 2 * n_img
         if self.attn2 is not None:                                                           # i2v:510-533
-            if fold2:
-                wf, ws, cb = p["f_q2"]
-                q = K.gemm(x, wf, cb, ln=(ws, self.eps))
-            else:
-                n = K.layernorm(x, p["g2"], p["b2"], self.eps)
-                q = K.gemm(n, p["w_q2"])
             if ctx_text is None:
                 raise ValueError("encoder_hidden_states is required by the cross-attention layer")
             if n_img % ctx_text.shape[0] != 0:
                 raise ValueError(f"context batch {ctx_text.shape[0]} does not divide batch {n_img}")
-            o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, n_img // ctx_text.shape[0])
+            kv_group = n_img // ctx_text.shape[0]
+            kv = self.attn2.context_kv(ctx_text, ctx_ip)
+            k, vt, kip, _vtip, lt, _li = kv
+            no_ip = kip is None or not self.attn2.ip_num_tokens
+            if FUSED_TEXT_ATTN and no_ip and K.cross_attn_fused_supported(x.shape[0], c, self.heads, self.dim_head, lt, kv_group * L):
+                # LayerNorm 2, to_q and the attention over the <= 80 context tokens in one launch (64^2 level of SD-1.5)
+                o = K.cross_attn_fused(x, p["g2_f32"], p["b2_f32"], p["wq2_frag"], self.attn2.context_fragments(ctx_text, kv), heads=self.heads,
+                                       head_dim=self.dim_head, ctx_len=lt, rows_per_ctx=kv_group * L, eps=self.eps,
+                                       scale=self.attn2.scale)
+            else:
+                if fold2:
+                    wf, ws, cb = p["f_q2"]
+                    q = K.gemm(x, wf, cb, ln=(ws, self.eps))
+                else:
+                    n = K.layernorm(x, p["g2"], p["b2"], self.eps)
+                    q = K.gemm(n, p["w_q2"])
+                o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, kv_group, kv=kv)
             x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
         if fold3:
             return self.ff._fwd_folded(x, self.eps, p["f_ff"])                               # i2v:539,554,561

@@ -335,19 +335,93 @@ def motion_attn_supported(rows, channels, heads, head_dim, frames):
     return bool(_lib.load().i2v_motion_attn_supported(rows, channels, heads, head_dim, frames))
 
 
-def pack_motion_qkv(wq, wk, wv, heads):
-    """`w_qkv` of i2v_motion_attn_f16: per head its rows of Wq, Wk, Wv, each zero-padded to a multiple of 16 rows, in
-    MFMA-fragment order [heads][3][C / 32][pad16(d) / 16][lane = 16 (k chunk) + row][8] (returned as [rows, C])."""
-    c_out, c_in = wq.shape
+def _pack_head_fragments(weights, heads):
+    """per head the rows of each weight, zero-padded to a multiple of 16 rows, in MFMA-fragment order
+    [heads][parts][C / 32][pad16(d) / 16][lane = 16 (k chunk) + row][8] (returned as [rows, C])."""
+    c_out, c_in = weights[0].shape
     d = c_out // heads
     dp = (d + 15) // 16 * 16
-    w = torch.zeros((heads, 3, dp, c_in), dtype=f16, device=wq.device)
-    for i, t in enumerate((wq, wk, wv)):
+    n = len(weights)
+    w = torch.zeros((heads, n, dp, c_in), dtype=f16, device=weights[0].device)
+    for i, t in enumerate(weights):
         w[:, i, :d] = t.detach().to(f16).view(heads, d, c_in)
-    if heads * 3 * dp != _lib.load().i2v_motion_attn_pack_rows(heads, d):
+    w = w.view(heads, n, dp // 16, 16, c_in // 32, 4, 8).permute(0, 1, 4, 2, 5, 3, 6)      # [h, part, s, t, g, l15, 8]
+    return w.contiguous().view(heads * n * dp, c_in)
+
+
+def pack_motion_qkv(wq, wk, wv, heads):
+    """`w_qkv` of i2v_motion_attn_f16: per head its rows of Wq, Wk, Wv in fragment order (`_pack_head_fragments`)."""
+    w = _pack_head_fragments((wq, wk, wv), heads)
+    if w.shape[0] != _lib.load().i2v_motion_attn_pack_rows(heads, wq.shape[0] // heads):
         raise RuntimeError("pack_motion_qkv: row count differs from i2v_motion_attn_pack_rows")
-    w = w.view(heads, 3, dp // 16, 16, c_in // 32, 4, 8).permute(0, 1, 4, 2, 5, 3, 6)      # [h, part, s, t, g, l15, 8]
-    return w.contiguous().view(heads * 3 * dp, c_in)
+    return w
+
+
+def pack_cross_q(wq, heads):
+    """`w_q` of i2v_cross_attn_fused_f16: per head its rows of to_q in fragment order."""
+    w = _pack_head_fragments((wq,), heads)
+    if w.shape[0] != _lib.load().i2v_cross_attn_fused_pack_rows(heads, wq.shape[0] // heads):
+        raise RuntimeError("pack_cross_q: row count differs from i2v_cross_attn_fused_pack_rows")
+    return w
+
+
+def cross_attn_fused_supported(rows, channels, heads, head_dim, ctx_len, rows_per_ctx):
+    """is the fused LayerNorm + to_q + cross-attention kernel implemented for this shape?"""
+    return bool(_lib.load().i2v_cross_attn_fused_supported(rows, channels, heads, head_dim, ctx_len, rows_per_ctx))
+
+
+def pack_ctx_fragments(k, vt, heads, ctx_len):
+    """`ctx_frag` of i2v_cross_attn_fused_f16 from the projected context as the other kernels take it -- k [n_ctx * ctx_len, C],
+    vt [n_ctx, C, >= ctx_len] (V^T) -- as MFMA operand fragments [n_ctx][heads][30][64][4], zero beyond the context's length
+    and the head's width.  A handful of small torch ops: done once per prompt (`ProjectedContext`), not per step."""
+    n_ctx, c = vt.shape[0], vt.shape[1]
+    d = c // heads
+    dt, kt_n = (d + 15) // 16, 5
+    if ctx_len > 16 * kt_n or k.shape[0] != n_ctx * ctx_len:
+        raise ValueError(f"pack_ctx_fragments: k {tuple(k.shape)} / ctx_len {ctx_len}")
+    kp = torch.zeros((n_ctx, 16 * kt_n, heads, 16 * dt), dtype=f16, device=k.device)
+    kp[:, :ctx_len, :, :d] = k[:, :c].reshape(n_ctx, ctx_len, heads, d)
+    kf = kp.view(n_ctx, kt_n, 16, heads, dt, 4, 4).permute(0, 3, 1, 4, 5, 2, 6)               # [n, h, kt, t, g, r, j]
+    vp = torch.zeros((n_ctx, heads, 16 * dt, 16 * kt_n), dtype=f16, device=k.device)
+    vp[:, :, :d, :ctx_len] = vt[:, :, :ctx_len].reshape(n_ctx, heads, d, ctx_len)
+    vf = vp.view(n_ctx, heads, dt, 16, kt_n, 4, 4).permute(0, 1, 2, 4, 5, 3, 6)               # [n, h, t, kt, g, r, j]
+    out = torch.cat([kf.reshape(n_ctx, heads, kt_n * dt, 64, 4), vf.reshape(n_ctx, heads, dt * kt_n, 64, 4)], dim=2).contiguous()
+    if out.numel() != _lib.load().i2v_cross_attn_fused_ctx_elems(n_ctx, heads, d):
+        raise RuntimeError("pack_ctx_fragments: size differs from i2v_cross_attn_fused_ctx_elems")
+    return out
+
+
+def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_len, rows_per_ctx, eps, scale=None, out=None):
+    """o = softmax((LayerNorm(x) Wq^T) K^T) V against a short context (i2v_cross_attn_fused_f16): x [rows, C]; ctx_frag from
+    `pack_ctx_fragments`; rows [i * rows_per_ctx, (i + 1) * rows_per_ctx) use context i."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    rows, c = x.shape
+    _req(w_q, "w_q")
+    _req(ctx_frag, "ctx_frag")
+    for name, t in (("gamma32", gamma32), ("beta32", beta32)):
+        _req(t, name, dtype=torch.float32)
+        if tuple(t.shape) != (c,):
+            raise ValueError(f"cross_attn_fused: {name} is {tuple(t.shape)}, expected ({c},)")
+    n_ctx = -(-rows // rows_per_ctx)
+    if c != heads * head_dim or not ctx_frag.is_contiguous() or \
+            ctx_frag.numel() != lib.i2v_cross_attn_fused_ctx_elems(n_ctx, heads, head_dim):
+        raise ValueError(f"cross_attn_fused: ctx_frag is {tuple(ctx_frag.shape)} for {n_ctx} contexts (pack_ctx_fragments)")
+    if tuple(w_q.shape) != (lib.i2v_cross_attn_fused_pack_rows(heads, head_dim), c) or not w_q.is_contiguous():
+        raise ValueError(f"cross_attn_fused: w_q is {tuple(w_q.shape)} (pack_cross_q)")
+    if out is None:
+        out = torch.empty((rows, c), dtype=f16, device=x.device)
+    out, ldo = _mat(out, "out")
+    p = _lib.CrossAttnFusedParams()
+    p.x, p.ldx = _p(x), ldx
+    p.gamma, p.beta, p.w_q = _p(gamma32), _p(beta32), _p(w_q)
+    p.ctx_frag = _p(ctx_frag)
+    p.out, p.ldo = _p(out), ldo
+    p.rows, p.rows_per_ctx = rows, rows_per_ctx
+    p.channels, p.heads, p.head_dim, p.ctx_len = c, heads, head_dim, ctx_len
+    p.eps, p.scale = float(eps), float(head_dim) ** -0.5 if scale is None else float(scale)
+    _lib.check(lib.i2v_cross_attn_fused_f16(C.byref(p), _stream()), "i2v_cross_attn_fused_f16")
+    return out
 
 
 def motion_attn_tables(gamma, beta, pe, frames):

@@ -3,7 +3,7 @@
 `with KernelProfile() as prof:` wraps every C-ABI wrapper of `kernels` with a pair of events recorded on torch's
 current stream (the stream the ctypes launches go to) and the ALGORITHMIC work of the call:
   flops: gemm 2 M N K; conv3x3 2 M Cout 9 Cin; attention 4 Lq Lk C Bq; temporal attention 4 F F C pixels; fused motion
-         attention sub-block 2 M C 3C + 4 M F C
+         attention sub-block 2 M C 3C + 4 M F C; fused text cross-attention 2 M C C + 4 M Lk C
   bytes: operands read once + result written once (fp16), GroupNorm 2 reads + 1 write, LayerNorm 1 read + 1 write
 (the counting rules of SURVEY.md Appendix B / section 8d).  Only used outside the timed region.
 """
@@ -56,6 +56,13 @@ def _work_mattn(args, kw, out):
             f"{rows}x{c} F{kw['frames']} h{kw['heads']} d{kw['head_dim']} (LN + q,k,v + attention)")
 
 
+def _work_cattn(args, kw, out):
+    x, w = args[0], args[3]
+    rows, c = x.shape
+    return ("cross_attn_fused", 2.0 * rows * c * c + 4.0 * rows * kw["ctx_len"] * c, _numel_bytes(x, w, args[4], out),
+            f"{rows}x{c} Lk{kw['ctx_len']} h{kw['heads']} d{kw['head_dim']} (LN + q + text attention)")
+
+
 def _work_gn(args, kw, out):
     return "groupnorm", 0.0, 3 * _numel_bytes(out), "x".join(map(str, out.shape))
 
@@ -77,7 +84,7 @@ def _work_misc(name):
 
 _WRAPPED = {
     "gemm": _work_gemm, "conv3x3": _work_conv, "attention": _work_attn, "temporal_attention": _work_tattn,
-    "motion_attn": _work_mattn,
+    "motion_attn": _work_mattn, "cross_attn_fused": _work_cattn,
     "groupnorm": _work_gn, "groupnorm_fold": _work_gn_fold, "layernorm": _work_ln, "silu": _work_misc("elementwise"),
     "copy3d": _work_misc("elementwise"), "timestep_embedding": _work_misc("elementwise"),
     "ddim_prep": _work_misc("elementwise"), "ddim_cfg_step": _work_misc("elementwise"),

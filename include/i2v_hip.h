@@ -230,6 +230,41 @@ int32_t i2v_motion_attn_pack_rows(int32_t heads, int32_t head_dim);
 int i2v_motion_attn_f16(const i2v_motion_attn_params* p, i2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * `norm2 -> attn2` of the spatial transformer block (i2v:510-533) up to (not including) to_out, for a context that fits
+ * the registers (the 77 CLIP tokens), in one launch: n = LayerNorm(x) * gamma + beta; q = n Wq^T;
+ *     out[row][head h] = softmax(q_h K_h^T * scale) V_h   with K = ctx_k rows, V^T = ctx_vt rows of the row's context
+ * (rows [i * rows_per_ctx, (i + 1) * rows_per_ctx) attend to context i: the frames of one sample share its prompt).
+ * Replaces native_layer_norm + to_q + SDPA(q, to_k(ctx), to_v(ctx)); the context projections are the caller's (they do
+ * not depend on the step).  gamma, beta: fp32 [channels]; w_q: to_q's rows per head, zero-padded to pad16(head_dim), in the
+ * fragment order of i2v_motion_attn_f16's w_qkv with one part ([heads][channels / 32][P / 16][64][8],
+ * i2v_cross_attn_fused_pack_rows(heads, head_dim) * channels elements).
+ * ctx_frag: the context's projected keys and values as the MFMA operand fragments the kernel keeps in registers, packed once
+ * per prompt: fp16 [n_ctx][heads][30][64][4] (i2v_cross_attn_fused_ctx_elems(n_ctx, heads, head_dim) elements) with
+ *   [c][h][3 kt + t][16 g + r][j]      = K[c][key = 16 kt + r][h * head_dim + 16 t + 4 g + j]       (kt < 5, t < 3)
+ *   [c][h][15 + 5 t + kt][16 g + r][j] = V[c][key = 16 kt + 4 g + j][h * head_dim + 16 t + r]
+ * and zero wherever key >= ctx_len or the channel offset >= head_dim.
+ * Implemented where i2v_cross_attn_fused_supported(...) != 0: channels 320, 8 heads of 40, ctx_len <= 80, rows and
+ * rows_per_ctx multiples of 128 (the SD-1.5 64^2 level).  The IP-Adapter's second softmax is not part of it: callers with
+ * image tokens use the un-fused kernels.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_cross_attn_fused_params {
+  const void* x; int64_t ldx;            /* fp16 [rows, channels] */
+  const void* gamma; const void* beta;   /* fp32 [channels] */
+  const void* w_q;
+  const void* ctx_frag;
+  void* out; int64_t ldo;                /* fp16 [rows, channels] */
+  int64_t rows, rows_per_ctx;
+  int32_t channels, heads, head_dim, ctx_len;
+  float eps, scale;
+} i2v_cross_attn_fused_params;
+
+int32_t i2v_cross_attn_fused_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t ctx_len,
+                                       int64_t rows_per_ctx);
+int32_t i2v_cross_attn_fused_pack_rows(int32_t heads, int32_t head_dim);
+int64_t i2v_cross_attn_fused_ctx_elems(int32_t n_ctx, int32_t heads, int32_t head_dim);
+int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) on token-major fp16: statistics in fp32.
  *   stat group = (frames_per_stat consecutive images) x (all pixels) x (C / groups channels)
  *   frames_per_stat = 1: ResnetBlock2D norm1/norm2, Transformer2D norm, conv_norm_out

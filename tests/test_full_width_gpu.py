@@ -133,6 +133,21 @@ def test_full_width_transformer_2d(dev, c, hw, frames):
         got = m(x.half().to(dev), enable_cross_frame_attn=True, num_frames=frames,
                 encoder_hidden_states=ctx.half().to(dev), return_dict=False)[0]
     compare(got, ref, rel=MODULE_REL_TOL, name=f"full-width T2D C={c} {hw}x{hw} F={frames}")
+    from i2v_adapter_unofficial_amd import i2v_adapter as mod, kernels as K
+    fused_shape = K.cross_attn_fused_supported(2 * frames * hw * hw, c, 8, c // 8, 77, hw * hw)
+    assert fused_shape == (c == 320)       # the 64^2-level width of SD-1.5 runs i2v_cross_attn_fused_f16 for norm2 -> attn2
+    if fused_shape:      # the same module on the un-fused kernels (I2V_TEXT_FUSED=0): both against the oracle, and close
+        assert mod.FUSED_TEXT_ATTN
+        mod.FUSED_TEXT_ATTN = False
+        try:
+            with torch.no_grad():
+                plain = m(x.half().to(dev), enable_cross_frame_attn=True, num_frames=frames,
+                          encoder_hidden_states=ctx.half().to(dev), return_dict=False)[0]
+        finally:
+            mod.FUSED_TEXT_ATTN = True
+        compare(plain, ref, rel=MODULE_REL_TOL, name=f"full-width T2D, un-fused text attention C={c}")
+        compare(got, plain, rel=MODULE_REL_TOL, name=f"T2D fused vs un-fused text attention C={c}")
+        assert not torch.equal(got, plain)
 
 
 @pytest.mark.parametrize("c,hw,frames", [(320, 32, 16), (640, 16, 16), (1280, 8, 16), (320, 16, 32)])

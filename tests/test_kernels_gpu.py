@@ -596,6 +596,45 @@ def test_motion_attention_sub_block_fused(dev, npix, amp, strided):
         k.motion_attn(xd[:rows - 16], g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps)
 
 
+@pytest.mark.parametrize("rows,n_ctx,lt,amp", [(256, 2, 77, 1.0), (128 * 37, 1, 77, 1.0), (1024, 2, 80, 3.0), (512, 4, 5, 1.0)])
+def test_text_cross_attention_sub_block_fused(dev, rows, n_ctx, lt, amp):
+    """i2v_cross_attn_fused_f16: LayerNorm, to_q and the attention against a <= 80-token context whose K / V^T are given, in one
+    launch (channels 320, 8 heads of 40) against fp32 torch on the same fp16-rounded operands, and against the un-fused kernels
+    (LayerNorm -> q GEMM -> i2v_attention_f16 with kv_group).  The pad columns of V^T hold NaN: they must not be read as data."""
+    k = K()
+    c, heads, d, eps = 320, 8, 40, 1e-5
+    rpc = rows // n_ctx
+    assert k.cross_attn_fused_supported(rows, c, heads, d, lt, rpc) and not k.cross_attn_fused_supported(rows, c, heads, d, 81, rpc)
+    assert not k.cross_attn_fused_supported(rows, c, heads, d, lt, rpc + 16) and not k.cross_attn_fused_supported(rows, 640, 8, 80, lt, rpc)
+    g = torch.Generator().manual_seed(rows + lt)
+    x = h(torch.randn(rows, c, generator=g) * 1.5 + 0.3)
+    gamma, beta = h(1 + 0.2 * torch.randn(c, generator=g)), h(0.1 * torch.randn(c, generator=g))
+    wq = h(torch.randn(c, c, generator=g) * amp * c ** -0.5)
+    kk = h(torch.randn(n_ctx, lt, c, generator=g) * amp)
+    vv = h(torch.randn(n_ctx, lt, c, generator=g))
+    n = h(F.layer_norm(x, (c,), gamma, beta, eps))
+    q = h(n @ wq.T)
+    ref = _attn_ref(q.view(n_ctx, rpc, c), kk, vv, heads, 1).reshape(rows, c)
+    D = lambda t: t.half().to(dev)
+    ld = k.pad8(lt)
+    vt = torch.full((n_ctx, c, ld), float("nan"))
+    vt[:, :, :lt] = vv.permute(0, 2, 1)
+    w = k.pack_cross_q(D(wq), heads)
+    assert tuple(w.shape) == (8 * 48, c)
+    g32, b32 = D(gamma).float(), D(beta).float()
+    kd, vtd, xd = D(kk.reshape(-1, c)), D(vt), D(x)
+    frag = k.pack_ctx_fragments(kd, vtd, heads, lt)
+    assert tuple(frag.shape) == (n_ctx, heads, 30, 64, 4) and torch.isfinite(frag.float()).all()
+    out = k.cross_attn_fused(xd, g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps)
+    close(out, ref, rel=3e-3 * amp * amp, name="fused text cross-attention vs fp32 torch")
+    nl = k.layernorm(xd, D(gamma), D(beta), eps)
+    old = k.attention(k.gemm(nl, D(wq)), kd, vtd, batch_q=n_ctx, lq=rpc, lk=lt, heads=heads, head_dim=d)
+    close(out, old, rel=1.5e-3 * amp * amp, name="fused text cross-attention vs the un-fused kernels")
+    assert torch.equal(out, k.cross_attn_fused(xd, g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps))
+    with pytest.raises(Exception, match="not a fused shape"):
+        k.cross_attn_fused(xd[:rows - 16], g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps)
+
+
 @pytest.mark.parametrize("n,hh,ww,c1,c2,groups,fps,silu,perm", [
     (4, 8, 8, 32, 0, 8, 1, True, False), (2, 16, 16, 320, 0, 32, 1, True, False),
     (4, 8, 8, 64, 0, 32, 4, False, True), (2, 20, 20, 64, 32, 32, 1, True, False),

@@ -124,7 +124,8 @@ def _grad_worker(rank, world, port, q):
     opt.fill_gradients(grads)
     mine = opt.grad.clone()
     div = opt.reduce_gradients()
-    q.put((rank, opt.names, mine, opt.grad.clone(), div, opt.master.numel()))
+    # (numpy arrays travel by value: a tensor on the queue is a file descriptor the parent has to fetch while the child lives)
+    q.put((rank, opt.names, mine.numpy().copy(), opt.grad.numpy().copy(), div, opt.master.numel()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -141,6 +142,7 @@ def test_adapter_gradient_allreduce_world_size_2():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, names0, mine0, red0, div0, n0), (_, names1, mine1, red1, div1, n1) = res
+    mine0, red0, mine1, red1 = (torch.from_numpy(t) for t in (mine0, red0, mine1, red1))
     assert names0 == names1 and len(names0) == 2 * 3 and all(".i2v_adapter.to_q." in n or ".i2v_adapter.to_out." in n for n in names0)
     assert n0 == n1 == 2 * (32 * 32 + 32 * 32 + 32)            # to_q.weight, to_out.0.weight, to_out.0.bias per block
     assert div0 == div1 == 2
