@@ -116,6 +116,19 @@ class CrossAttnFusedParams(C.Structure):
     ]
 
 
+class FfFusedParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("rows", C.c_int64),
+        ("channels", C.c_int32), ("inner", C.c_int32),
+        ("eps", C.c_float),
+    ]
+
+
 class GnParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("c1", C.c_int32),
@@ -159,6 +172,8 @@ SIGNATURES = {
     "i2v_cross_attn_fused_pack_rows": (C.c_int32, [C.c_int32, C.c_int32]),
     "i2v_cross_attn_fused_ctx_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_cross_attn_fused_f16": (C.c_int, [C.POINTER(CrossAttnFusedParams), _P]),
+    "i2v_ff_fused_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32]),
+    "i2v_ff_fused_f16": (C.c_int, [C.POINTER(FfFusedParams), _P]),
     "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_groupnorm_f16": (C.c_int, [C.POINTER(GnParams), _P]),
     "i2v_groupnorm_fold_f16": (C.c_int, [C.POINTER(GnParams), _P, C.c_int64, _P, C.c_int32, _P, _P, _P]),

@@ -513,13 +513,26 @@ class FeedForward(HipModule):
             w1, b1 = pack_geglu(proj.weight.detach(), proj.bias.detach())
         else:
             w1, b1 = w16(proj.weight), w16(proj.bias)
-        return dict(w1=w1, b1=b1, w2=w16(self.net[2].weight), b2=w16(self.net[2].bias))
+        out = dict(w1=w1, b1=b1, w2=w16(self.net[2].weight), b2=w16(self.net[2].bias))
+        if self.activation_fn == "geglu" and K.ff_fused_supported(128, self.net[2].weight.shape[0], self.net[2].weight.shape[1]):
+            # operands of the one-launch form (i2v_ff_fused_f16: the SD-1.5 64^2 width)
+            out["fused"] = K.pack_ff_fused(proj.weight, proj.bias, self.net[2].weight, self.net[2].bias)
+        return out
 
     def _fwd(self, n2d, residual2d, **store):
         p = self.packed()
         epi = I2V_EPI_GEGLU if self.activation_fn == "geglu" else I2V_EPI_GELU
         h = K.gemm(n2d, p["w1"], p["b1"], epilogue=epi)
         return K.gemm(h, p["w2"], p["b2"], residual=residual2d, **store)
+
+    def fused_supported(self, x2d):
+        """does the one-launch LayerNorm + GEGLU feed-forward + residual kernel take this problem?"""
+        p = self.packed()
+        return FUSED_FF and "fused" in p and K.ff_fused_supported(x2d.shape[0], x2d.shape[1], p["b1"].numel() // 2)
+
+    def _fwd_fused(self, x2d, gamma32, beta32, eps):
+        """x + FF(LayerNorm(x)) in one launch: the inner activation never leaves the CU."""
+        return K.ff_fused(x2d, gamma32, beta32, self.packed()["fused"], eps=eps)
 
     def fold_norm(self, norm):
         """(W', wsum, b') of `norm` (LayerNorm) followed by the first projection, or None when the activation has no
@@ -571,6 +584,7 @@ class SinusoidalPositionalEmbedding(nn.Module):
 
 
 FUSED_MOTION_ATTN = os.environ.get("I2V_MOTION_FUSED", "1") != "0"
+FUSED_FF = os.environ.get("I2V_FF_FUSED", "1") != "0"
 
 
 class TemporalTransformerBlock(HipModule):
@@ -621,6 +635,7 @@ class TemporalTransformerBlock(HipModule):
         for i, attn in enumerate((self.attn1, self.attn2), 1):
             p[f"wqkv{i}"] = K.pack_motion_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, self.heads)
         self._ma_tables = {}          # (site, frames) -> (gamma fp32, beta + pe[frame] fp32), made on first use
+        p["g3_f32"], p["b3_f32"] = self.norm3.weight.detach().float().contiguous(), self.norm3.bias.detach().float().contiguous()
         return p
 
     def _fold_ok(self, t, frames):
@@ -676,6 +691,8 @@ class TemporalTransformerBlock(HipModule):
             o = K.temporal_attention(qk[:, :c], qk[:, c:], vt, n_pixels=n_pixels, frames=frames, heads=self.heads,
                                      head_dim=self.dim_head, scale=self.dim_head ** -0.5)
             t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)
+        if self.ff.fused_supported(t):
+            return self.ff._fwd_fused(t, p["g3_f32"], p["b3_f32"], self.eps)
         if fold_ff:
             return self.ff._fwd_folded(t, self.eps, p["f_ff"])
         n = K.layernorm(t, p["g3"], p["b3"], self.eps)

@@ -137,6 +137,7 @@ class I2VAdapterTransformerBlock(HipModule):
                                     self.norm1.weight, self.norm1.bias)
         p["f_v1"] = fold_layernorm(a1.to_v.weight, None, self.norm1.weight, self.norm1.bias)
         p["f_ff"] = self.ff.fold_norm(self.norm3)
+        p["g3_f32"], p["b3_f32"] = self.norm3.weight.detach().float().contiguous(), self.norm3.bias.detach().float().contiguous()
         return p
 
     def _fold_ok(self, x, L, rows_qkq):
@@ -245,6 +246,8 @@ class I2VAdapterTransformerBlock(HipModule):
                     q = K.gemm(n, p["w_q2"])
                 o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, kv_group, kv=kv)
             x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
+        if self.ff.fused_supported(x):
+            return self.ff._fwd_fused(x, p["g3_f32"], p["b3_f32"], self.eps)                 # i2v:539,554,561 in one launch
         if fold3:
             return self.ff._fwd_folded(x, self.eps, p["f_ff"])                               # i2v:539,554,561
         n = K.layernorm(x, p["g3"], p["b3"], self.eps)                                       # i2v:539

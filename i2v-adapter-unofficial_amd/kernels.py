@@ -424,6 +424,60 @@ def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_
     return out
 
 
+def ff_fused_supported(rows, channels, inner):
+    """is the one-launch GEGLU feed-forward implemented for this shape?"""
+    return bool(_lib.load().i2v_ff_fused_supported(rows, channels, inner))
+
+
+def pack_ff_fused(w1, b1, w2, b2):
+    """(w1 fragments, b1 fp32, w2 fragments, b2 fp32) of i2v_ff_fused_f16 from diffusers' GEGLU.proj (w1 [2 inner, C], rows
+    [values ; gates]) and the output Linear (w2 [C, inner]); layouts in include/i2v_hip.h."""
+    inner, c = w2.shape[1], w2.shape[0]
+    nch, heads, dn = inner // 64, 8, c // 8
+    dt = (dn + 15) // 16
+    dev = w1.device
+    # W1 rows of tile (ch, w): m = 0 .. 15 -> (m & 1) * inner + 64 ch + 8 w + (m >> 1)
+    m = torch.arange(16, device=dev)
+    idx = ((m & 1) * inner)[None, None, :] + (64 * torch.arange(nch, device=dev))[:, None, None] + \
+        (8 * torch.arange(8, device=dev))[None, :, None] + (m >> 1)[None, None, :]                     # [nch, 8, 16]
+    t1 = w1.detach().to(f16)[idx.reshape(-1)].view(nch, 8, 16, c // 32, 4, 8)                         # [ch, w, l15, s, g, j]
+    w1f = t1.permute(0, 1, 3, 4, 2, 5).contiguous().view(-1, 8)                                        # [ch, w, s, g, l15, j]
+    b1f = b1.detach().float()[idx.reshape(-1)].view(nch, 8, 16).contiguous()
+    w2p = torch.zeros((heads, 16 * dt, inner), dtype=f16, device=dev)
+    w2p[:, :dn] = w2.detach().to(f16).view(heads, dn, inner)
+    t2 = w2p.view(heads, dt, 16, nch, 2, 4, 8)                                                         # [w, t, l15, ch, ks, g, j]
+    w2f = t2.permute(0, 3, 4, 1, 5, 2, 6).contiguous().view(-1, 8)                                     # [w, ch, ks, t, g, l15, j]
+    return w1f, b1f, w2f, b2.detach().float().contiguous()
+
+
+def ff_fused(x, gamma32, beta32, packed, *, eps, out=None):
+    """out = x + GEGLU-FF(LayerNorm(x)) in one launch (i2v_ff_fused_f16); packed = `pack_ff_fused(...)`."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    rows, c = x.shape
+    w1f, b1f, w2f, b2f = packed
+    inner = b1f.numel() // 2
+    for name, t, dt_ in (("gamma32", gamma32, torch.float32), ("beta32", beta32, torch.float32), ("w1", w1f, f16),
+                         ("b1", b1f, torch.float32), ("w2", w2f, f16), ("b2", b2f, torch.float32)):
+        _req(t, name, dtype=dt_)
+    if tuple(gamma32.shape) != (c,) or tuple(beta32.shape) != (c,) or b2f.numel() != c or w1f.numel() != 2 * inner * c or \
+            w2f.numel() != 8 * ((c // 8 + 15) // 16 * 16) * inner:
+        raise ValueError(f"ff_fused: operand sizes do not match C {c}, inner {inner} (pack_ff_fused)")
+    if out is None:
+        out = torch.empty((rows, c), dtype=f16, device=x.device)
+    out, ldo = _mat(out, "out")
+    if tuple(out.shape) != (rows, c):
+        raise ValueError(f"ff_fused: out is {tuple(out.shape)}")
+    p = _lib.FfFusedParams()
+    p.x, p.ldx = _p(x), ldx
+    p.gamma, p.beta = _p(gamma32), _p(beta32)
+    p.w1, p.b1, p.w2, p.b2 = _p(w1f), _p(b1f), _p(w2f), _p(b2f)
+    p.out, p.ldo = _p(out), ldo
+    p.rows, p.channels, p.inner, p.eps = rows, c, inner, float(eps)
+    _lib.check(lib.i2v_ff_fused_f16(C.byref(p), _stream()), "i2v_ff_fused_f16")
+    return out
+
+
 def motion_attn_tables(gamma, beta, pe, frames):
     """(gamma fp32 [C], shift fp32 [frames, C] = beta + pe[frame]): the LayerNorm constants of i2v_motion_attn_f16."""
     return (gamma.detach().float().contiguous(),

@@ -63,6 +63,14 @@ def _work_cattn(args, kw, out):
             f"{rows}x{c} Lk{kw['ctx_len']} h{kw['heads']} d{kw['head_dim']} (LN + q + text attention)")
 
 
+def _work_ff(args, kw, out):
+    x = args[0]
+    rows, c = x.shape
+    inner = args[3][1].numel() // 2
+    return ("ff_fused", 2.0 * rows * c * 2 * inner + 2.0 * rows * inner * c, _numel_bytes(x, args[3][0], args[3][2], out),
+            f"{rows}x{c} inner {inner} (LN + GEGLU FF + residual)")
+
+
 def _work_gn(args, kw, out):
     return "groupnorm", 0.0, 3 * _numel_bytes(out), "x".join(map(str, out.shape))
 
@@ -84,7 +92,7 @@ def _work_misc(name):
 
 _WRAPPED = {
     "gemm": _work_gemm, "conv3x3": _work_conv, "attention": _work_attn, "temporal_attention": _work_tattn,
-    "motion_attn": _work_mattn, "cross_attn_fused": _work_cattn,
+    "motion_attn": _work_mattn, "cross_attn_fused": _work_cattn, "ff_fused": _work_ff,
     "groupnorm": _work_gn, "groupnorm_fold": _work_gn_fold, "layernorm": _work_ln, "silu": _work_misc("elementwise"),
     "copy3d": _work_misc("elementwise"), "timestep_embedding": _work_misc("elementwise"),
     "ddim_prep": _work_misc("elementwise"), "ddim_cfg_step": _work_misc("elementwise"),

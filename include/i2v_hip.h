@@ -265,6 +265,33 @@ int64_t i2v_cross_attn_fused_ctx_elems(int32_t n_ctx, int32_t heads, int32_t hea
 int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* p, i2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The GEGLU feed-forward of a transformer block in one launch (i2v:539-561 `norm3 -> ff -> + residual`; the temporal block's
+ * FeedForward):  out = x + W2 (value o gelu(gate)) + b2  with  [value | gate] = (LayerNorm(x) gamma + beta) W1^T + b1.
+ * The inner activation (rows x inner) never leaves the CU.  LayerNorm output and the inner activation are rounded to fp16 where
+ * the un-fused kernels store them; statistics, GELU (common.h gelu_erf) and accumulation in fp32.  out may alias x.
+ * gamma, beta: fp32 [channels]; b2: fp32 [channels].  Packed operands (fp16 unless noted), with the inner dimension in chunks of 64:
+ *   w1 [inner / 64][8][channels / 32][64][8]: element [ch][w][s][l][j] = W1[(m & 1) * inner + 64 ch + 8 w + (m >> 1)][32 s + 8 (l >> 4) + j],
+ *      m = l & 15  (diffusers GEGLU.proj: rows [0, inner) are the values, [inner, 2 inner) the gates: a tile holds 8 (value, gate) pairs);
+ *   b1 fp32 [inner / 64][8][16]: the same 16 rows' biases;
+ *   w2 [8][inner / 64][2][3][64][8]: element [w][ch][ks][t][l][j] = W2[n = 40 w + 16 t + (l & 15)][64 ch + 32 ks + 8 (l >> 4) + j],
+ *      zero where 16 t + (l & 15) >= 40.
+ * Implemented for the SD-1.5 64^2 level (i2v_ff_fused_supported: channels 320, inner 1280, rows a multiple of 128).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_ff_fused_params {
+  const void* x; int64_t ldx;            /* fp16 [rows, channels] */
+  const void* gamma; const void* beta;   /* fp32 [channels] */
+  const void* w1; const void* b1;
+  const void* w2; const void* b2;
+  void* out; int64_t ldo;                /* fp16 [rows, channels] */
+  int64_t rows;
+  int32_t channels, inner;
+  float eps;
+} i2v_ff_fused_params;
+
+int32_t i2v_ff_fused_supported(int64_t rows, int32_t channels, int32_t inner);
+int i2v_ff_fused_f16(const i2v_ff_fused_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) on token-major fp16: statistics in fp32.
  *   stat group = (frames_per_stat consecutive images) x (all pixels) x (C / groups channels)
  *   frames_per_stat = 1: ResnetBlock2D norm1/norm2, Transformer2D norm, conv_norm_out

@@ -43,7 +43,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_ctypes_structs_match_header(lib):
     names = {"i2v_gemm_params": lib.GemmParams, "i2v_attn_params": lib.AttnParams, "i2v_tattn_params": lib.TAttnParams,
              "i2v_gn_params": lib.GnParams, "i2v_ln_params": lib.LnParams, "i2v_motion_attn_params": lib.MotionAttnParams,
-             "i2v_cross_attn_fused_params": lib.CrossAttnFusedParams}
+             "i2v_cross_attn_fused_params": lib.CrossAttnFusedParams, "i2v_ff_fused_params": lib.FfFusedParams}
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, cls in names.items():
         prog.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -83,6 +83,8 @@ def test_bad_arguments_return_error_codes_without_a_gpu(lib):
     assert h.i2v_motion_attn_f16(C.byref(mp), None) == -1 and b"null pointer" in h.i2v_last_error()
     assert h.i2v_cross_attn_fused_supported(131072, 320, 8, 40, 77, 65536) == 1 and h.i2v_cross_attn_fused_pack_rows(8, 40) == 8 * 48
     assert h.i2v_cross_attn_fused_supported(131072, 320, 8, 40, 81, 65536) == 0 and h.i2v_cross_attn_fused_f16(None, None) == -1
+    assert h.i2v_ff_fused_supported(131072, 320, 1280) == 1 and h.i2v_ff_fused_supported(32768, 640, 2560) == 0
+    assert h.i2v_ff_fused_f16(None, None) == -1
     assert h.i2v_colsum_workspace_bytes(1000, 70) == 4 * 70 * 4 and h.i2v_colsum_det_f32(None, 0, None, 0, None, 0, 0, None, None) == -1
 
 

@@ -176,6 +176,16 @@ def test_full_width_motion_module(dev, c, hw, frames):
             compare(plain, ref, rel=MODULE_REL_TOL, name=f"full-width motion module, un-fused attention sub-block C={c}")
             compare(got, plain, rel=MODULE_REL_TOL, name=f"motion module fused vs un-fused C={c}")
             assert not torch.equal(got, plain)               # (different roundings: the two paths really differ)
+            # the one-launch feed-forward (i2v_ff_fused_f16) against the LayerNorm-folded GEGLU GEMM + output GEMM (I2V_FF_FUSED=0)
+            assert blocks.FUSED_FF and m.transformer_blocks[0].ff.fused_supported(torch.empty(2 * frames * hw * hw, c))
+            blocks.FUSED_FF = False
+            try:
+                plain_ff = m(x.half().to(dev), num_frames=frames)[0]
+            finally:
+                blocks.FUSED_FF = True
+            compare(plain_ff, ref, rel=MODULE_REL_TOL, name=f"full-width motion module, un-fused feed-forward C={c}")
+            compare(got, plain_ff, rel=MODULE_REL_TOL, name=f"motion module fused vs un-fused feed-forward C={c}")
+            assert not torch.equal(got, plain_ff)
 
 
 @pytest.mark.parametrize("kind,c,hw,frames,gain", [("t2d", 320, 32, 16, 4.0), ("t2d", 1280, 8, 16, 3.0), ("motion", 320, 32, 16, 4.0),

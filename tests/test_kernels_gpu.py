@@ -596,6 +596,39 @@ def test_motion_attention_sub_block_fused(dev, npix, amp, strided):
         k.motion_attn(xd[:rows - 16], g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps)
 
 
+@pytest.mark.parametrize("rows,strided", [(128, False), (128 * 300, True), (128 * 771, False)])
+def test_feed_forward_fused(dev, rows, strided):
+    """i2v_ff_fused_f16: x + W2 GEGLU(LayerNorm(x) W1^T + b1) + b2 in one launch (C = 320, inner 1280: the SD-1.5 64^2 level)
+    against fp32 torch on the same fp16-rounded operands and against the un-fused pair (LayerNorm -> GEGLU GEMM -> GEMM + residual)."""
+    k = K()
+    c, inner, eps = 320, 1280, 1e-5
+    assert k.ff_fused_supported(rows, c, inner) and not k.ff_fused_supported(rows + 16, c, inner) and not k.ff_fused_supported(rows, 640, 2560)
+    g = torch.Generator().manual_seed(rows)
+    ld = c + 32 if strided else c
+    xb = h(torch.randn(rows, ld, generator=g) * 1.2 + 0.2)
+    x = xb[:, :c]
+    gamma, beta = h(1 + 0.2 * torch.randn(c, generator=g)), h(0.1 * torch.randn(c, generator=g))
+    w1, b1 = h(torch.randn(2 * inner, c, generator=g) * c ** -0.5), h(0.1 * torch.randn(2 * inner, generator=g))
+    w2, b2 = h(torch.randn(c, inner, generator=g) * inner ** -0.5), h(0.1 * torch.randn(c, generator=g))
+    n = h(F.layer_norm(x, (c,), gamma, beta, eps))
+    pre = n @ w1.T + b1
+    hh = h(pre[:, :inner] * F.gelu(pre[:, inner:]))
+    ref = x + hh @ w2.T + b2
+    D = lambda t: t.half().to(dev)
+    packed = k.pack_ff_fused(D(w1), D(b1), D(w2), D(b2))
+    xd = D(xb)[:, :c]
+    out = k.ff_fused(xd, D(gamma).float(), D(beta).float(), packed, eps=eps)
+    close(out, ref, rel=3e-3, name="fused feed-forward vs fp32 torch")
+    from i2v_adapter_unofficial_amd.blocks import pack_geglu
+    nl = k.layernorm(xd.contiguous(), D(gamma), D(beta), eps)
+    w1p, b1p = pack_geglu(D(w1), D(b1))
+    old = k.gemm(k.gemm(nl, w1p, b1p, epilogue=k.I2V_EPI_GEGLU), D(w2), D(b2), residual=xd.contiguous())
+    close(out, old, rel=1.5e-3, name="fused feed-forward vs the un-fused pair")
+    assert torch.equal(out, k.ff_fused(xd, D(gamma).float(), D(beta).float(), packed, eps=eps))
+    with pytest.raises(Exception, match="not a fused shape"):
+        k.ff_fused(xd[:rows - 16], D(gamma).float(), D(beta).float(), packed, eps=eps)
+
+
 @pytest.mark.parametrize("rows,n_ctx,lt,amp", [(256, 2, 77, 1.0), (128 * 37, 1, 77, 1.0), (1024, 2, 80, 3.0), (512, 4, 5, 1.0)])
 def test_text_cross_attention_sub_block_fused(dev, rows, n_ctx, lt, amp):
     """i2v_cross_attn_fused_f16: LayerNorm, to_q and the attention against a <= 80-token context whose K / V^T are given, in one

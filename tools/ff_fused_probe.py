@@ -1,0 +1,53 @@
+"""Time the one-launch GEGLU feed-forward (i2v_ff_fused_f16) against the pair it replaces at the SD-1.5 64^2 level
+(131072 rows, C = 320, inner 1280): LayerNorm-folded GEGLU GEMM + the output GEMM with the residual."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import i2v_adapter_unofficial_amd as pkg  # noqa: E402
+from i2v_adapter_unofficial_amd.blocks import fold_layernorm_geglu  # noqa: E402
+
+K = pkg.kernels
+dev = torch.device("cuda:0")
+rows, c, inner = 131072, 320, 1280
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn(rows, c, device=dev, generator=g).half()
+gamma, beta = (1 + 0.1 * torch.randn(c, device=dev, generator=g)).half(), (0.1 * torch.randn(c, device=dev, generator=g)).half()
+w1 = torch.randn(2 * inner, c, device=dev, generator=g).mul(c ** -0.5).half()
+b1 = torch.randn(2 * inner, device=dev, generator=g).mul(0.1).half()
+w2 = torch.randn(c, inner, device=dev, generator=g).mul(inner ** -0.5).half()
+b2 = torch.randn(c, device=dev, generator=g).mul(0.1).half()
+packed = K.pack_ff_fused(w1, b1, w2, b2)
+wf, ws, bf = fold_layernorm_geglu(w1, b1, gamma, beta)
+g32, b32 = gamma.float(), beta.float()
+
+
+def timeit(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def old():
+    hmid = K.gemm(x, wf, bf, epilogue=K.I2V_EPI_GEGLU, ln=(ws, 1e-5))
+    return K.gemm(hmid, w2, b2, residual=x)
+
+
+def new():
+    return K.ff_fused(x, g32, b32, packed, eps=1e-5)
+
+
+a, b = old(), new()
+print("max |fused - unfused|", (a.float() - b.float()).abs().max().item(), "max |ref|", a.float().abs().max().item())
+t_old, t_new = timeit(old), timeit(new)
+flop = 2.0 * rows * c * 2 * inner + 2.0 * rows * inner * c
+print(f"un-fused (LayerNorm-folded GEGLU GEMM, output GEMM + residual): {t_old:8.1f} us ({flop / t_old / 1e6:.0f} TFLOP/s)")
+print(f"fused i2v_ff_fused_f16:                                         {t_new:8.1f} us ({flop / t_new / 1e6:.0f} TFLOP/s)")

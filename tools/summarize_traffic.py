@@ -18,6 +18,8 @@ def classify(name):
         return "conv3x3" if m.group(3) == "1" else "gemm"
     if "splitk_reduce" in name:
         return "splitk_reduce"
+    if "ff_fused" in name:
+        return "ff_fused"
     if "motion_attn" in name:      # motion_attn_kernel<C, D, H, CROSS>: the text cross-attention form shares the template
         return "cross_attn_fused" if re.search(r"motion_attn_kernel<[^>]*true>", name) else "motion_attn"
     if "tattn" in name:
