@@ -433,19 +433,19 @@ def pack_ff_fused(w1, b1, w2, b2):
     """(w1 fragments, b1 fp32, w2 fragments, b2 fp32) of i2v_ff_fused_f16 from diffusers' GEGLU.proj (w1 [2 inner, C], rows
     [values ; gates]) and the output Linear (w2 [C, inner]); layouts in include/i2v_hip.h."""
     inner, c = w2.shape[1], w2.shape[0]
-    nch, heads, dn = inner // 64, 8, c // 8
+    nch, heads, dn = inner // 128, 8, c // 8
     dt = (dn + 15) // 16
     dev = w1.device
-    # W1 rows of tile (ch, w): m = 0 .. 15 -> (m & 1) * inner + 64 ch + 8 w + (m >> 1)
+    # W1 rows of tile (ch, w, u): m = 0 .. 15 -> (m & 1) * inner + 128 ch + 16 w + 8 u + (m >> 1)
     m = torch.arange(16, device=dev)
-    idx = ((m & 1) * inner)[None, None, :] + (64 * torch.arange(nch, device=dev))[:, None, None] + \
-        (8 * torch.arange(8, device=dev))[None, :, None] + (m >> 1)[None, None, :]                     # [nch, 8, 16]
-    t1 = w1.detach().to(f16)[idx.reshape(-1)].view(nch, 8, 16, c // 32, 4, 8)                         # [ch, w, l15, s, g, j]
-    w1f = t1.permute(0, 1, 3, 4, 2, 5).contiguous().view(-1, 8)                                        # [ch, w, s, g, l15, j]
-    b1f = b1.detach().float()[idx.reshape(-1)].view(nch, 8, 16).contiguous()
+    idx = ((m & 1) * inner + (m >> 1))[None, None, None, :] + (128 * torch.arange(nch, device=dev))[:, None, None, None] + \
+        (16 * torch.arange(8, device=dev))[None, :, None, None] + (8 * torch.arange(2, device=dev))[None, None, :, None]   # [nch, 8, 2, 16]
+    t1 = w1.detach().to(f16)[idx.reshape(-1)].view(nch, 8, 2, 16, c // 32, 4, 8)                      # [ch, w, u, l15, s, g, j]
+    w1f = t1.permute(0, 1, 2, 4, 5, 3, 6).contiguous().view(-1, 8)                                     # [ch, w, u, s, g, l15, j]
+    b1f = b1.detach().float()[idx.reshape(-1)].view(nch, 8, 2, 16).contiguous()
     w2p = torch.zeros((heads, 16 * dt, inner), dtype=f16, device=dev)
     w2p[:, :dn] = w2.detach().to(f16).view(heads, dn, inner)
-    t2 = w2p.view(heads, dt, 16, nch, 2, 4, 8)                                                         # [w, t, l15, ch, ks, g, j]
+    t2 = w2p.view(heads, dt, 16, nch, 4, 4, 8)                                                         # [w, t, l15, ch, ks, g, j]
     w2f = t2.permute(0, 3, 4, 1, 5, 2, 6).contiguous().view(-1, 8)                                     # [w, ch, ks, t, g, l15, j]
     return w1f, b1f, w2f, b2.detach().float().contiguous()
 

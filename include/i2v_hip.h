@@ -269,11 +269,12 @@ int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* p, i2v_stream_t 
  * FeedForward):  out = x + W2 (value o gelu(gate)) + b2  with  [value | gate] = (LayerNorm(x) gamma + beta) W1^T + b1.
  * The inner activation (rows x inner) never leaves the CU.  LayerNorm output and the inner activation are rounded to fp16 where
  * the un-fused kernels store them; statistics, GELU (common.h gelu_erf) and accumulation in fp32.  out may alias x.
- * gamma, beta: fp32 [channels]; b2: fp32 [channels].  Packed operands (fp16 unless noted), with the inner dimension in chunks of 64:
- *   w1 [inner / 64][8][channels / 32][64][8]: element [ch][w][s][l][j] = W1[(m & 1) * inner + 64 ch + 8 w + (m >> 1)][32 s + 8 (l >> 4) + j],
- *      m = l & 15  (diffusers GEGLU.proj: rows [0, inner) are the values, [inner, 2 inner) the gates: a tile holds 8 (value, gate) pairs);
- *   b1 fp32 [inner / 64][8][16]: the same 16 rows' biases;
- *   w2 [8][inner / 64][2][3][64][8]: element [w][ch][ks][t][l][j] = W2[n = 40 w + 16 t + (l & 15)][64 ch + 32 ks + 8 (l >> 4) + j],
+ * gamma, beta: fp32 [channels]; b2: fp32 [channels].  Packed operands (fp16 unless noted), with the inner dimension in chunks of 128:
+ *   w1 [inner / 128][8][2][channels / 32][64][8]: element [ch][w][u][s][l][j] =
+ *      W1[(m & 1) * inner + 128 ch + 16 w + 8 u + (m >> 1)][32 s + 8 (l >> 4) + j], m = l & 15  (diffusers GEGLU.proj: rows
+ *      [0, inner) are the values, [inner, 2 inner) the gates: a 16-row tile holds 8 (value, gate) pairs);
+ *   b1 fp32 [inner / 128][8][2][16]: the same rows' biases;
+ *   w2 [8][inner / 128][4][3][64][8]: element [w][ch][ks][t][l][j] = W2[n = 40 w + 16 t + (l & 15)][128 ch + 32 ks + 8 (l >> 4) + j],
  *      zero where 16 t + (l & 15) >= 40.
  * Implemented for the SD-1.5 64^2 level (i2v_ff_fused_supported: channels 320, inner 1280, rows a multiple of 128).
  * ------------------------------------------------------------------------------------------------ */

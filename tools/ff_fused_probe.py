@@ -5,6 +5,10 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
+stamps = "--stamps" in sys.argv
+if stamps:       # a -DI2V_FF_STAMPS build reads the buffer's address from the environment
+    sbuf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda:0")
+    os.environ["I2V_FF_STAMP_PTR"] = str(sbuf.data_ptr())
 import i2v_adapter_unofficial_amd as pkg  # noqa: E402
 from i2v_adapter_unofficial_amd.blocks import fold_layernorm_geglu  # noqa: E402
 
@@ -51,3 +55,14 @@ t_old, t_new = timeit(old), timeit(new)
 flop = 2.0 * rows * c * 2 * inner + 2.0 * rows * inner * c
 print(f"un-fused (LayerNorm-folded GEGLU GEMM, output GEMM + residual): {t_old:8.1f} us ({flop / t_old / 1e6:.0f} TFLOP/s)")
 print(f"fused i2v_ff_fused_f16:                                         {t_new:8.1f} us ({flop / t_new / 1e6:.0f} TFLOP/s)")
+
+if stamps:
+    sbuf.zero_()
+    new()
+    torch.cuda.synchronize()
+    st = sbuf.view(256, 8, 8).cpu().double()[:, :, :6]
+    names = ["load + LN", "FF1", "GEGLU + write", "barrier", "FF2", "epilogue"]
+    print("cycles per workgroup (4 tiles), by phase, mean over workgroups; waves 0-3 / 4-7")
+    for i, n in enumerate(names):
+        print(f"  {n:14s} {st[:, :4, i].mean():10.0f} {st[:, 4:, i].mean():10.0f}")
+    print(f"  total          {st[:, :4].sum(-1).mean():10.0f} {st[:, 4:].sum(-1).mean():10.0f}")
