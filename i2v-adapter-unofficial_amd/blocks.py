@@ -436,8 +436,18 @@ class Attention(HipModule):
         sig = (k.data_ptr(), k._version, vt.data_ptr(), vt._version)
         hit = ctx_text.frag.get(self)
         if hit is None or hit[0] != sig:
-            hit = ctx_text.frag[self] = (sig, K.pack_ctx_fragments(k, vt, self.heads, lt))
+            # (a stale entry is rewritten IN PLACE: a captured graph may be reading that buffer)
+            hit = ctx_text.frag[self] = (sig, K.pack_ctx_fragments(k, vt, self.heads, lt, out=None if hit is None else hit[1]))
         return hit[1]
+
+    def refresh_context_fragments(self, pc):
+        """after `project_kv(..., out=...)` rewrote this layer's K / V^T of a ProjectedContext in place (the next prompt of a
+        captured hipGraph): bring the fragments made from them up to date in THEIR buffer -- the graph reads that memory and no
+        Python runs between its replays."""
+        hit = pc.frag.get(self)
+        if hit is not None:       # unconditionally: the library's kernels write through raw pointers, no version counter moves
+            k, vt, _kip, _vtip, lt, _li = self.context_kv(pc, None)
+            K.pack_ctx_fragments(k, vt, self.heads, lt, out=hit[1])
 
     def _cross(self, q, ctx_text, ctx_ip, batch_q, lq, kv_group, kv=None):
         """softmax(q Kt^T) Vt (+ ip_scale * softmax(q Kip^T) Vip) for context tensors [Bc, L, D] (or a

@@ -370,10 +370,11 @@ def cross_attn_fused_supported(rows, channels, heads, head_dim, ctx_len, rows_pe
     return bool(_lib.load().i2v_cross_attn_fused_supported(rows, channels, heads, head_dim, ctx_len, rows_per_ctx))
 
 
-def pack_ctx_fragments(k, vt, heads, ctx_len):
+def pack_ctx_fragments(k, vt, heads, ctx_len, out=None):
     """`ctx_frag` of i2v_cross_attn_fused_f16 from the projected context as the other kernels take it -- k [n_ctx * ctx_len, C],
     vt [n_ctx, C, >= ctx_len] (V^T) -- as MFMA operand fragments [n_ctx][heads][30][64][4], zero beyond the context's length
-    and the head's width.  A handful of small torch ops: done once per prompt (`ProjectedContext`), not per step."""
+    and the head's width.  A handful of small torch ops: done once per prompt (`ProjectedContext`), not per step.
+    `out`: a previous result to overwrite in place (a captured hipGraph keeps reading that memory for the next prompt)."""
     n_ctx, c = vt.shape[0], vt.shape[1]
     d = c // heads
     dt, kt_n = (d + 15) // 16, 5
@@ -385,9 +386,14 @@ def pack_ctx_fragments(k, vt, heads, ctx_len):
     vp = torch.zeros((n_ctx, heads, 16 * dt, 16 * kt_n), dtype=f16, device=k.device)
     vp[:, :, :d, :ctx_len] = vt[:, :, :ctx_len].reshape(n_ctx, heads, d, ctx_len)
     vf = vp.view(n_ctx, heads, dt, 16, kt_n, 4, 4).permute(0, 1, 2, 4, 5, 3, 6)               # [n, h, t, kt, g, r, j]
-    out = torch.cat([kf.reshape(n_ctx, heads, kt_n * dt, 64, 4), vf.reshape(n_ctx, heads, dt * kt_n, 64, 4)], dim=2).contiguous()
-    if out.numel() != _lib.load().i2v_cross_attn_fused_ctx_elems(n_ctx, heads, d):
+    new = torch.cat([kf.reshape(n_ctx, heads, kt_n * dt, 64, 4), vf.reshape(n_ctx, heads, dt * kt_n, 64, 4)], dim=2).contiguous()
+    if new.numel() != _lib.load().i2v_cross_attn_fused_ctx_elems(n_ctx, heads, d):
         raise RuntimeError("pack_ctx_fragments: size differs from i2v_cross_attn_fused_ctx_elems")
+    if out is None:
+        return new
+    if out.shape != new.shape or out.dtype != new.dtype:
+        raise ValueError(f"pack_ctx_fragments: out is {tuple(out.shape)}, expected {tuple(new.shape)}")
+    out.copy_(new)
     return out
 
 

@@ -621,6 +621,7 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
             pc.text, pc.ip = ctx_text, ctx_ip
         for attn in self._cross_attention_layers():
             pc.kv[attn] = attn.project_kv(ctx_text, ctx_ip, out=pc.kv.get(attn))
+            attn.refresh_context_fragments(pc)       # (the fused text cross-attention's packed K / V, where a forward made them)
         return pc
 
     def _temb_pack(self):

@@ -465,6 +465,30 @@ def test_config4_full_size_two_samples_per_replay(dev, pair_ip):
     assert torch.equal(eager, both)
 
 
+def test_graph_reuse_with_a_new_prompt_refreshes_the_packed_context(dev, pair):
+    """A captured step is replayed for the next sample of the same shape with its inputs copied into the graph's buffers
+    (pipeline `_run_steps`); the fused text cross-attention reads the prompt's K / V as packed MFMA fragments, which must be
+    rewritten IN PLACE with the new prompt's (no Python runs between replays).  Sample B through a pipeline that captured its
+    graph on sample A must equal sample B through a fresh pipeline bit for bit, and differ from sample A.  16 frames at
+    128 x 128: all three fused sub-block kernels are on the path (C = 320 at the top level, rows a multiple of 128)."""
+    hu = pair[1]
+    frames, lat = 16, 16
+    inp = _batch_inputs(2, frames, lat, seed=46)
+    assert pkg().kernels.cross_attn_fused_supported(2 * frames * lat * lat, 320, 8, 40, 77, frames * lat * lat)
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+    a = _pipe_call(pipe, inp, [0], frames)
+    b_reused = _pipe_call(pipe, inp, [1], frames)                   # cache hit: same shapes, new prompt / image / noise
+    b_fresh = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp, [1], frames)
+    assert torch.equal(b_reused, b_fresh), (b_reused - b_fresh).abs().max().item()
+    assert (a - b_fresh).abs().max().item() > 0.1
+    # and the same prompt changed in isolation (same latents, same noise): only the context differs
+    inp2 = dict(inp)
+    inp2["pe"] = inp["pe"].flip(0).contiguous()
+    c_reused = _pipe_call(pipe, inp2, [1], frames)
+    c_fresh = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp2, [1], frames)
+    assert torch.equal(c_reused, c_fresh) and not torch.equal(c_fresh, b_fresh)
+
+
 def test_config4_two_sample_cfg_forward_vs_oracle(dev, pair_ip):
     """one CFG forward of TWO samples (batch 4 = [neg_0, neg_1, pos_0, pos_1]) with IP tokens against the oracle: the
     per-sample structure (frame-0 K / V per clip, context and time rows per sample) at SD-1.5 width."""
