@@ -113,6 +113,7 @@ class CrossAttnFusedParams(C.Structure):
         ("rows", C.c_int64), ("rows_per_ctx", C.c_int64),
         ("channels", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("ctx_len", C.c_int32),
         ("eps", C.c_float), ("scale", C.c_float),
+        ("ip_frag", C.c_void_p), ("ip_len", C.c_int32), ("ip_scale", C.c_float),
     ]
 
 

@@ -428,26 +428,30 @@ class Attention(HipModule):
         return k, vt, kip, vtip, lt, li
 
     def context_fragments(self, ctx_text, kv):
-        """the text context's K / V of this layer as the fragments i2v_cross_attn_fused_f16 keeps in registers: cached on a
-        ProjectedContext (once per prompt; refreshed when its projections are rewritten in place), packed per call otherwise."""
-        k, vt, _kip, _vtip, lt, _li = kv
+        """(text fragments, image-token fragments or None): this layer's K / V of the context as the fragments
+        i2v_cross_attn_fused_f16 keeps in registers -- cached on a ProjectedContext (once per prompt; `project_context(..., out=)`
+        rewrites them in place), packed per call otherwise."""
+        k, vt, kip, vtip, lt, li = kv
+        use_ip = kip is not None and bool(self.ip_num_tokens)
         if not isinstance(ctx_text, ProjectedContext):
-            return K.pack_ctx_fragments(k, vt, self.heads, lt)
-        sig = (k.data_ptr(), k._version, vt.data_ptr(), vt._version)
+            return K.pack_ctx_fragments(k, vt, self.heads, lt), (K.pack_ctx_fragments(kip, vtip, self.heads, li) if use_ip else None)
         hit = ctx_text.frag.get(self)
-        if hit is None or hit[0] != sig:
-            # (a stale entry is rewritten IN PLACE: a captured graph may be reading that buffer)
-            hit = ctx_text.frag[self] = (sig, K.pack_ctx_fragments(k, vt, self.heads, lt, out=None if hit is None else hit[1]))
-        return hit[1]
+        if hit is None:
+            hit = ctx_text.frag[self] = (K.pack_ctx_fragments(k, vt, self.heads, lt),
+                                         K.pack_ctx_fragments(kip, vtip, self.heads, li) if use_ip else None)
+        return hit
 
     def refresh_context_fragments(self, pc):
         """after `project_kv(..., out=...)` rewrote this layer's K / V^T of a ProjectedContext in place (the next prompt of a
-        captured hipGraph): bring the fragments made from them up to date in THEIR buffer -- the graph reads that memory and no
-        Python runs between its replays."""
+        captured hipGraph): bring the fragments made from them up to date in THEIR buffers -- the graph reads that memory and no
+        Python runs between its replays.  Unconditionally: the library's kernels write through raw pointers, no tensor version
+        counter moves."""
         hit = pc.frag.get(self)
-        if hit is not None:       # unconditionally: the library's kernels write through raw pointers, no version counter moves
-            k, vt, _kip, _vtip, lt, _li = self.context_kv(pc, None)
-            K.pack_ctx_fragments(k, vt, self.heads, lt, out=hit[1])
+        if hit is not None:
+            k, vt, kip, vtip, lt, li = self.context_kv(pc, None)
+            K.pack_ctx_fragments(k, vt, self.heads, lt, out=hit[0])
+            if hit[1] is not None:
+                K.pack_ctx_fragments(kip, vtip, self.heads, li, out=hit[1])
 
     def _cross(self, q, ctx_text, ctx_ip, batch_q, lq, kv_group, kv=None):
         """softmax(q Kt^T) Vt (+ ip_scale * softmax(q Kip^T) Vip) for context tensors [Bc, L, D] (or a

@@ -61,6 +61,8 @@ struct ma_args {
   // CROSS only: the context's projected keys and values as MFMA fragments (i2v_cross_attn_fused_params.ctx_frag)
   const void* ctx_frag;
   int32_t lt; int32_t tiles_per_ctx;
+  // CROSS, optional: the IP-Adapter's image tokens of the same rows' context (a second softmax, added with its own weight)
+  const void* ip_frag; int32_t ip_len; float ip_scale;
 };
 
 constexpr int MA_KT = 5;               // CROSS: key tiles of 16 (<= 80 context tokens: the 77 of CLIP)
@@ -270,6 +272,18 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
           kf[kt][t] = *reinterpret_cast<const f16x4*>(cf + (kt * DT + t) * 256);
           vf[t][kt] = *reinterpret_cast<const f16x4*>(cf + (MA_KT * DT + t * MA_KT + kt) * 256);
         }
+      // decoupled image cross-attention of the IP-Adapter (softmax(q K_ip^T) V_ip over <= 16 image tokens, added with
+      // ip_scale): the first key tile of a second fragment set in the same layout
+      const bool has_ip = p.ip_len > 0;             // (workgroup-uniform)
+      f16x4 kfi[DT], vfi[DT];
+      if (has_ip) {
+        const f16* ci = reinterpret_cast<const f16*>(p.ip_frag) + ((int64_t)ctx * H + wave) * (2 * MA_KT * DT * 256) + lane * 4;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          kfi[t] = *reinterpret_cast<const f16x4*>(ci + t * 256);
+          vfi[t] = *reinterpret_cast<const f16x4*>(ci + (MA_KT * DT + t * MA_KT) * 256);
+        }
+      }
       MA_STAMP(4);
       MA_STAMP(5);
       f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
@@ -305,14 +319,41 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
         f16x4 pk[MA_KT];
 #pragma unroll
         for (int kt = 0; kt < MA_KT; ++kt) pk[kt] = f16x4{(f16)sv[kt][0], (f16)sv[kt][1], (f16)sv[kt][2], (f16)sv[kt][3]};
-        u32x2 oh[DT];
+        f32x4 ov[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
           f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kt = 0; kt < MA_KT; ++kt) o = mfma16x16x16(vf[t][kt], pk[kt], o);
-          oh[t] = __builtin_bit_cast(u32x2, to_half(o * inv));
+          ov[t] = o * inv;
         }
+        if (has_ip) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < DT; ++t) sacc = mfma16x16x16(kfi[t], qh[pix][t], sacc);
+          float si[4];
+          float mi = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            si[r] = (4 * g + r < p.ip_len) ? sacc[r] : -INFINITY;
+            mi = fmaxf(mi, si[r]);
+          }
+          mi = lane_xor32_max(lane_xor16_max(mi));
+          float li = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            si[r] = __builtin_amdgcn_exp2f(si[r] - mi);
+            li += si[r];
+          }
+          li = lane_xor32_sum(lane_xor16_sum(li));
+          const float wi = p.ip_scale / li;
+          const f16x4 pi = {(f16)si[0], (f16)si[1], (f16)si[2], (f16)si[3]};
+#pragma unroll
+          for (int t = 0; t < DT; ++t) ov[t] += mfma16x16x16(vfi[t], pi, f32x4{0.f, 0.f, 0.f, 0.f}) * wi;
+        }
+        u32x2 oh[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) oh[t] = __builtin_bit_cast(u32x2, to_half(ov[t]));
         store_tiles(O + (int64_t)(16 * pix + l15) * p.ldo, oh);
       }
       MA_STAMP(6);
@@ -453,12 +494,15 @@ extern "C" int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* pp, i
                 "(i2v_cross_attn_fused_supported)", (long long)p.rows, p.channels, p.heads, p.head_dim, p.ctx_len,
                 (long long)p.rows_per_ctx);
   I2V_CHECK_ARG(p.ldx >= p.channels && p.ldx % 8 == 0 && p.ldo >= p.channels && p.ldo % 8 == 0, "i2v_cross_attn_fused_f16: row strides");
-  I2V_CHECK_ARG(al16(p.x) && al16(p.gamma) && al16(p.beta) && al16(p.w_q) && al16(p.out) && al16(p.ctx_frag),
+  I2V_CHECK_ARG(al16(p.x) && al16(p.gamma) && al16(p.beta) && al16(p.w_q) && al16(p.out) && al16(p.ctx_frag) && al16(p.ip_frag),
                 "i2v_cross_attn_fused_f16: pointers must be 16-byte aligned");
+  I2V_CHECK_ARG(p.ip_frag == nullptr || (p.ip_len >= 1 && p.ip_len <= 16), "i2v_cross_attn_fused_f16: ip_len (%d) must be in [1, 16]",
+                p.ip_len);
   ma_args a = {};
   a.x = p.x; a.ldx = p.ldx; a.gamma = p.gamma; a.shift = p.beta; a.ld_shift = 0; a.w = p.w_q; a.out = p.out; a.ldo = p.ldo;
   a.eps = p.eps;
   a.ctx_frag = p.ctx_frag; a.lt = p.ctx_len;
+  a.ip_frag = p.ip_frag; a.ip_len = p.ip_frag ? p.ip_len : 0; a.ip_scale = p.ip_scale;
   a.tiles_per_ctx = (int32_t)(p.rows_per_ctx / (MA_PIX * MA_F));
   return launch_ma<320, 40, 8, true>(a, p.rows, p.scale, reinterpret_cast<hipStream_t>(stream), "i2v_cross_attn_fused_f16");
 }

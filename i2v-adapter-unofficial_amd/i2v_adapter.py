@@ -230,13 +230,15 @@ class I2VAdapterTransformerBlock(HipModule):
                 raise ValueError(f"context batch {ctx_text.shape[0]} does not divide batch {n_img}")
             kv_group = n_img // ctx_text.shape[0]
             kv = self.attn2.context_kv(ctx_text, ctx_ip)
-            k, vt, kip, _vtip, lt, _li = kv
-            no_ip = kip is None or not self.attn2.ip_num_tokens
-            if FUSED_TEXT_ATTN and no_ip and K.cross_attn_fused_supported(x.shape[0], c, self.heads, self.dim_head, lt, kv_group * L):
-                # LayerNorm 2, to_q and the attention over the <= 80 context tokens in one launch (64^2 level of SD-1.5)
-                o = K.cross_attn_fused(x, p["g2_f32"], p["b2_f32"], p["wq2_frag"], self.attn2.context_fragments(ctx_text, kv), heads=self.heads,
-                                       head_dim=self.dim_head, ctx_len=lt, rows_per_ctx=kv_group * L, eps=self.eps,
-                                       scale=self.attn2.scale)
+            _k, _vt, kip, _vtip, lt, li = kv
+            use_ip = kip is not None and bool(self.attn2.ip_num_tokens)
+            if FUSED_TEXT_ATTN and (not use_ip or li <= 16) and \
+                    K.cross_attn_fused_supported(x.shape[0], c, self.heads, self.dim_head, lt, kv_group * L):
+                # LayerNorm 2, to_q and the attention over the <= 80 context tokens (+ the IP-Adapter's image tokens) in one launch
+                frag, frag_ip = self.attn2.context_fragments(ctx_text, kv)
+                o = K.cross_attn_fused(x, p["g2_f32"], p["b2_f32"], p["wq2_frag"], frag, heads=self.heads, head_dim=self.dim_head,
+                                       ctx_len=lt, rows_per_ctx=kv_group * L, eps=self.eps, scale=self.attn2.scale,
+                                       ip_frag=frag_ip, ip_len=li if use_ip else 0, ip_scale=float(self.attn2.ip_scale))
             else:
                 if fold2:
                     wf, ws, cb = p["f_q2"]

@@ -397,9 +397,11 @@ def pack_ctx_fragments(k, vt, heads, ctx_len, out=None):
     return out
 
 
-def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_len, rows_per_ctx, eps, scale=None, out=None):
+def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_len, rows_per_ctx, eps, scale=None, out=None,
+                     ip_frag=None, ip_len=0, ip_scale=1.0):
     """o = softmax((LayerNorm(x) Wq^T) K^T) V against a short context (i2v_cross_attn_fused_f16): x [rows, C]; ctx_frag from
-    `pack_ctx_fragments`; rows [i * rows_per_ctx, (i + 1) * rows_per_ctx) use context i."""
+    `pack_ctx_fragments`; rows [i * rows_per_ctx, (i + 1) * rows_per_ctx) use context i.  ip_frag (+ ip_len <= 16, ip_scale):
+    the IP-Adapter's image tokens packed the same way; their softmax is added with weight ip_scale."""
     lib = _lib.load()
     x, ldx = _mat(x, "x")
     rows, c = x.shape
@@ -426,6 +428,11 @@ def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_
     p.rows, p.rows_per_ctx = rows, rows_per_ctx
     p.channels, p.heads, p.head_dim, p.ctx_len = c, heads, head_dim, ctx_len
     p.eps, p.scale = float(eps), float(head_dim) ** -0.5 if scale is None else float(scale)
+    if ip_frag is not None:
+        _req(ip_frag, "ip_frag")
+        if not ip_frag.is_contiguous() or ip_frag.numel() != ctx_frag.numel():
+            raise ValueError(f"cross_attn_fused: ip_frag is {tuple(ip_frag.shape)} (pack_ctx_fragments of the image tokens)")
+        p.ip_frag, p.ip_len, p.ip_scale = _p(ip_frag), int(ip_len), float(ip_scale)
     _lib.check(lib.i2v_cross_attn_fused_f16(C.byref(p), _stream()), "i2v_cross_attn_fused_f16")
     return out
 

@@ -244,8 +244,9 @@ int i2v_motion_attn_f16(const i2v_motion_attn_params* p, i2v_stream_t stream);
  *   [c][h][15 + 5 t + kt][16 g + r][j] = V[c][key = 16 kt + 4 g + j][h * head_dim + 16 t + r]
  * and zero wherever key >= ctx_len or the channel offset >= head_dim.
  * Implemented where i2v_cross_attn_fused_supported(...) != 0: channels 320, 8 heads of 40, ctx_len <= 80, rows and
- * rows_per_ctx multiples of 128 (the SD-1.5 64^2 level).  The IP-Adapter's second softmax is not part of it: callers with
- * image tokens use the un-fused kernels.
+ * rows_per_ctx multiples of 128 (the SD-1.5 64^2 level).
+ * ip_frag (optional, NULL = none): the IP-Adapter's image tokens of the same contexts (unet:1263-1279) packed the
+ * same way from to_k_ip / to_v_ip (ip_len <= 16 tokens, i.e. key tile 0 of the layout): out += ip_scale * softmax(q K_ip^T * scale) V_ip.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct i2v_cross_attn_fused_params {
   const void* x; int64_t ldx;            /* fp16 [rows, channels] */
@@ -256,6 +257,7 @@ typedef struct i2v_cross_attn_fused_params {
   int64_t rows, rows_per_ctx;
   int32_t channels, heads, head_dim, ctx_len;
   float eps, scale;
+  const void* ip_frag; int32_t ip_len; float ip_scale;
 } i2v_cross_attn_fused_params;
 
 int32_t i2v_cross_attn_fused_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t ctx_len,

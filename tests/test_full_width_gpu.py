@@ -465,13 +465,21 @@ def test_config4_full_size_two_samples_per_replay(dev, pair_ip):
     assert torch.equal(eager, both)
 
 
+def test_graph_reuse_with_a_new_prompt_and_image_refreshes_the_packed_context(dev, pair_ip):
+    """the same with the IP-Adapter installed: the image tokens' packed K / V are a second buffer the graph reads"""
+    _graph_reuse_case(pair_ip[1])
+
+
 def test_graph_reuse_with_a_new_prompt_refreshes_the_packed_context(dev, pair):
     """A captured step is replayed for the next sample of the same shape with its inputs copied into the graph's buffers
     (pipeline `_run_steps`); the fused text cross-attention reads the prompt's K / V as packed MFMA fragments, which must be
     rewritten IN PLACE with the new prompt's (no Python runs between replays).  Sample B through a pipeline that captured its
     graph on sample A must equal sample B through a fresh pipeline bit for bit, and differ from sample A.  16 frames at
     128 x 128: all three fused sub-block kernels are on the path (C = 320 at the top level, rows a multiple of 128)."""
-    hu = pair[1]
+    _graph_reuse_case(pair[1])
+
+
+def _graph_reuse_case(hu):
     frames, lat = 16, 16
     inp = _batch_inputs(2, frames, lat, seed=46)
     assert pkg().kernels.cross_attn_fused_supported(2 * frames * lat * lat, 320, 8, 40, 77, frames * lat * lat)
@@ -484,6 +492,7 @@ def test_graph_reuse_with_a_new_prompt_refreshes_the_packed_context(dev, pair):
     # and the same prompt changed in isolation (same latents, same noise): only the context differs
     inp2 = dict(inp)
     inp2["pe"] = inp["pe"].flip(0).contiguous()
+    inp2["ie"] = inp["ie"].flip(0).contiguous()
     c_reused = _pipe_call(pipe, inp2, [1], frames)
     c_fresh = _pipe_call(pkg().I2VAdapterPipeline(unet=hu), inp2, [1], frames)
     assert torch.equal(c_reused, c_fresh) and not torch.equal(c_fresh, b_fresh)

@@ -664,6 +664,20 @@ def test_text_cross_attention_sub_block_fused(dev, rows, n_ctx, lt, amp):
     old = k.attention(k.gemm(nl, D(wq)), kd, vtd, batch_q=n_ctx, lq=rpc, lk=lt, heads=heads, head_dim=d)
     close(out, old, rel=1.5e-3 * amp * amp, name="fused text cross-attention vs the un-fused kernels")
     assert torch.equal(out, k.cross_attn_fused(xd, g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps))
+    # + the IP-Adapter's decoupled image cross-attention (4 image tokens, weight 0.7): a second softmax over its own K / V
+    li, ip_scale = 4, 0.7
+    ki, vi = h(torch.randn(n_ctx, li, c, generator=g) * amp), h(torch.randn(n_ctx, li, c, generator=g))
+    ref_ip = ref + ip_scale * _attn_ref(q.view(n_ctx, rpc, c), ki, vi, heads, 1).reshape(rows, c)
+    vti = torch.full((n_ctx, c, k.pad8(li)), float("nan"))
+    vti[:, :, :li] = vi.permute(0, 2, 1)
+    frag_ip = k.pack_ctx_fragments(D(ki.reshape(-1, c)), D(vti), heads, li)
+    out_ip = k.cross_attn_fused(xd, g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps,
+                                ip_frag=frag_ip, ip_len=li, ip_scale=ip_scale)
+    close(out_ip, ref_ip, rel=3e-3 * amp * amp, name="fused text + image cross-attention vs fp32 torch")
+    old_ip = old.clone()
+    k.attention(k.gemm(nl, D(wq)), D(ki.reshape(-1, c)), D(vti), batch_q=n_ctx, lq=rpc, lk=li, heads=heads, head_dim=d, out=old_ip,
+                accumulate=True, acc_scale=ip_scale)
+    close(out_ip, old_ip, rel=1.5e-3 * amp * amp, name="fused text + image cross-attention vs the un-fused kernels")
     with pytest.raises(Exception, match="not a fused shape"):
         k.cross_attn_fused(xd[:rows - 16], g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps)
 
