@@ -625,6 +625,9 @@ def test_feed_forward_fused(dev, rows, strided):
     old = k.gemm(k.gemm(nl, w1p, b1p, epilogue=k.I2V_EPI_GEGLU), D(w2), D(b2), residual=xd.contiguous())
     close(out, old, rel=1.5e-3, name="fused feed-forward vs the un-fused pair")
     assert torch.equal(out, k.ff_fused(xd, D(gamma).float(), D(beta).float(), packed, eps=eps))
+    inplace = xd.contiguous().clone()            # out may alias x: a tile's rows are read (twice) and written by one workgroup only
+    k.ff_fused(inplace, D(gamma).float(), D(beta).float(), packed, eps=eps, out=inplace)
+    assert torch.equal(inplace, out)
     with pytest.raises(Exception, match="not a fused shape"):
         k.ff_fused(xd[:rows - 16], D(gamma).float(), D(beta).float(), packed, eps=eps)
 
