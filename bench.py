@@ -524,8 +524,9 @@ def main():
         if rank == 0:
             load_group(groups[0])
             torch.cuda._sleep(int(2.0e8))   # ~0.1 s device-side spin (not one of our kernels): the host runs ahead
-            # (single-stream for this one step: the event pairs must bracket one kernel each; the timed replays above
-            #  run the small levels' independent chains on two streams, streams.py)
+            # (single-stream for this one step: the event pairs must bracket one kernel each.  The timed replays above are
+            #  single-stream too by default -- the two-stream form of the small levels' chains, streams.py, is an
+            #  off-by-default experiment (I2V_STREAMS=1); `disabled()` only matters when it is switched on)
             from i2v_adapter_unofficial_amd import streams
             with KernelProfile() as prof, streams.disabled():
                 pipe._step(st)
@@ -617,7 +618,12 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SD-v1.5 + motion-adapter-v1-5-2 + I2V-Adapter topology, {F}f x {args.size}x{args.size}, "
                                    f"CFG 7.5 (B=2 per sample), DDIM 25-step table, fp16, IP {'on' if ip else 'off'}, "
-                                   f"{n_pairs_total} sample(s) over {world} GPU(s), {B} per graph replay (BASELINE {cfg_name})",
+                                   f"{n_pairs_total} sample(s) over {world} GPU(s), {B} per graph replay (BASELINE {cfg_name}); "
+                                   "hoisted out of the timed step, computed once per sample as the product pipeline does "
+                                   "(pipeline_i2v_adapter.py _run_steps): the context K / V^T of the 16 cross-attention layers "
+                                   "and the time-embedding chain of every timestep of the schedule (the step copies its row)",
+                       "hoisted_per_sample": ["context K / V^T projections of the 16 cross-attention layers (prompt + image tokens)",
+                                              "time_proj -> time_embedding -> silu -> 22 time_emb_proj for all timesteps of the schedule"],
                        "samples_total": n_pairs_total, "samples_per_replay": B, "graph": used_graph, "finite": finite,
                        "unet_forwards_per_cfg_half_per_sec": 2 * value,
                        "cfg_shared_prefix": bool(pl.CFG_SHARED),

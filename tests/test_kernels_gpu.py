@@ -430,9 +430,18 @@ def _variants_env(**switches):
     if missing or handle.i2v_abi_version() != pkg._lib.ABI_VERSION:
         pytest.skip(f".ab_libs/variants.so is older than include/i2v_hip.h (missing {missing[:3]}): rebuild it with "
                     "bash tools/build_variant.sh --variants")
+    # ... and one that was not built from THIS tree's kernel sources proves nothing about them (tools/build_variant.sh writes the
+    # hash of csrc/ + the header beside the library)
+    stamp_file = lib + ".stamp"
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    headers = [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")] + [os.path.join(root, "include", "i2v_hip.h")]
+    if not os.path.exists(stamp_file) or open(stamp_file).read().strip() != ge._stamp(headers):
+        pytest.skip(".ab_libs/variants.so was not built from this tree's kernel sources: bash tools/build_variant.sh --variants")
     return dict(os.environ, I2V_LIB_PATH=lib, **switches)
 
 
+@pytest.mark.variants
 def test_attention_32x32_formulation_opt_in(dev):
     """the head_dim-40 kernel on 32x32x16 MFMAs (csrc/variants/attention32.hip) is opt-in (I2V_ATTN32=1, read once per process): run
     it in a child process against torch SDPA, with a query tail, a key tail, K/V sharing and the accumulate form."""
@@ -466,6 +475,7 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.variants
 def test_attention_software_pipelined_opt_in_child_process(dev):
     """I2V_ATTN_PIPE=1 (read once per process, hence the child): the three-stage software-pipelined key loop of csrc/variants/attention_pipe.hip
     for head_dim 40 and whole 64-key tiles -- same results as the default kernel at unit and at large logits, odd and even tile
@@ -830,6 +840,7 @@ def test_gemm_k320_row_major_flavours(dev, M, N, kind):
     _ws_case(dev, M, N, kind)
 
 
+@pytest.mark.variants
 def test_gemm_weight_stationary_opt_in_child_process(dev):
     """csrc/variants/gemm_ws.hip (W slices in registers, A through three LDS stages; measured not faster, opt-in
     I2V_GEMM_WS=1 in the variants library): the same cases in a child process."""
@@ -1102,6 +1113,7 @@ def test_bad_arguments_raise(dev):
                     torch.zeros(1, 12, 8, dtype=torch.float16, device=dev), batch_q=1, lq=8, lk=8, heads=1, head_dim=12)
 
 
+@pytest.mark.variants
 def test_gemm_4wave_two_workgroups_per_cu_variant(dev):
     """the 4-wave form of the big GEMM kernel (128 x 320 x 32 tiles, two workgroups per CU; gemm_big.hip `NW`) measured
     slower on every shape of the step and is off by default; with I2V_GEMM_4W=1 (read once per process) every eligible
@@ -1115,6 +1127,7 @@ def test_gemm_4wave_two_workgroups_per_cu_variant(dev):
     assert " passed" in r.stdout
 
 
+@pytest.mark.variants
 def test_gemm_alternating_groups_opt_in_child_process(dev):
     """I2V_GEMM_ALT=2 (read once per process) sends the short-K GEMM flavours to the alternating-groups kernel (csrc/variants/gemm_alt.hip:
     one wave group in the K loop of a 128-row tile while the other runs the previous tile's epilogue; measured slower, kept

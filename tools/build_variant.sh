@@ -31,4 +31,12 @@ for f in "$@"; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o .ab_libs/$name.so "${objs[@]}" .ab_libs/obj_$name/*.o
+# the source stamp of the tree this library was built from (tests/test_kernels_gpu.py `_variants_env` checks it)
+python - "$name" <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import __graft_entry__ as ge
+headers = [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")] + [os.path.join(ge.ROOT, "include", "i2v_hip.h")]
+open(os.path.join(".ab_libs", sys.argv[1] + ".so.stamp"), "w").write(ge._stamp(headers) + "\n")
+PY
 echo ".ab_libs/$name.so"
