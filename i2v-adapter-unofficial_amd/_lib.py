@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # I2V_LIB_PATH selects another build of the same ABI (same-box A/B of two kernels, tools/ab_bench.sh); the in-tree
 # library is never overwritten by tooling
 LIB_PATH = os.environ.get("I2V_LIB_PATH") or os.path.join(_HERE, "libi2v_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
 I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
@@ -127,6 +127,9 @@ class FfFusedParams(C.Structure):
         ("rows", C.c_int64),
         ("channels", C.c_int32), ("inner", C.c_int32),
         ("eps", C.c_float),
+        ("w3", C.c_void_p), ("b3", C.c_void_p),
+        ("res2", C.c_void_p), ("ld_res2", C.c_int64),
+        ("perm_frames", C.c_int32), ("perm_hw", C.c_int32),
     ]
 
 
@@ -174,6 +177,7 @@ SIGNATURES = {
     "i2v_cross_attn_fused_ctx_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_cross_attn_fused_f16": (C.c_int, [C.POINTER(CrossAttnFusedParams), _P]),
     "i2v_ff_fused_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32]),
+    "i2v_ff_fused_tail_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "i2v_ff_fused_f16": (C.c_int, [C.POINTER(FfFusedParams), _P]),
     "i2v_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_groupnorm_f16": (C.c_int, [C.POINTER(GnParams), _P]),

@@ -502,6 +502,14 @@ class GELU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out, bias=bias)
 
 
+def ff_tail_operands(weight, bias, c_in, c_out):
+    """`pack_ff_tail` of a block's closing Linear where the fused feed-forward can take it as its tail (a square Linear of the
+    fused width), else None."""
+    if c_in != c_out or not K.ff_fused_tail_supported(128, c_in, 4 * c_in):
+        return None
+    return K.pack_ff_tail(weight.detach().reshape(c_out, c_in), bias)
+
+
 class FeedForward(HipModule):
     """A7: Linear(C -> 8C) with the GEGLU gate fused into the GEMM epilogue, then Linear(4C -> C) with the
     residual add fused."""
@@ -544,9 +552,17 @@ class FeedForward(HipModule):
         p = self.packed()
         return FUSED_FF and "fused" in p and K.ff_fused_supported(x2d.shape[0], x2d.shape[1], p["b1"].numel() // 2)
 
-    def _fwd_fused(self, x2d, gamma32, beta32, eps):
-        """x + FF(LayerNorm(x)) in one launch: the inner activation never leaves the CU."""
-        return K.ff_fused(x2d, gamma32, beta32, self.packed()["fused"], eps=eps)
+    def _fwd_fused(self, x2d, gamma32, beta32, eps, tail=None):
+        """x + FF(LayerNorm(x)) in one launch: the inner activation never leaves the CU.  `tail` (see `tail_supported`): the
+        Linear that follows the block -- the spatial transformer's / the motion module's proj_out with its residual -- in the
+        same launch."""
+        return K.ff_fused(x2d, gamma32, beta32, self.packed()["fused"], eps=eps, tail=tail)
+
+    def tail_supported(self, x2d, tail):
+        """tail = (pack_ff_tail(w, b), residual rows in output order, perm_frames, perm_hw): can the fused launch take it?"""
+        p = self.packed()
+        return (FUSED_FF and FUSED_FF_TAIL and tail is not None and tail[0] is not None and "fused" in p and
+                K.ff_fused_tail_supported(x2d.shape[0], x2d.shape[1], p["b1"].numel() // 2, tail[2], tail[3]))
 
     def fold_norm(self, norm):
         """(W', wsum, b') of `norm` (LayerNorm) followed by the first projection, or None when the activation has no
@@ -599,6 +615,7 @@ class SinusoidalPositionalEmbedding(nn.Module):
 
 FUSED_MOTION_ATTN = os.environ.get("I2V_MOTION_FUSED", "1") != "0"
 FUSED_FF = os.environ.get("I2V_FF_FUSED", "1") != "0"
+FUSED_FF_TAIL = os.environ.get("I2V_FF_TAIL", "1") != "0"       # proj_out (+ residual, row order) inside the fused feed-forward
 
 
 class TemporalTransformerBlock(HipModule):
@@ -670,9 +687,10 @@ class TemporalTransformerBlock(HipModule):
         key = (t.shape[0], frames)
         return self._plan.get(("attn",) + key, probe_attn), self._plan.get(("ff",) + key, probe_ff)
 
-    def _fwd(self, t, n_pixels, frames, **final_store):
-        """t [n_pixels * frames, C] in (b, pixel, frame) order.  `final_store` (ROWPERM + residual) is applied by
-        the caller's proj_out, not here."""
+    def _fwd(self, t, n_pixels, frames, tail=None):
+        """t [n_pixels * frames, C] in (b, pixel, frame) order.  With `tail` (FeedForward.tail_supported) returns
+        (result, applied): applied = the module's proj_out (+ residual, rows back in (b, frame, pixel) order) ran inside the
+        fused feed-forward launch and `result` is the module's output; otherwise the caller's proj_out GEMM does it."""
         if frames > self.max_len:
             raise ValueError(f"num_frames {frames} exceeds the positional table ({self.max_len})")
         p = self.packed()
@@ -705,12 +723,16 @@ class TemporalTransformerBlock(HipModule):
             o = K.temporal_attention(qk[:, :c], qk[:, c:], vt, n_pixels=n_pixels, frames=frames, heads=self.heads,
                                      head_dim=self.dim_head, scale=self.dim_head ** -0.5)
             t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)
+        def ret(v, applied=False):
+            return v if tail is None else (v, applied)
         if self.ff.fused_supported(t):
-            return self.ff._fwd_fused(t, p["g3_f32"], p["b3_f32"], self.eps)
+            if self.ff.tail_supported(t, tail):
+                return ret(self.ff._fwd_fused(t, p["g3_f32"], p["b3_f32"], self.eps, tail=tail), True)
+            return ret(self.ff._fwd_fused(t, p["g3_f32"], p["b3_f32"], self.eps))
         if fold_ff:
-            return self.ff._fwd_folded(t, self.eps, p["f_ff"])
+            return ret(self.ff._fwd_folded(t, self.eps, p["f_ff"]))
         n = K.layernorm(t, p["g3"], p["b3"], self.eps)
-        return self.ff._fwd(n, t)
+        return ret(self.ff._fwd(n, t))
 
 
 class TransformerTemporalModel(HipModule):
@@ -742,8 +764,11 @@ class TransformerTemporalModel(HipModule):
         self.proj_out = nn.Linear(inner_dim, in_channels)
 
     def _pack(self):
-        return dict(g=w16(self.norm.weight), b=w16(self.norm.bias), wi=w16(self.proj_in.weight),
-                    bi=w16(self.proj_in.bias), wo=w16(self.proj_out.weight), bo=w16(self.proj_out.bias))
+        p = dict(g=w16(self.norm.weight), b=w16(self.norm.bias), wi=w16(self.proj_in.weight),
+                 bi=w16(self.proj_in.bias), wo=w16(self.proj_out.weight), bo=w16(self.proj_out.bias))
+        # proj_out as the tail of the last block's fused feed-forward (the SD-1.5 64^2 width: a square 320 x 320 Linear)
+        p["tail"] = ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels)
+        return p
 
     def _fwd(self, x, num_frames):
         p = self.packed()
@@ -752,8 +777,14 @@ class TransformerTemporalModel(HipModule):
             raise ValueError(f"batch {n} is not a multiple of num_frames {num_frames}")
         n_pixels = (n // num_frames) * hh * ww
         t = gn_proj_in(x, p["g"], p["b"], self.groups, 1e-6, p["wi"], p["bi"], frames=num_frames)   # rows now (b, pixel, frame)
-        for blk in self.transformer_blocks:
-            t = blk._fwd(t, n_pixels, num_frames)
+        applied = False
+        for j, blk in enumerate(self.transformer_blocks):
+            if j + 1 == len(self.transformer_blocks):
+                t, applied = blk._fwd(t, n_pixels, num_frames, tail=(p["tail"], x.view(-1, c), num_frames, hh * ww))
+            else:
+                t = blk._fwd(t, n_pixels, num_frames)
+        if applied:                                                         # proj_out + residual ran inside the feed-forward
+            return t.view(n, hh, ww, c)
         out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c), store=I2V_STORE_ROWPERM, frames=num_frames,
                      hw=hh * ww)                                            # rows back in (b, frame, pixel)
         return out.view(n, hh, ww, c)

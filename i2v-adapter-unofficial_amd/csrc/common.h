@@ -32,6 +32,9 @@ void i2v_set_error(const char* fmt, ...);
   } while (0)
 
 int i2v_check_launch(const char* what);
+// CUs of the current device after opting `func` in to `lds_bytes` of dynamic LDS there (cached per kernel and device), 0 when the
+// device refuses (runtime.hip)
+int i2v_big_lds_kernel_cus(const void* func, size_t lds_bytes);
 
 static inline int64_t i2v_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -128,6 +131,17 @@ __device__ __forceinline__ float sum_lanes8(float x) {
   x += dpp(x, std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
   x += dpp(x, std::integral_constant<int, 0x141>{});      // row_half_mirror: lane i <-> 7 - i of each 8
   return x;
+}
+
+// Workgroup barrier for LDS traffic only: this wave's LDS reads / writes are complete (lgkmcnt), every wave has arrived.  Unlike
+// __syncthreads() -- whose release fence makes the compiler wait vmcnt(0) first -- global loads, stores and LDS-DMA already issued
+// STAY IN FLIGHT across it (r5: the fused feed-forward's end-of-tile __syncthreads() waited for the epilogue's stores and for the
+// next tile's prefetch: 20k cycles of a 150k-cycle tile).  Data that arrives in LDS by DMA is published by an explicit
+// `s_waitcnt vmcnt` in front of the barrier, where a barrier has to publish it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 // XCD-aware block remap (guide T1, bijective form): blocks b and b+8 share an XCD/L2, so give each XCD a

@@ -42,8 +42,16 @@ __device__ __forceinline__ f32x4 mfma16x16x16(f16x4 a, f16x4 b, f32x4 c) {
 
 // buffer_load_dwordx4 ... offen lds: 16 bytes per lane, global -> LDS at (wave-uniform LDS base) + 16 * lane (a plain function
 // on purpose, as in gemm_big.hip: called directly from the kernel template, the builtin makes hipcc drop the launch stub)
-__device__ __forceinline__ void ma_dma16(__amdgpu_buffer_rsrc_t rsrc, f16* lds_wave_base, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+__device__ __forceinline__ void ma_dma16(__amdgpu_buffer_rsrc_t rsrc, f16* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+// a copy of a lane-dependent value that the compiler cannot see through: address arithmetic derived from it is redone where it is
+// used instead of being hoisted out of the tile loop.  (r5: hoisted, the ten DMA offsets of `fetch_rows` and the output rows' store
+// addresses were SPILLED, and each reload was followed by `s_waitcnt vmcnt(0)` -- scratch loads count on vmcnt -- so every DMA
+// instruction waited for the one before it to land and every store for the weight fragments in flight.)
+__device__ __forceinline__ int ma_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
 constexpr int MA_PIX = 8;              // pixels per tile (x 16 frames = 128 rows)
@@ -96,11 +104,13 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
   auto fetch_rows = [&](const int tile, f16* panel) {
     const f16* base = X + ((int64_t)tile * (MA_PIX * MA_F) + 16 * wave) * p.ldx;        // (wave-uniform)
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)((15 * p.ldx + C) * 2), 0x00020000);
+    const int ln = ma_opaque(lane);
+    const unsigned voff = (unsigned)(((ln >> 3) * p.ldx + (ln & 7) * 8) * 2);      // the instruction's part is a scalar offset
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        ma_dma16(rs, panel + 16 * wave * C + (half * NJ + j) * 512, (unsigned)(((8 * half + (lane >> 3)) * p.ldx + (sub + 8 * j) * 8) * 2));
+        ma_dma16(rs, panel + 16 * wave * C + (half * NJ + j) * 512, voff, (unsigned)((8 * half * p.ldx + 8 * j * 8) * 2));
   };
   auto normalise_rows = [&](f16* panel) {
     f16x8 xv[2][NJ];
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
   // pairs the lane groups g, g ^ 1 so that even groups end with 8 consecutive channels of tile 0 and odd groups with 8 of tile 1
   // -- one 16-byte store per lane for two tiles (as 8-byte stores the output cost 6.5k of a tile's 50k cycles: issue-bound).
   static_assert(DT == 3 && D == 40, "store pattern of three 16-channel tiles holding 40 channels");
-  auto store_tiles = [&](f16* orow, const u32x2 (&oh)[DT]) {
+  auto store_tiles = [&](f16* orow, const int g, const u32x2 (&oh)[DT]) {      // (g: from an opaque copy of the lane index)
     u32x2 a = oh[0], b = oh[1], c2 = oh[2], d2 = oh[2];
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
                  "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   normalise_rows(panels);
   MA_STAMP(1);
-  __syncthreads();
+  lds_barrier();
   for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
     const f16* panel = panels + (it & 1) * (MA_PIX * MA_F * C);
     const int next = tile + (int)gridDim.x;
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
       MA_STAMP(4);
       MA_STAMP(5);
       f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
+      const int sln = ma_opaque(lane), sg = sln >> 4, sl15 = sln & 15;
 #pragma unroll
       for (int pix = 0; pix < MA_PIX; ++pix) {
         float sv[MA_KT][4];
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
         u32x2 oh[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) oh[t] = __builtin_bit_cast(u32x2, to_half(ov[t]));
-        store_tiles(O + (int64_t)(16 * pix + l15) * p.ldo, oh);
+        store_tiles(O + (int64_t)(16 * pix + sl15) * p.ldo, sg, oh);
       }
       MA_STAMP(6);
       if (next < ntiles) normalise_rows(other);
@@ -396,13 +407,14 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
     project(panel, 2, std::false_type{});
     MA_STAMP(5);
     f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
+    const int sln = ma_opaque(lane), sg = sln >> 4, sl15 = sln & 15;
 #pragma unroll
     for (int pix = 0; pix < MA_PIX; ++pix) {
       u32x2 oh[DT];
 #pragma unroll
       for (int t = 0; t < DT; ++t)
         oh[t] = __builtin_bit_cast(u32x2, to_half(mfma16x16x16(to_half(acc[pix][t]), ph[pix], f32x4{0.f, 0.f, 0.f, 0.f})));
-      store_tiles(O + (int64_t)(16 * pix + l15) * p.ldo, oh);
+      store_tiles(O + (int64_t)(16 * pix + sl15) * p.ldo, sg, oh);
     }
     MA_STAMP(6);
     if (next < ntiles) normalise_rows(other);
@@ -415,22 +427,21 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
       for (int k = 0; k < 8; ++k) st[k] = stamp[k];
     }
 #endif
-    __syncthreads();
+    lds_barrier();       // (LDS only: the output stores stay in flight across it)
   }
 #undef MA_STAMP
 }
 
 template <int C, int D, int H, bool CROSS>
+int ma_cus() {       // CUs of the current device once it has granted this kernel its two panels of LDS; 0: refused (runtime.hip)
+  return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H, CROSS>), 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16));
+}
+
+template <int C, int D, int H, bool CROSS>
 int launch_ma(const ma_args& p, int64_t rows, float scale, hipStream_t s, const char* what) {
   const size_t lds = 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16);
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H, CROSS>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-  if (!attr_ok) I2V_FAIL(I2V_ERR_UNSUPPORTED, "%s: %zu bytes of LDS refused", what, lds);
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int cus = ma_cus<C, D, H, CROSS>();
+  if (cus <= 0) I2V_FAIL(I2V_ERR_UNSUPPORTED, "%s: %zu bytes of LDS refused by this device", what, lds);
   const int ntiles = (int)(rows / (MA_PIX * MA_F));
   // one workgroup per CU (160 KB of LDS each), every workgroup the same number of tiles where the count allows it
   const int per = (ntiles + cus - 1) / cus;
@@ -450,7 +461,7 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 extern "C" int32_t i2v_motion_attn_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t frames) {
   return rows > 0 && rows % (MA_PIX * MA_F) == 0 && rows / (MA_PIX * MA_F) < (1 << 24) && channels == 320 && heads == 8 &&
-         head_dim == 40 && frames == MA_F;
+         head_dim == 40 && frames == MA_F && ma_cus<320, 40, 8, false>() > 0;
 }
 
 extern "C" int32_t i2v_motion_attn_pack_rows(int32_t heads, int32_t head_dim) { return heads * 3 * ((head_dim + 15) / 16) * 16; }
@@ -476,7 +487,7 @@ extern "C" int32_t i2v_cross_attn_fused_supported(int64_t rows, int32_t channels
                                                   int64_t rows_per_ctx) {
   return rows > 0 && rows % (MA_PIX * MA_F) == 0 && rows / (MA_PIX * MA_F) < (1 << 24) && channels == 320 && heads == 8 &&
          head_dim == 40 && ctx_len >= 1 && ctx_len <= 16 * MA_KT && rows_per_ctx > 0 && rows_per_ctx % (MA_PIX * MA_F) == 0 &&
-         rows % rows_per_ctx == 0;
+         rows % rows_per_ctx == 0 && ma_cus<320, 40, 8, true>() > 0;
 }
 
 extern "C" int32_t i2v_cross_attn_fused_pack_rows(int32_t heads, int32_t head_dim) { return heads * ((head_dim + 15) / 16) * 16; }

@@ -18,7 +18,7 @@ from torch import nn
 
 from . import kernels as K
 from . import streams
-from .blocks import (gn_proj_in, Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
+from .blocks import (gn_proj_in, ff_tail_operands, Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
                      to_tokens, w16)
 from ._lib import HipLibraryError
 from .checkpoint import PretrainedMixin
@@ -162,8 +162,10 @@ class I2VAdapterTransformerBlock(HipModule):
         return (self._plan.get((1, M, L, rows_qkq), probe1),
                 self.attn2 is not None and self._plan.get((2, M), probe2), self._plan.get((3, M), probe3))
 
-    def _fwd(self, x, n_img, L, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip, cfg_expand=False):
+    def _fwd(self, x, n_img, L, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip, cfg_expand=False, tail=None):
         """x [n_img * L, C] tokens; ctx_text [Bc, Lt, Dc] (+ ctx_ip [Bc, Li, Dc]) with n_img % Bc == 0.
+        tail (FeedForward.tail_supported: the model's proj_out + residual): returns (result, applied) -- applied = it ran inside
+        the fused feed-forward launch.
         cfg_expand: x holds ONE of the two identical CFG halves of the batch; the self- / cross-frame attention stage
         (i2v:444-501, no dependence on the prompt) runs on it once, and the result is duplicated in front of the text
         cross-attention, where the halves start to differ (returns 2 * n_img images)."""
@@ -248,12 +250,16 @@ class I2VAdapterTransformerBlock(HipModule):
                     q = K.gemm(n, p["w_q2"])
                 o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, kv_group, kv=kv)
             x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
+        def ret(v, applied=False):
+            return v if tail is None else (v, applied)
         if self.ff.fused_supported(x):
-            return self.ff._fwd_fused(x, p["g3_f32"], p["b3_f32"], self.eps)                 # i2v:539,554,561 in one launch
+            if self.ff.tail_supported(x, tail):                                              # ... and i2v:298-314 with them
+                return ret(self.ff._fwd_fused(x, p["g3_f32"], p["b3_f32"], self.eps, tail=tail), True)
+            return ret(self.ff._fwd_fused(x, p["g3_f32"], p["b3_f32"], self.eps))            # i2v:539,554,561 in one launch
         if fold3:
-            return self.ff._fwd_folded(x, self.eps, p["f_ff"])                               # i2v:539,554,561
+            return ret(self.ff._fwd_folded(x, self.eps, p["f_ff"]))                          # i2v:539,554,561
         n = K.layernorm(x, p["g3"], p["b3"], self.eps)                                       # i2v:539
-        return self.ff._fwd(n, x)                                                            # i2v:554,561
+        return ret(self.ff._fwd(n, x))                                                       # i2v:554,561
 
     def _split_ctx(self, encoder_hidden_states):
         if encoder_hidden_states is None:
@@ -339,7 +345,9 @@ class I2VAdapterTransformer2DModel(HipModule):
     def _pack(self):
         return dict(g=w16(self.norm.weight), b=w16(self.norm.bias),
                     wi=w16(self.proj_in.weight.reshape(self.inner_dim, self.in_channels)), bi=w16(self.proj_in.bias),
-                    wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias))
+                    wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias),
+                    # proj_out as the tail of the last block's fused feed-forward (the SD-1.5 64^2 width)
+                    tail=ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels))
 
     def packed(self):
         # only this module's own leaf parameters feed its pack (the transformer blocks pack themselves): a training step
@@ -362,11 +370,19 @@ class I2VAdapterTransformer2DModel(HipModule):
         p = self.packed()
         n_img, hh, ww, c = x.shape
         t = gn_proj_in(x, p["g"], p["b"], self.groups, 1e-6, p["wi"], p["bi"])             # i2v:218-226
+        applied = False
         for j, blk in enumerate(self.transformer_blocks):                                    # i2v:285-295
-            t = blk._fwd(t, n_img, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip,
-                         cfg_expand=cfg_expand and j == 0)
-            if cfg_expand and j == 0:
+            expand = cfg_expand and j == 0
+            n_in = n_img
+            if expand:
                 n_img, x = 2 * n_img, K.duplicate_batch(x)                                   # the residual of proj_out
+            if j + 1 == len(self.transformer_blocks):
+                t, applied = blk._fwd(t, n_in, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip,
+                                      cfg_expand=expand, tail=(p["tail"], x.view(-1, c), 0, 0))
+            else:
+                t = blk._fwd(t, n_in, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip, cfg_expand=expand)
+        if applied:                                                                          # i2v:298-314 ran inside the feed-forward
+            return t.view(n_img, hh, ww, c)
         out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c))                            # i2v:298-314
         return out.view(n_img, hh, ww, c)
 

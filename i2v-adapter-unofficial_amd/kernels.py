@@ -463,8 +463,21 @@ def pack_ff_fused(w1, b1, w2, b2):
     return w1f, b1f, w2f, b2.detach().float().contiguous()
 
 
-def ff_fused(x, gamma32, beta32, packed, *, eps, out=None):
-    """out = x + GEGLU-FF(LayerNorm(x)) in one launch (i2v_ff_fused_f16); packed = `pack_ff_fused(...)`."""
+def ff_fused_tail_supported(rows, channels, inner, perm_frames=0, perm_hw=0):
+    """... and with the Linear that follows the block in the same launch (`tail=` of ff_fused)?"""
+    return bool(_lib.load().i2v_ff_fused_tail_supported(rows, channels, inner, perm_frames, perm_hw))
+
+
+def pack_ff_tail(w3, b3):
+    """(w3 fragments, b3 fp32) of the tail of i2v_ff_fused_f16: the [C, C] Linear per 40-row slice in fragment order."""
+    return pack_cross_q(w3, 8), b3.detach().float().contiguous()
+
+
+def ff_fused(x, gamma32, beta32, packed, *, eps, out=None, tail=None):
+    """out = x + GEGLU-FF(LayerNorm(x)) in one launch (i2v_ff_fused_f16); packed = `pack_ff_fused(...)`.
+    tail = (packed_tail, res2, perm_frames, perm_hw): the block's proj_out in the same launch --
+    out[perm(r)] = res2[perm(r)] + (x + FF(LN(x)))[r] W3^T + b3, packed_tail = `pack_ff_tail(w3, b3)`; perm_frames > 0: rows are
+    in (batch, pixel, frame) order and leave in (batch, frame, pixel) order (res2 is read in that order too)."""
     lib = _lib.load()
     x, ldx = _mat(x, "x")
     rows, c = x.shape
@@ -487,6 +500,19 @@ def ff_fused(x, gamma32, beta32, packed, *, eps, out=None):
     p.w1, p.b1, p.w2, p.b2 = _p(w1f), _p(b1f), _p(w2f), _p(b2f)
     p.out, p.ldo = _p(out), ldo
     p.rows, p.channels, p.inner, p.eps = rows, c, inner, float(eps)
+    if tail is not None:
+        (w3f, b3f), res2, perm_frames, perm_hw = tail
+        _req(w3f, "w3")
+        _req(b3f, "b3", dtype=torch.float32)
+        res2, ld2 = _mat(res2, "res2")
+        if tuple(w3f.shape) != (8 * ((c // 8 + 15) // 16 * 16), c) or not w3f.is_contiguous() or b3f.numel() != c or \
+                tuple(res2.shape) != (rows, c):
+            raise ValueError(f"ff_fused: tail operands w3 {tuple(w3f.shape)}, b3 {tuple(b3f.shape)}, res2 {tuple(res2.shape)} "
+                             f"do not match rows {rows}, C {c} (pack_ff_tail)")
+        if perm_frames and out.data_ptr() == x.data_ptr():
+            raise ValueError("ff_fused: out must not alias x when the tail permutes the rows")
+        p.w3, p.b3, p.res2, p.ld_res2 = _p(w3f), _p(b3f), _p(res2), ld2
+        p.perm_frames, p.perm_hw = int(perm_frames), int(perm_hw)
     _lib.check(lib.i2v_ff_fused_f16(C.byref(p), _stream()), "i2v_ff_fused_f16")
     return out
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 7
+#define I2V_ABI_VERSION 8
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -278,7 +278,16 @@ int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* p, i2v_stream_t 
  *   b1 fp32 [inner / 128][8][2][16]: the same rows' biases;
  *   w2 [8][inner / 128][4][3][64][8]: element [w][ch][ks][t][l][j] = W2[n = 40 w + 16 t + (l & 15)][128 ch + 32 ks + 8 (l >> 4) + j],
  *      zero where 16 t + (l & 15) >= 40.
- * Implemented for the SD-1.5 64^2 level (i2v_ff_fused_supported: channels 320, inner 1280, rows a multiple of 128).
+ * Implemented for the SD-1.5 64^2 level (i2v_ff_fused_supported: channels 320, inner 1280, rows a multiple of 128; 0 also when
+ * the current device refuses the kernel's 160 KB of LDS -- callers then take the un-fused GEMM pair).
+ *
+ * Optional tail (ABI 8; w3 != NULL): the Linear that follows the block in the same launch --
+ *     out[perm(r)] = res2[perm(r)] + y[r] W3^T + b3,   y = x + FF(LayerNorm(x)) rounded to fp16 as the un-fused kernel stores it
+ * i.e. the spatial transformer's proj_out with its residual (i2v:298-314; perm = identity) or the motion module's proj_out
+ * (perm_frames = F > 0, a power of two: rows arrive in (batch, pixel, frame) order, and out / res2 are addressed in
+ * (batch, frame, pixel) order with perm_hw pixels per image -- I2V_STORE_ROWPERM of i2v_gemm_f16).  w3: W3 [channels, channels]
+ * per 40-row slice in fragment order, the layout of i2v_cross_attn_fused_params.w_q ([8][channels / 32][3][64][8]); b3 fp32
+ * [channels]; res2 fp16 rows of ld_res2 elements.  With the tail, out must not alias x when perm_frames > 0.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct i2v_ff_fused_params {
   const void* x; int64_t ldx;            /* fp16 [rows, channels] */
@@ -289,9 +298,15 @@ typedef struct i2v_ff_fused_params {
   int64_t rows;
   int32_t channels, inner;
   float eps;
+  /* tail (all zero: none) */
+  const void* w3; const void* b3;
+  const void* res2; int64_t ld_res2;
+  int32_t perm_frames, perm_hw;
 } i2v_ff_fused_params;
 
 int32_t i2v_ff_fused_supported(int64_t rows, int32_t channels, int32_t inner);
+/* ... with the tail: rows in (batch, pixel, frame) order of `perm_frames` frames and `perm_hw` pixels per image (0, 0: no permutation) */
+int32_t i2v_ff_fused_tail_supported(int64_t rows, int32_t channels, int32_t inner, int32_t perm_frames, int32_t perm_hw);
 int i2v_ff_fused_f16(const i2v_ff_fused_params* p, i2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

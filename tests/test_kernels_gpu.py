@@ -642,6 +642,58 @@ def test_feed_forward_fused(dev, rows, strided):
         k.ff_fused(xd[:rows - 16], D(gamma).float(), D(beta).float(), packed, eps=eps)
 
 
+@pytest.mark.parametrize("batch,frames,hw,strided", [(1, 0, 0, False), (3, 0, 0, True), (1, 16, 8, False), (2, 16, 200, True),
+                                                     (1, 8, 48, False), (2, 32, 36, False)])
+def test_feed_forward_fused_with_proj_out_tail(dev, batch, frames, hw, strided):
+    """the tail of i2v_ff_fused_f16 (ABI 8): the Linear that follows the block in the same launch --
+    out[perm(r)] = res2[perm(r)] + fp16(x + FF(LayerNorm(x)))[r] W3^T + b3 -- without a permutation (the spatial transformer's
+    proj_out, i2v:298-314) and with rows arriving in (batch, pixel, frame) order and leaving in (batch, frame, pixel) order (the
+    motion module's): against fp32 torch on the same fp16-rounded operands, and bit-for-bit against the two launches it replaces
+    (fused feed-forward, then i2v_gemm_f16 with the residual / I2V_STORE_ROWPERM)... up to the GEMM kernels' own summation order."""
+    k = K()
+    c, inner, eps = 320, 1280, 1e-5
+    rows = batch * frames * hw if frames else 128 * 5 * batch
+    assert rows % 128 == 0
+    assert k.ff_fused_tail_supported(rows, c, inner, frames, hw)
+    assert not k.ff_fused_tail_supported(rows, c, inner, 12, 32) and not k.ff_fused_tail_supported(rows + 16, c, inner, 0, 0)
+    g = torch.Generator().manual_seed(rows + frames)
+    ld = c + 32 if strided else c
+    xb = h(torch.randn(rows, ld, generator=g) * 1.2 + 0.2)
+    x = xb[:, :c]
+    res2 = h(torch.randn(rows, c, generator=g))                      # rows in OUTPUT order
+    gamma, beta = h(1 + 0.2 * torch.randn(c, generator=g)), h(0.1 * torch.randn(c, generator=g))
+    w1, b1 = h(torch.randn(2 * inner, c, generator=g) * c ** -0.5), h(0.1 * torch.randn(2 * inner, generator=g))
+    w2, b2 = h(torch.randn(c, inner, generator=g) * inner ** -0.5), h(0.1 * torch.randn(c, generator=g))
+    w3, b3 = h(torch.randn(c, c, generator=g) * c ** -0.5), h(0.1 * torch.randn(c, generator=g))
+    n = h(F.layer_norm(x, (c,), gamma, beta, eps))
+    pre = n @ w1.T + b1
+    y = h(x + h(pre[:, :inner] * F.gelu(pre[:, inner:])) @ w2.T + b2)
+    z = y @ w3.T + b3
+    if frames:                                                       # (b, pixel, frame) -> (b, frame, pixel)
+        z = z.view(batch, hw, frames, c).permute(0, 2, 1, 3).reshape(rows, c)
+    ref = res2 + z
+    D = lambda t: t.half().to(dev)
+    packed = k.pack_ff_fused(D(w1), D(b1), D(w2), D(b2))
+    tail = (k.pack_ff_tail(D(w3), D(b3)), D(res2), frames, hw)
+    xd = D(xb)[:, :c]
+    out = k.ff_fused(xd, D(gamma).float(), D(beta).float(), packed, eps=eps, tail=tail)
+    close(out, ref, rel=3e-3, name="fused feed-forward + proj_out vs fp32 torch")
+    yd = k.ff_fused(xd, D(gamma).float(), D(beta).float(), packed, eps=eps)
+    close(yd, y, rel=3e-3, name="fused feed-forward (no tail) vs fp32 torch")
+    store = dict(store=k.I2V_STORE_ROWPERM, frames=frames, hw=hw) if frames else {}
+    old = k.gemm(yd, D(w3), D(b3), residual=D(res2), **store)
+    close(out, old, rel=1e-3, name="fused feed-forward + proj_out vs the two launches")
+    assert torch.equal(out, k.ff_fused(xd, D(gamma).float(), D(beta).float(), packed, eps=eps, tail=tail))
+    if not frames:         # without a permutation out may alias x and res2
+        buf = xd.contiguous().clone()
+        k.ff_fused(buf, D(gamma).float(), D(beta).float(), packed, eps=eps, tail=tail, out=buf)
+        assert torch.equal(buf, out)
+    else:
+        with pytest.raises(Exception, match="alias"):
+            buf = xd.contiguous().clone()
+            k.ff_fused(buf, D(gamma).float(), D(beta).float(), packed, eps=eps, tail=tail, out=buf)
+
+
 @pytest.mark.parametrize("rows,n_ctx,lt,amp", [(256, 2, 77, 1.0), (128 * 37, 1, 77, 1.0), (1024, 2, 80, 3.0), (512, 4, 5, 1.0)])
 def test_text_cross_attention_sub_block_fused(dev, rows, n_ctx, lt, amp):
     """i2v_cross_attn_fused_f16: LayerNorm, to_q and the attention against a <= 80-token context whose K / V^T are given, in one
