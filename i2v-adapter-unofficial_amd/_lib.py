@@ -133,6 +133,19 @@ class FfFusedParams(C.Structure):
     ]
 
 
+class LnQkvParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("w", C.c_void_p),
+        ("qk", C.c_void_p), ("ld_qk", C.c_int64),
+        ("vt", C.c_void_p), ("vt_batch_stride", C.c_int64), ("vt_row_stride", C.c_int64),
+        ("rows", C.c_int64), ("rows_per_image", C.c_int64),
+        ("channels", C.c_int32), ("n_qk", C.c_int32),
+        ("eps", C.c_float),
+    ]
+
+
 class GnParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("c1", C.c_int32),
@@ -176,6 +189,8 @@ SIGNATURES = {
     "i2v_cross_attn_fused_pack_rows": (C.c_int32, [C.c_int32, C.c_int32]),
     "i2v_cross_attn_fused_ctx_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "i2v_cross_attn_fused_f16": (C.c_int, [C.POINTER(CrossAttnFusedParams), _P]),
+    "i2v_ln_qkv_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int64]),
+    "i2v_ln_qkv_f16": (C.c_int, [C.POINTER(LnQkvParams), _P]),
     "i2v_ff_fused_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32]),
     "i2v_ff_fused_tail_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "i2v_ff_fused_f16": (C.c_int, [C.POINTER(FfFusedParams), _P]),

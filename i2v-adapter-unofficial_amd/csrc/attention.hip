@@ -292,9 +292,32 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2, const int qbw_
           }
           sv[kt][r] = v;
         }
-      float mx = max3(sv[0][0], sv[0][1], fmaxf(sv[0][2], sv[0][3]));
+      // the lane's own 4 NKT keys as a TREE of three-input maxima: (4 NKT - 1) / 2 instructions (8 for 16 keys) and a dependency
+      // chain of 3 -- as a running maximum per key tile the compiler emitted 6 v_max3 + 6 v_max per query tile (r5: -8 VALU
+      // instructions per 32-query x 64-key trip of a loop that is bound by its instruction count)
+      float red[4 * NKT];
 #pragma unroll
-      for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(max3(mx, sv[kt][0], sv[kt][1]), fmaxf(sv[kt][2], sv[kt][3]));
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[4 * kt + r] = sv[kt][r];
+      {
+        int n = 4 * NKT;
+#pragma unroll
+        for (int level = 0; level < 5 && n > 1; ++level) {
+          int m = 0;
+#pragma unroll
+          for (int i = 0; i + 2 < n; i += 3) red[m++] = max3(red[i], red[i + 1], red[i + 2]);
+          if (n % 3 == 2) {
+            red[m] = fmaxf(red[n - 2], red[n - 1]);
+            ++m;
+          } else if (n % 3 == 1) {
+            red[m] = red[n - 1];
+            ++m;
+          }
+          n = m;
+        }
+      }
+      float mx = red[0];
       // mx = the lane's own 16 keys.  The test needs no cross-lane traffic: if NO lane of the wave holds a score above the
       // threshold, every P of the tile is <= 2^8 against the running max as it stands.  Only when some lane does (the first
       // tile, then rarely) is the row maximum completed over the four lane groups of the query

@@ -71,6 +71,7 @@ class I2VAdapterModule(PretrainedMixin, nn.Module):
 
 
 FUSED_TEXT_ATTN = os.environ.get("I2V_TEXT_FUSED", "1") != "0"
+FUSED_LN_QKV = os.environ.get("I2V_QKV_FUSED", "1") != "0"       # LayerNorm 1 + q | k | q_adapter + V^T projection in one launch
 
 
 class I2VAdapterTransformerBlock(HipModule):
@@ -138,6 +139,12 @@ class I2VAdapterTransformerBlock(HipModule):
         p["f_v1"] = fold_layernorm(a1.to_v.weight, None, self.norm1.weight, self.norm1.bias)
         p["f_ff"] = self.ff.fold_norm(self.norm3)
         p["g3_f32"], p["b3_f32"] = self.norm3.weight.detach().float().contiguous(), self.norm3.bias.detach().float().contiguous()
+        # the one-launch LayerNorm 1 + [q | k | q_adapter] + V^T projection's operands (64^2 level of SD-1.5), with and without
+        # the adapter's query
+        if K.ln_qkv_supported(128, self.dim, 3 * self.dim, 128):
+            p["g1_f32"], p["b1_f32"] = self.norm1.weight.detach().float().contiguous(), self.norm1.bias.detach().float().contiguous()
+            p["w_lnqkv3"] = K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), a1.to_v.weight)
+            p["w_lnqkv2"] = K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight], dim=0), a1.to_v.weight)
         return p
 
     def _fold_ok(self, x, L, rows_qkq):
@@ -184,11 +191,17 @@ class I2VAdapterTransformerBlock(HipModule):
         overlap = x.shape[0] <= streams.MAX_ROWS
         # LayerNorm 1 (i2v:444-445): folded into the q|k|q_ad and V^T GEMMs (never materialised) where the library
         # implements the fold for this level, else one pass that both chains read
-        n = None if fold1 else K.layernorm(x, p["g1"], p["b1"], self.eps)
+        fused_qkv = FUSED_LN_QKV and "w_lnqkv3" in p and K.ln_qkv_supported(x.shape[0], c, rows_qkq, L)
+        n = None if (fold1 or fused_qkv) else K.layernorm(x, p["g1"], p["b1"], self.eps)
         k0 = v0t = None
+        if fused_qkv:          # LayerNorm 1, q | k | q_adapter and V^T in one launch (64^2 level of SD-1.5): x is read once
+            proj, vt1 = K.ln_qkv(x, p["g1_f32"], p["b1_f32"], p["w_lnqkv3" if enable_cross_frame_attn else "w_lnqkv2"],
+                                 n_qk=rows_qkq, rows_per_image=L, eps=self.eps)
         with streams.fork(overlap, x.device) as fk:
             with fk.side():
-                if fold1:
+                if fused_qkv:
+                    pass
+                elif fold1:
                     wv, sv, cv = p["f_v1"]
                     vt1 = K.project_vt(x, wv, L, bias=cv, ln=(sv, self.eps))
                 else:
@@ -207,7 +220,9 @@ class I2VAdapterTransformerBlock(HipModule):
                     f2d = first.reshape(-1, c)
                     k0 = K.gemm(f2d, p["w_k_ad"])
                     v0t = K.project_vt(f2d, p["w_v_ad"], L)
-            if fold1:
+            if fused_qkv:
+                pass
+            elif fold1:
                 wf, ws, cb = p["f_qkq"]
                 proj = K.gemm(x, wf[:rows_qkq], cb[:rows_qkq], ln=(ws[:rows_qkq], self.eps))
             else:

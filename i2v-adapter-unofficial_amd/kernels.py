@@ -437,6 +437,54 @@ def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_
     return out
 
 
+def ln_qkv_supported(rows, channels, n_qk, rows_per_image):
+    """is the one-launch LayerNorm + [q | k | q_adapter] + V^T projection implemented for this shape?"""
+    return bool(_lib.load().i2v_ln_qkv_supported(rows, channels, n_qk, rows_per_image))
+
+
+def pack_ln_qkv(w_qk, w_v):
+    """`w` of i2v_ln_qkv_f16: the rows of [w_qk ; w_v] per 16-row tile in fragment order [tile][C / 32][lane][8]."""
+    w = torch.cat([w_qk.detach().to(f16), w_v.detach().to(f16)], dim=0)
+    n, c = w.shape
+    if n % 160 or c % 32:
+        raise ValueError(f"pack_ln_qkv: {n} rows x {c} columns is not whole waves of 160 rows / K steps of 32")
+    return w.view(n // 16, 16, c // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(n, c)     # [tile, s, g, l15, j]
+
+
+def ln_qkv(x, gamma32, beta32, w_packed, *, n_qk, rows_per_image, eps, qk=None, vt=None):
+    """(qk [rows, n_qk], vt [rows / rows_per_image, C, pad8(rows_per_image)]) = projections of LayerNorm(x) in one launch
+    (i2v_ln_qkv_f16); w_packed = `pack_ln_qkv(w_qk, w_v)`."""
+    lib = _lib.load()
+    x, ldx = _mat(x, "x")
+    rows, c = x.shape
+    _req(w_packed, "w")
+    for name, t in (("gamma32", gamma32), ("beta32", beta32)):
+        _req(t, name, dtype=torch.float32)
+    if tuple(gamma32.shape) != (c,) or tuple(beta32.shape) != (c,) or tuple(w_packed.shape) != (n_qk + c, c) or \
+            not w_packed.is_contiguous():
+        raise ValueError(f"ln_qkv: gamma {tuple(gamma32.shape)}, beta {tuple(beta32.shape)}, w {tuple(w_packed.shape)} for C {c}, "
+                         f"n_qk {n_qk} (pack_ln_qkv)")
+    if rows % rows_per_image:
+        raise ValueError(f"ln_qkv: {rows} rows are not whole images of {rows_per_image}")
+    n_img, ld = rows // rows_per_image, pad8(rows_per_image)
+    if qk is None:
+        qk = torch.empty((rows, n_qk), dtype=f16, device=x.device)
+    if vt is None:
+        vt = torch.empty((n_img, c, ld), dtype=f16, device=x.device)
+    qk, ld_qk = _mat(qk, "qk")
+    _req(vt, "vt")
+    if tuple(qk.shape) != (rows, n_qk) or tuple(vt.shape) != (n_img, c, ld) or not vt.is_contiguous():
+        raise ValueError(f"ln_qkv: qk {tuple(qk.shape)}, vt {tuple(vt.shape)}")
+    p = _lib.LnQkvParams()
+    p.x, p.ldx = _p(x), ldx
+    p.gamma, p.beta, p.w = _p(gamma32), _p(beta32), _p(w_packed)
+    p.qk, p.ld_qk = _p(qk), ld_qk
+    p.vt, p.vt_batch_stride, p.vt_row_stride = _p(vt), c * ld, ld
+    p.rows, p.rows_per_image, p.channels, p.n_qk, p.eps = rows, rows_per_image, c, n_qk, float(eps)
+    _lib.check(lib.i2v_ln_qkv_f16(C.byref(p), _stream()), "i2v_ln_qkv_f16")
+    return qk, vt
+
+
 def ff_fused_supported(rows, channels, inner):
     """is the one-launch GEGLU feed-forward implemented for this shape?"""
     return bool(_lib.load().i2v_ff_fused_supported(rows, channels, inner))

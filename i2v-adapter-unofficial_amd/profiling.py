@@ -67,8 +67,20 @@ def _work_ff(args, kw, out):
     x = args[0]
     rows, c = x.shape
     inner = args[3][1].numel() // 2
+    tail = kw.get("tail")
+    if tail is not None:       # the block's closing Linear (proj_out + its residual) in the same launch
+        return ("ff_fused", 2.0 * rows * c * 2 * inner + 2.0 * rows * inner * c + 2.0 * rows * c * c,
+                _numel_bytes(x, args[3][0], args[3][2], tail[0][0], tail[1], out),
+                f"{rows}x{c} inner {inner} (LN + GEGLU FF + residual + proj_out + residual{', rows permuted' if tail[2] else ''})")
     return ("ff_fused", 2.0 * rows * c * 2 * inner + 2.0 * rows * inner * c, _numel_bytes(x, args[3][0], args[3][2], out),
             f"{rows}x{c} inner {inner} (LN + GEGLU FF + residual)")
+
+
+def _work_lnqkv(args, kw, out):
+    x, w = args[0], args[3]
+    rows, c = x.shape
+    return ("ln_qkv", 2.0 * rows * c * (kw["n_qk"] + c), _numel_bytes(x, w, out[0], out[1]),
+            f"{rows}x{kw['n_qk']}+{c}x{c} (LN + q,k[,q_adapter] + V^T)")
 
 
 def _work_gn(args, kw, out):
@@ -92,7 +104,7 @@ def _work_misc(name):
 
 _WRAPPED = {
     "gemm": _work_gemm, "conv3x3": _work_conv, "attention": _work_attn, "temporal_attention": _work_tattn,
-    "motion_attn": _work_mattn, "cross_attn_fused": _work_cattn, "ff_fused": _work_ff,
+    "motion_attn": _work_mattn, "cross_attn_fused": _work_cattn, "ff_fused": _work_ff, "ln_qkv": _work_lnqkv,
     "groupnorm": _work_gn, "groupnorm_fold": _work_gn_fold, "layernorm": _work_ln, "silu": _work_misc("elementwise"),
     "copy3d": _work_misc("elementwise"), "timestep_embedding": _work_misc("elementwise"),
     "ddim_prep": _work_misc("elementwise"), "ddim_cfg_step": _work_misc("elementwise"),

@@ -267,6 +267,32 @@ int64_t i2v_cross_attn_fused_ctx_elems(int32_t n_ctx, int32_t heads, int32_t hea
 int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* p, i2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (ABI 8) LayerNorm 1 and the projections in front of the spatial block's self- / cross-frame attention in one launch
+ * (i2v:444-445 `norm1`, 468-473 `attn1` to_q / to_k / to_v, 483-492 the adapter's to_q):
+ *     n = LayerNorm(x) gamma + beta;   qk[r, :] = n[r] W_qk^T  (n_qk = 2 C: [q | k], or 3 C: [q | k | q_adapter]);
+ *     vt[r / rows_per_image][c][r % rows_per_image] = (n[r] W_v^T)[c]     (the V^T operand of i2v_attention_f16)
+ * replaces native_layer_norm + three / four aten addmm (+ the transpose SDPA does internally).  LayerNorm output rounded to fp16
+ * where the un-fused kernels store it; statistics and accumulation in fp32.  gamma, beta: fp32 [channels].
+ * w: the rows of [W_qk ; W_v] ((n_qk + C) x C, diffusers Linear layout) per 16-row tile in MFMA-fragment order
+ *    [(n_qk + C) / 16][C / 32][64][8]: element [T][s][l][j] = W[16 T + (l & 15)][32 s + 8 (l >> 4) + j].
+ * Implemented for the SD-1.5 64^2 level (i2v_ln_qkv_supported: channels 320, rows and rows_per_image multiples of 128; 0 also when
+ * the current device refuses the kernel's 160 KB of LDS).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_ln_qkv_params {
+  const void* x; int64_t ldx;            /* fp16 [rows, channels] */
+  const void* gamma; const void* beta;   /* fp32 [channels] */
+  const void* w;
+  void* qk; int64_t ld_qk;               /* fp16 [rows, n_qk] */
+  void* vt; int64_t vt_batch_stride, vt_row_stride;   /* fp16 [rows / rows_per_image][channels][>= rows_per_image] */
+  int64_t rows, rows_per_image;
+  int32_t channels, n_qk;
+  float eps;
+} i2v_ln_qkv_params;
+
+int32_t i2v_ln_qkv_supported(int64_t rows, int32_t channels, int32_t n_qk, int64_t rows_per_image);
+int i2v_ln_qkv_f16(const i2v_ln_qkv_params* p, i2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * The GEGLU feed-forward of a transformer block in one launch (i2v:539-561 `norm3 -> ff -> + residual`; the temporal block's
  * FeedForward):  out = x + W2 (value o gelu(gate)) + b2  with  [value | gate] = (LayerNorm(x) gamma + beta) W1^T + b1.
  * The inner activation (rows x inner) never leaves the CU.  LayerNorm output and the inner activation are rounded to fp16 where

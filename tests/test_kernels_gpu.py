@@ -606,6 +606,43 @@ def test_motion_attention_sub_block_fused(dev, npix, amp, strided):
         k.motion_attn(xd[:rows - 16], g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps)
 
 
+@pytest.mark.parametrize("n_img,L,adapter,strided,amp", [(1, 128, True, False, 1.0), (3, 1024, True, True, 1.0), (2, 4096, False, False, 1.0),
+                                                          (5, 256, True, False, 30.0)])
+def test_layernorm_qkv_projection_fused(dev, n_img, L, adapter, strided, amp):
+    """i2v_ln_qkv_f16: LayerNorm 1, [q | k | q_adapter] (row-major) and V^T (per image [channel][key]) of the spatial block's
+    self- / cross-frame attention in one launch (C = 320: the SD-1.5 64^2 level), against fp32 torch on the same fp16-rounded
+    operands and against the kernels it replaces (LayerNorm -> i2v_gemm_f16, project_vt).  amp: rows with a large common offset
+    (mean / std = 30): the statistics are exact two-pass ones."""
+    k = K()
+    c, eps = 320, 1e-5
+    rows, n_qk = n_img * L, (3 if adapter else 2) * c
+    assert k.ln_qkv_supported(rows, c, n_qk, L) and not k.ln_qkv_supported(rows, 640, 3 * 640, L) and not k.ln_qkv_supported(rows, c, c, L)
+    assert not k.ln_qkv_supported(rows + 16, c, n_qk, L) and not k.ln_qkv_supported(rows, c, n_qk, L + 64)
+    g = torch.Generator().manual_seed(rows + n_qk)
+    ld = c + 64 if strided else c
+    xb = h(torch.randn(rows, ld, generator=g) * 1.3 + amp * 0.4)
+    x = xb[:, :c]
+    gamma, beta = h(1 + 0.2 * torch.randn(c, generator=g)), h(0.1 * torch.randn(c, generator=g))
+    w_qk, w_v = h(torch.randn(n_qk, c, generator=g) * c ** -0.5), h(torch.randn(c, c, generator=g) * c ** -0.5)
+    n = h(F.layer_norm(x, (c,), gamma, beta, eps))
+    ref_qk = n @ w_qk.T
+    ref_vt = (n @ w_v.T).view(n_img, L, c).transpose(1, 2)
+    D = lambda t: t.half().to(dev)
+    wp = k.pack_ln_qkv(D(w_qk), D(w_v))
+    xd = D(xb)[:, :c]
+    qk, vt = k.ln_qkv(xd, D(gamma).float(), D(beta).float(), wp, n_qk=n_qk, rows_per_image=L, eps=eps)
+    assert tuple(qk.shape) == (rows, n_qk) and tuple(vt.shape) == (n_img, c, L)
+    close(qk, ref_qk, rel=3e-3, name="fused LayerNorm + q | k | q_adapter vs fp32 torch")
+    close(vt, ref_vt, rel=3e-3, name="fused LayerNorm + V^T vs fp32 torch")
+    nl = k.layernorm(xd.contiguous(), D(gamma), D(beta), eps)
+    close(qk, k.gemm(nl, D(w_qk)), rel=1e-3, name="fused q | k | q_adapter vs LayerNorm -> GEMM")
+    close(vt, k.project_vt(nl, D(w_v), L), rel=1e-3, name="fused V^T vs LayerNorm -> project_vt")
+    qk2, vt2 = k.ln_qkv(xd, D(gamma).float(), D(beta).float(), wp, n_qk=n_qk, rows_per_image=L, eps=eps)
+    assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
+    with pytest.raises(Exception, match="not a fused shape"):          # images of 64 rows: not whole 128-row tiles
+        k.ln_qkv(xd, D(gamma).float(), D(beta).float(), wp, n_qk=n_qk, rows_per_image=64, eps=eps)
+
+
 @pytest.mark.parametrize("rows,strided", [(128, False), (128 * 300, True), (128 * 771, False)])
 def test_feed_forward_fused(dev, rows, strided):
     """i2v_ff_fused_f16: x + W2 GEGLU(LayerNorm(x) W1^T + b1) + b2 in one launch (C = 320, inner 1280: the SD-1.5 64^2 level)
