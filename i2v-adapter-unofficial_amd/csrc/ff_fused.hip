@@ -63,6 +63,9 @@ __global__ __launch_bounds__(64 * H) void ff_fused_kernel(const i2v_ff_fused_par
   static_assert(2 * FF_PIX * 16 * FF_CH <= FF_PIX * 16 * C, "the raw rows of a tile cover the chunk buffers (160 KB of LDS in all)");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15, sub = lane & 7, sw = l15 & 7;
+  // (chunk 4 s + g of a K step swizzled by the row: ((4 s + g) ^ sw) = 8 (s >> 1) + ((4 (s & 1) + g) ^ sw) -- TWO lane-dependent offsets
+  //  and an immediate instead of one hoisted (and spilled) register per K step)
+  const int swz[2] = {(g ^ sw) * 8, ((4 + g) ^ sw) * 8};
   const f16* __restrict__ X = reinterpret_cast<const f16*>(p.x);
 
   // ---- rows of a tile by LDS-DMA into the wave's own 10 KB of the panel, normalised in place (as motion_attn.hip)
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(64 * H) void ff_fused_kernel(const i2v_ff_fused_par
         for (int u = 0; u < FF_U; ++u) wf[s][u] = ldw1(u, s);
       constexpr int NI = KS * FF_PIX;
       auto lda = [&](const int i) {
-        return *reinterpret_cast<const f16x8*>(alane + 16 * (i % FF_PIX) * C + (((4 * (i / FF_PIX) + g) ^ sw) * 8));
+        return *reinterpret_cast<const f16x8*>(alane + 16 * (i % FF_PIX) * C + 64 * ((i / FF_PIX) >> 1) + swz[(i / FF_PIX) & 1]);
       };
       f16x8 af[FF_AD + 1];
 #pragma unroll
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64 * H) void ff_fused_kernel(const i2v_ff_fused_par
           for (int t = 0; t < DT; ++t) wf[s][t] = ldw3(s, t);
         constexpr int NI = KS * FF_PIX;
         auto lda = [&](const int i) {
-          return *reinterpret_cast<const f16x8*>(alane + 16 * (i % FF_PIX) * C + (((4 * (i / FF_PIX) + g) ^ sw) * 8));
+          return *reinterpret_cast<const f16x8*>(alane + 16 * (i % FF_PIX) * C + 64 * ((i / FF_PIX) >> 1) + swz[(i / FF_PIX) & 1]);
         };
         f16x8 af[FF_AD + 1];
 #pragma unroll

@@ -177,6 +177,9 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, H * PARTS * DP * C * 2, 0x00020000);
   const int w_lane = lane * 16, w_wave = wave * (PARTS * DP * C * 2);
   const int sw = l15 & 7;
+  // (chunk 4 s + g of a K step swizzled by the row: ((4 s + g) ^ sw) = 8 (s >> 1) + ((4 (s & 1) + g) ^ sw) -- TWO lane-dependent offsets
+  //  and an immediate instead of one hoisted register per K step)
+  const int swz[2] = {(g ^ sw) * 8, ((4 + g) ^ sw) * 8};
   f32x4 acc[MA_PIX][DT];
   auto project = [&](const f16* panel, const int part, auto transposed) {
     constexpr bool TR = decltype(transposed)::value;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
       for (int t = 0; t < DT; ++t) wf[s][t] = ldw(s, t);
     constexpr int AD = MA_AD, NI = KS * MA_PIX;
     auto lda = [&](const int i) {
-      return *reinterpret_cast<const f16x8*>(alane + 16 * (i % MA_PIX) * C + (((4 * (i / MA_PIX) + g) ^ sw) * 8));
+      return *reinterpret_cast<const f16x8*>(alane + 16 * (i % MA_PIX) * C + 64 * ((i / MA_PIX) >> 1) + swz[(i / MA_PIX) & 1]);
     };
     f16x8 af[AD + 1];
 #pragma unroll
