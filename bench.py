@@ -411,6 +411,10 @@ def main():
                          "adapter gradients + clip + AdamW; one clip per rank per step) -- not the BASELINE metric")
     ap.add_argument("--update-motion-modules", action="store_true",
                     help="with --train: the 21 motion modules train too (train_image_to_video.py:452, 669)")
+    ap.add_argument("--parity-only", action="store_true",
+                    help="no timing: ONE CFG UNet forward of this workload (--frames / --size / --ip) through the HIP model and "
+                         "through the CPU oracle on the same weights and inputs, one JSON line with the errors (builder-run: "
+                         "minutes of host time at 32 f x 768^2; profiles/r5_parity_configs.jsonl)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-rank plumbing on a box WITHOUT GPUs: launcher, rendezvous, gloo group, flat "
                          "weight broadcast, pair sharding, timed loop with a stub step, MAX all-reduce, JSON line "
@@ -456,6 +460,23 @@ def main():
     if args.latent_parity > 0:
         latent_parity(args, model, dev)
         return 0
+    if args.parity_only:
+        import threading
+        done = threading.Event()
+
+        def heartbeat():          # (the box kills a command that is silent for minutes)
+            t0 = time.time()
+            while not done.wait(45):
+                print(f"# oracle forward running: {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
+        base, parity = cpu_baseline_and_parity(model, ip_sd, args.frames, args.size // 8, dev, n_forwards=1)
+        done.set()
+        parity["tolerance"] = PARITY_ABS_TOL
+        parity["parity_ok"] = bool(parity["max_abs_err"] <= PARITY_ABS_TOL)
+        print(json.dumps({"parity_only": True, "workload": f"{args.frames}f x {args.size}x{args.size}, CFG batch (B = 2), IP "
+                          f"{'on' if ip else 'off'}, SD-1.5 width", "parity": parity, "cpu_oracle": base,
+                          "library_source_stamp": source_stamp()}), flush=True)
+        return 0 if parity["parity_ok"] else 3
 
     # ---- this rank's samples (static block partition, no per-step collective)
     F, h_lat, B = args.frames, args.size // 8, args.batch

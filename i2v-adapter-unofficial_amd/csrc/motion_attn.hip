@@ -79,11 +79,15 @@ constexpr int MA_KT = 5;               // CROSS: key tiles of 16 (<= 80 context 
 // CROSS = true: `norm2 -> attn2` of the spatial block (i2v:510-533) for a context that fits the registers -- LayerNorm, to_q, then
 //   per 16 queries S^T = K_ctx Q^T (15 MFMAs of 16x16x16 against key fragments that stay in registers for the whole tile), softmax
 //   over the <= 80 keys in the lane, O^T = V_ctx^T P^T (15 more): one pass over the panel instead of three, no q in memory.
-template <int C, int D, int H, bool CROSS>
+// F (motion form): frames per pixel -- 16: a 16-row MFMA tile IS one pixel's sequence; 8: a tile holds two pixels and the scores
+//   between them are masked; 32: a pixel is two tiles, its scores four 16 x 16 blocks (r5: the 8-frame / 256^2 and the 32-frame /
+//   768^2 configurations took the un-fused chain)
+template <int C, int D, int H, bool CROSS, int F = 16>
 __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, const float scale_log2, const int ntiles,
                                                              long long* __restrict__ stamps) {
   constexpr int DT = (D + 15) / 16, DP = 16 * DT, KS = C / 32, NJ = C / 64, PARTS = CROSS ? 1 : 3;
   static_assert(C % 64 == 0 && H == 8, "one wave per head, 8 lanes x C / 64 chunks per row in the LayerNorm pass");
+  static_assert(F == 8 || F == 16 || F == 32, "frames per pixel");
   extern __shared__ __attribute__((aligned(16))) f16 panels[];       // 2 x [128][C], chunk index ^= row & 7
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: SGPR)
   const int g = lane >> 4, l15 = lane & 15, sub = lane & 7;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int row = 16 * wave + 8 * half + (lane >> 3);
-      const float* sh = sp + (int64_t)(8 * half + (lane >> 3)) * p.ld_shift;      // (tiles start at frame 0: frame = row & 15)
+      const float* sh = sp + (int64_t)((16 * wave + 8 * half + (lane >> 3)) & (F - 1)) * p.ld_shift;   // (tiles start at frame 0)
       f32x4 sv[NJ][2];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -373,31 +377,45 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
       MA_STAMP(6);
       if (next < ntiles) normalise_rows(other);
     } else {
-    // k^T, then S^T[key][query] and the softmax over the keys
-    f16x4 ph[MA_PIX];
+    // k^T, then S^T[key][query] and the softmax over the keys.  NB = 16-row tiles per pixel (F = 32: two -- the keys of a query
+    // are the 8 accumulator rows of two score blocks and the 4 lane groups); ph[key tile][query tile of the same pixel]
+    constexpr int NB = F == 32 ? 2 : 1;
+    f16x4 ph[MA_PIX][NB];
     project(panel, 1, std::true_type{});
 #pragma unroll
-    for (int pix = 0; pix < MA_PIX; ++pix) {
-      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    for (int px = 0; px < MA_PIX; px += NB) {
 #pragma unroll
-      for (int t = 0; t < DT; ++t) sacc = mfma16x16x16(to_half(acc[pix][t]), qh[pix][t], sacc);
-      float sv[4];
-      float mx = -INFINITY;
+      for (int jq = 0; jq < NB; ++jq) {
+        float sv[NB][4];
+        float mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sv[r] = sacc[r] * scale_log2;
-        mx = fmaxf(mx, sv[r]);
+        for (int ik = 0; ik < NB; ++ik) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < DT; ++t) sacc = mfma16x16x16(to_half(acc[px + ik][t]), qh[px + jq][t], sacc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sv[ik][r] = sacc[r] * scale_log2;
+            // F = 8: key row 4 g + r and query column l15 of a tile belong to the same pixel iff their bit 3 agrees
+            if (F == 8 && (g >> 1) != (l15 >> 3)) sv[ik][r] = -INFINITY;
+            mx = fmaxf(mx, sv[ik][r]);
+          }
+        }
+        mx = lane_xor32_max(lane_xor16_max(mx));
+        float ls = 0.f;
+#pragma unroll
+        for (int ik = 0; ik < NB; ++ik)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sv[ik][r] = __builtin_amdgcn_exp2f(sv[ik][r] - mx);
+            ls += sv[ik][r];
+          }
+        ls = lane_xor32_sum(lane_xor16_sum(ls));
+        const float inv = 1.0f / ls;
+#pragma unroll
+        for (int ik = 0; ik < NB; ++ik)
+          ph[px + ik][jq] = f16x4{(f16)(sv[ik][0] * inv), (f16)(sv[ik][1] * inv), (f16)(sv[ik][2] * inv), (f16)(sv[ik][3] * inv)};
       }
-      mx = lane_xor32_max(lane_xor16_max(mx));
-      float ls = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sv[r] = __builtin_amdgcn_exp2f(sv[r] - mx);
-        ls += sv[r];
-      }
-      ls = lane_xor32_sum(lane_xor16_sum(ls));
-      const float inv = 1.0f / ls;
-      ph[pix] = f16x4{(f16)(sv[0] * inv), (f16)(sv[1] * inv), (f16)(sv[2] * inv), (f16)(sv[3] * inv)};
     }
     MA_STAMP(4);
 
@@ -412,13 +430,19 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
     f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
     const int sln = ma_opaque(lane), sg = sln >> 4, sl15 = sln & 15;
 #pragma unroll
-    for (int pix = 0; pix < MA_PIX; ++pix) {
-      u32x2 oh[DT];
+    for (int px = 0; px < MA_PIX; px += NB)
 #pragma unroll
-      for (int t = 0; t < DT; ++t)
-        oh[t] = __builtin_bit_cast(u32x2, to_half(mfma16x16x16(to_half(acc[pix][t]), ph[pix], f32x4{0.f, 0.f, 0.f, 0.f})));
-      store_tiles(O + (int64_t)(16 * pix + sl15) * p.ldo, sg, oh);
-    }
+      for (int jq = 0; jq < NB; ++jq) {
+        u32x2 oh[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ik = 0; ik < NB; ++ik) o = mfma16x16x16(to_half(acc[px + ik][t]), ph[px + ik][jq], o);
+          oh[t] = __builtin_bit_cast(u32x2, to_half(o));
+        }
+        store_tiles(O + (int64_t)(16 * (px + jq) + sl15) * p.ldo, sg, oh);
+      }
     MA_STAMP(6);
     if (next < ntiles) normalise_rows(other);
     }
@@ -435,15 +459,15 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
 #undef MA_STAMP
 }
 
-template <int C, int D, int H, bool CROSS>
+template <int C, int D, int H, bool CROSS, int F = 16>
 int ma_cus() {       // CUs of the current device once it has granted this kernel its two panels of LDS; 0: refused (runtime.hip)
-  return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H, CROSS>), 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16));
+  return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H, CROSS, F>), 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16));
 }
 
-template <int C, int D, int H, bool CROSS>
+template <int C, int D, int H, bool CROSS, int F = 16>
 int launch_ma(const ma_args& p, int64_t rows, float scale, hipStream_t s, const char* what) {
   const size_t lds = 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16);
-  const int cus = ma_cus<C, D, H, CROSS>();
+  const int cus = ma_cus<C, D, H, CROSS, F>();
   if (cus <= 0) I2V_FAIL(I2V_ERR_UNSUPPORTED, "%s: %zu bytes of LDS refused by this device", what, lds);
   const int ntiles = (int)(rows / (MA_PIX * MA_F));
   // one workgroup per CU (160 KB of LDS each), every workgroup the same number of tiles where the count allows it
@@ -453,7 +477,7 @@ int launch_ma(const ma_args& p, int64_t rows, float scale, hipStream_t s, const 
 #ifdef I2V_MA_STAMPS
   stamps = getenv("I2V_MA_STAMP_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("I2V_MA_STAMP_PTR"), nullptr, 0)) : nullptr;
 #endif
-  hipLaunchKernelGGL((motion_attn_kernel<C, D, H, CROSS>), dim3((unsigned)grid), dim3(64 * H), lds, s, p, scale * 1.4426950408889634f,
+  hipLaunchKernelGGL((motion_attn_kernel<C, D, H, CROSS, F>), dim3((unsigned)grid), dim3(64 * H), lds, s, p, scale * 1.4426950408889634f,
                      ntiles, stamps);
   return i2v_check_launch(what);
 }
@@ -464,7 +488,9 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 extern "C" int32_t i2v_motion_attn_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t frames) {
   return rows > 0 && rows % (MA_PIX * MA_F) == 0 && rows / (MA_PIX * MA_F) < (1 << 24) && channels == 320 && heads == 8 &&
-         head_dim == 40 && frames == MA_F && ma_cus<320, 40, 8, false>() > 0;
+         head_dim == 40 &&
+         ((frames == 16 && ma_cus<320, 40, 8, false, 16>() > 0) || (frames == 8 && ma_cus<320, 40, 8, false, 8>() > 0) ||
+          (frames == 32 && ma_cus<320, 40, 8, false, 32>() > 0));
 }
 
 extern "C" int32_t i2v_motion_attn_pack_rows(int32_t heads, int32_t head_dim) { return heads * 3 * ((head_dim + 15) / 16) * 16; }
@@ -483,7 +509,10 @@ extern "C" int i2v_motion_attn_f16(const i2v_motion_attn_params* pp, i2v_stream_
   ma_args a = {};
   a.x = p.x; a.ldx = p.ldx; a.gamma = p.gamma; a.shift = p.shift; a.ld_shift = p.ld_shift; a.w = p.w_qkv; a.out = p.out;
   a.ldo = p.ldo; a.eps = p.eps;
-  return launch_ma<320, 40, 8, false>(a, p.rows, p.scale, reinterpret_cast<hipStream_t>(stream), "i2v_motion_attn_f16");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.frames == 8) return launch_ma<320, 40, 8, false, 8>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
+  if (p.frames == 32) return launch_ma<320, 40, 8, false, 32>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
+  return launch_ma<320, 40, 8, false, 16>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
 }
 
 extern "C" int32_t i2v_cross_attn_fused_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t ctx_len,

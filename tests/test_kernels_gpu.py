@@ -565,16 +565,21 @@ def test_temporal_attention_large_logits(dev, npix, frames, heads, d, amp):
     close(out.view(npix, frames, c), ref, rel=6e-4 * amp * amp, name="temporal attention, large logits")
 
 
-@pytest.mark.parametrize("npix,amp,strided", [(8, 1.0, False), (1000, 1.0, True), (256, 3.0, False), (8 * 771, 1.0, False)])
-def test_motion_attention_sub_block_fused(dev, npix, amp, strided):
-    """i2v_motion_attn_f16: LayerNorm + positional table, q / k / v projections and the attention over the 16 frames of a
+@pytest.mark.parametrize("npix,amp,strided,frames", [(8, 1.0, False, 16), (1000, 1.0, True, 16), (256, 3.0, False, 16),
+                                                      (8 * 771, 1.0, False, 16), (16, 1.0, False, 8), (16 * 37, 3.0, True, 8),
+                                                      (4, 1.0, False, 32), (4 * 53, 3.0, True, 32)])
+def test_motion_attention_sub_block_fused(dev, npix, amp, strided, frames):
+    """i2v_motion_attn_f16: LayerNorm + positional table, q / k / v projections and the attention over the frames of a
     pixel in one launch (channels 320, 8 heads of 40: the SD-1.5 64^2 level) against fp32 torch on the same fp16-rounded
-    operands, and against the un-fused kernels it replaces (LayerNorm -> q|k GEMM, V GEMM -> temporal attention)."""
+    operands, and against the un-fused kernels it replaces (LayerNorm -> q|k GEMM, V GEMM -> temporal attention).  16 frames (a
+    16-row MFMA tile is one pixel's sequence), 8 (two pixels per tile: the scores between them are masked) and 32 (a pixel is
+    two tiles: the configurations of 8 f x 256^2 and 32 f x 768^2)."""
     k = K()
-    c, heads, d, frames, eps = 320, 8, 40, 16, 1e-5
+    c, heads, d, eps = 320, 8, 40, 1e-5
     rows = npix * frames
     assert k.motion_attn_supported(rows, c, heads, d, frames) and not k.motion_attn_supported(rows + 16, c, heads, d, frames)
-    assert not k.motion_attn_supported(rows, 640, 8, 80, frames) and not k.motion_attn_supported(rows, c, heads, d, 8)
+    assert not k.motion_attn_supported(rows, 640, 8, 80, frames) and not k.motion_attn_supported(rows, c, heads, d, 4)
+    assert not k.motion_attn_supported(rows, c, heads, d, 24)
     g = torch.Generator().manual_seed(npix)
     ld = c + 64 if strided else c
     xb = h(torch.randn(rows, ld, generator=g) * 1.5 + 0.3)
