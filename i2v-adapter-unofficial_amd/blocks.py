@@ -1004,16 +1004,29 @@ class DDIMScheduler:
     def scale_model_input(self, sample, timestep=None):
         return sample
 
-    def step_coefficients(self, timesteps) -> torch.Tensor:
-        """[len(timesteps), 4] fp32: sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev), sqrt(1 - a_prev) with
-        t_prev = t - num_train_timesteps // num_inference_steps (the FULL step count, A12)."""
+    def step_coefficients(self, timesteps, eta: float = 0.0) -> torch.Tensor:
+        """[len(timesteps), 4] fp32: sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev), sqrt(1 - a_prev - sigma_t^2) with
+        t_prev = t - num_train_timesteps // num_inference_steps (the FULL step count, A12) and sigma_t of `step_sigmas`
+        (0 for eta = 0: the deterministic DDIM update of the hot path)."""
         rows = []
+        sig = self.step_sigmas(timesteps, eta)
+        for t, s in zip([int(v) for v in timesteps], sig):
+            prev_t = t - self.num_train_timesteps // self.num_inference_steps
+            a_t = self.alphas_cumprod[t]
+            a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+            rows.append(torch.stack([a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p - s ** 2) ** 0.5]))
+        return torch.stack(rows).to(torch.float32)
+
+    def step_sigmas(self, timesteps, eta: float = 0.0):
+        """sigma_t = eta sqrt((1 - a_prev) / (1 - a_t)) sqrt(1 - a_t / a_prev) per step (diffusers DDIMScheduler.step's
+        `std_dev_t`, pipe:550, 659-660): the weight of the fresh noise a stochastic step adds."""
+        out = []
         for t in [int(v) for v in timesteps]:
             prev_t = t - self.num_train_timesteps // self.num_inference_steps
             a_t = self.alphas_cumprod[t]
             a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
-            rows.append(torch.stack([a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5]))
-        return torch.stack(rows).to(torch.float32)
+            out.append(float(eta) * float((((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)) ** 0.5))
+        return out
 
     def add_noise(self, original_samples, noise, timesteps):
         ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)

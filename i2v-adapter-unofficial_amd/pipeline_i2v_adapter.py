@@ -273,8 +273,6 @@ class I2VAdapterPipeline:
         if condition_image_latents is None:
             raise ValueError("`condition_image` (or `condition_image_latents`) is required: the reference's prior "
                              "(pipe:647-656) needs the condition image and crashes without it")
-        if eta != 0.0:
-            raise NotImplementedError("eta = 0 on the hot path (pipe:550)")
         output_type, use_graph = self._resolve_call_defaults(output_type, callback, use_graph)
         dev = self.unet.device
         if dev.type != "cuda":
@@ -328,21 +326,28 @@ class I2VAdapterPipeline:
         st = dict(
             latents=latents, cond=cond_dev, copies=copies,
             num_frames=num_frames, guidance=float(guidance_scale),
-            t_table=timesteps.to(torch.float32).to(dev), coef=self.scheduler.step_coefficients(timesteps).to(dev),
+            t_table=timesteps.to(torch.float32).to(dev), coef=self.scheduler.step_coefficients(timesteps, eta).to(dev),
             step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
             ctx_text=prompt_embeds.to(dev, f16).contiguous(),
             ctx_ip=self.unet._project_image_embeds(
                 {"image_embeds": image_embeds.to(dev)} if image_embeds is not None else None))
         # K / V^T of the prompt (+ image) context for all 16 cross-attention layers: once per sample, not once per step
         # (projected where it is consumed: a graph-cache hit projects straight into the graph's static buffers)
-        if callback is None:
+        if callback is None and eta == 0.0:
             st["latents"] = self._run_steps(st, len(timesteps), use_graph)
         else:
+            # eager steps: a per-step host hook (pipe:693-697), and / or the stochastic DDIM update (eta > 0, pipe:550, 659-660:
+            # sigma_t is out of the direction coefficient -- `step_coefficients(timesteps, eta)` -- and comes back as fresh noise,
+            # one draw of the latents' shape per step from `generator` as diffusers' scheduler draws it)
+            sigmas = self.scheduler.step_sigmas(timesteps, eta)
             st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
             st["temb_table"] = self.unet.project_time_table(st["t_table"])
             for i, t in enumerate(timesteps):                                                   # pipe:666-697
                 self._step(st)
-                if i % callback_steps == 0:
+                if eta > 0:
+                    z = _draw(torch.randn, tuple(st["latents"].shape), generator, dev).to(torch.float32).contiguous()
+                    K.axpby(st["latents"], z, 1.0, sigmas[i])
+                if callback is not None and i % callback_steps == 0:
                     callback(i, t, st["latents"])
         latents = st["latents"]
         latents[:, 0] = st["cond"]                                                              # pipe:699-700

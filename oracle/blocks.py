@@ -522,17 +522,24 @@ class DDIMScheduler:
             sb = sb.unsqueeze(-1)
         return sa * original_samples + sb * noise
 
-    def step(self, model_output, timestep, sample, eta: float = 0.0):
-        if eta != 0.0:
-            raise NotImplementedError("eta=0 on the hot path (pipe:550)")
+    def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None, variance_noise=None):
+        """diffusers DDIMScheduler.step, epsilon prediction, no clipping.  eta > 0 (pipe:550, 659-660
+        `prepare_extra_step_kwargs`): sigma_t = eta sqrt((1 - a_prev) / (1 - a_t)) sqrt(1 - a_t / a_prev) is taken out of the
+        direction term and added back as fresh Gaussian noise (drawn from `generator` unless `variance_noise` is given)."""
         t = int(timestep)
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         b_t = 1 - a_t
+        std = eta * (((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)) ** 0.5
         pred_x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
-        pred_dir = (1 - a_prev) ** 0.5 * model_output
-        return a_prev ** 0.5 * pred_x0 + pred_dir
+        pred_dir = (1 - a_prev - std ** 2) ** 0.5 * model_output
+        prev = a_prev ** 0.5 * pred_x0 + pred_dir
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
+            prev = prev + std * variance_noise
+        return prev
 
 
 class DDPMScheduler(DDIMScheduler):

@@ -97,7 +97,7 @@ class I2VAdapterPipeline:
             if do_cfg:
                 u, c = noise_pred.chunk(2)
                 noise_pred = u + guidance_scale * (c - u)                                         # pipe:686-688
-            latents = self.scheduler.step(noise_pred, t, latents, eta=eta)                        # pipe:691
+            latents = self.scheduler.step(noise_pred, t, latents, eta=eta, generator=generator)   # pipe:659-660, 691
             if callback is not None:
                 callback(i, t, latents)
         latents[:, 0] = condition_image_latents                                                   # pipe:699-700

@@ -356,6 +356,31 @@ def test_pipeline_trajectory_two_samples_with_ip(dev, use_graph):
     assert (got[0] - got[1]).abs().max().item() > 0.1
 
 
+def test_pipeline_trajectory_stochastic_ddim(dev):
+    """eta > 0 (pipe:550, 659-660 `prepare_extra_step_kwargs` -> diffusers DDIMScheduler.step): sigma_t leaves the direction
+    coefficient and comes back as one fresh Gaussian draw of the latents' shape per step from `generator` -- the same draws, in
+    the same order, as the oracle loop makes; eta = 0 stays the deterministic path bit for bit."""
+    from oracle.pipeline_i2v_adapter import I2VAdapterPipeline as OP
+    ou = oracle_small_unet()
+    hu = hip_unet_from_oracle(ou, dev)
+    g = torch.Generator().manual_seed(33)
+    pe, ne = h(torch.randn(1, 7, 64, generator=g)), h(torch.randn(1, 7, 64, generator=g))
+    cond = torch.randn(1, 4, 16, 16, generator=g)
+    kw = dict(num_frames=4, num_inference_steps=10, guidance_scale=7.5, frame_similarity_sample_ratio=0.9)
+    gens = lambda: dict(generator=torch.Generator().manual_seed(5), prior_mask_generator=torch.Generator().manual_seed(6),
+                        prior_noise_generator=torch.Generator().manual_seed(7))
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+    run = lambda eta: pipe(prompt_embeds=pe, negative_prompt_embeds=ne, condition_image_latents=cond, eta=eta, **kw, **gens()).frames
+    det = run(0.0)
+    for eta in (0.5, 1.0):
+        ref = OP(ou)(pe, ne, cond, eta=eta, **kw, **gens()).frames
+        got = run(eta)
+        assert torch.equal(got[:, 0].cpu(), cond)
+        compare(got, ref, rel=REL_TOL_TRAJECTORY, name=f"stochastic DDIM trajectory, eta = {eta}")
+        assert (got - det).abs().max().item() > 0.1, "eta > 0 must change the trajectory"
+        assert torch.equal(got, run(eta)), "same seeds, same trajectory"
+
+
 def test_stream_forks_opt_in_child_process(dev):
     """I2V_STREAMS=1 (read at import) forks the independent chains of the 8 x 8 level onto a side stream (streams.py):
     the module, UNet and pipeline tests (oracle parity, eager == hipGraph bit for bit, cached-graph replays) re-run that way
