@@ -53,6 +53,47 @@ def w16(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(f16).contiguous()
 
 
+class LazyPack(dict):
+    """the dict a `_pack` returns, with entries that are built on FIRST USE: `p.lazy(name, fn)` / `p.lazy_group(names, fn)`.
+    The operands of the one-launch fused kernels (fragment-ordered weights, fp32 LayerNorm tables) are such entries: an
+    inference forward builds them once, while a training step -- whose optimiser writes the adapter's parameters in place, so
+    that the block's pack is rebuilt every step, and whose trainers never call a fused kernel -- does not pay their index
+    gathers and allocations."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._lazy = {}
+
+    def lazy(self, name, fn):
+        self._lazy[name] = (fn, None)
+
+    def lazy_group(self, names, fn):
+        """fn() returns one value per name (operands that are made together)"""
+        for i, n in enumerate(names):
+            self._lazy[n] = (fn, (tuple(names), i))
+
+    def __missing__(self, key):
+        if key not in self._lazy:
+            raise KeyError(key)
+        fn, grp = self._lazy[key]
+        with torch.no_grad():
+            val = fn()
+        if grp is None:
+            del self._lazy[key]
+            self[key] = val
+        else:
+            for n, v in zip(grp[0], val):
+                self._lazy.pop(n, None)
+                dict.__setitem__(self, n, v)
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 def pack_conv3x3(weight: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
     """[Cout, Cin, 3, 3] -> [Cout, 9 * Cin'] (Cin zero-padded to Cin') in the contraction order the conv kernel walks:
     tap-major k = (ky * 3 + kx) * Cin' + ci, or, when Cin' % 64 == 0 (`K.conv_k_block`), channel-block-major
@@ -535,10 +576,10 @@ class FeedForward(HipModule):
             w1, b1 = pack_geglu(proj.weight.detach(), proj.bias.detach())
         else:
             w1, b1 = w16(proj.weight), w16(proj.bias)
-        out = dict(w1=w1, b1=b1, w2=w16(self.net[2].weight), b2=w16(self.net[2].bias))
+        out = LazyPack(w1=w1, b1=b1, w2=w16(self.net[2].weight), b2=w16(self.net[2].bias))
         if self.activation_fn == "geglu" and K.ff_fused_supported(128, self.net[2].weight.shape[0], self.net[2].weight.shape[1]):
-            # operands of the one-launch form (i2v_ff_fused_f16: the SD-1.5 64^2 width)
-            out["fused"] = K.pack_ff_fused(proj.weight, proj.bias, self.net[2].weight, self.net[2].bias)
+            # operands of the one-launch form (i2v_ff_fused_f16: the SD-1.5 64^2 width), built on first use
+            out.lazy("fused", lambda: K.pack_ff_fused(proj.weight, proj.bias, self.net[2].weight, self.net[2].bias))
         return out
 
     def _fwd(self, n2d, residual2d, **store):
@@ -645,7 +686,7 @@ class TemporalTransformerBlock(HipModule):
         self._plan = LnFoldPlan()
 
     def _pack(self):
-        p = dict(pe=w16(self.pos_embed.pe[0]))
+        p = LazyPack(pe=w16(self.pos_embed.pe[0]))
         for i, (norm, attn) in enumerate(((self.norm1, self.attn1), (self.norm2, self.attn2)), 1):
             p[f"g{i}"], p[f"b{i}"] = w16(norm.weight), w16(norm.bias)
             p[f"wqk{i}"] = w16(torch.cat([attn.to_q.weight, attn.to_k.weight], dim=0))
@@ -662,11 +703,13 @@ class TemporalTransformerBlock(HipModule):
             p[f"f_wv{i}"], p[f"f_sv{i}"], p[f"f_cv{i}"] = fold_layernorm(attn.to_v.weight, None, norm.weight, norm.bias)
             p[f"f_pev{i}"] = (pe @ attn.to_v.weight.detach().float().T).T.to(f16).contiguous()       # [C, max_len]
         p["f_ff"] = self.ff.fold_norm(self.norm3)
-        # the fused LayerNorm + q / k / v + attention kernel's weights (per head, rows padded to 16)
+        # the fused LayerNorm + q / k / v + attention kernel's weights (per head, rows padded to 16) and the fused feed-forward's
+        # fp32 LayerNorm constants: built on first use (LazyPack)
         for i, attn in enumerate((self.attn1, self.attn2), 1):
-            p[f"wqkv{i}"] = K.pack_motion_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, self.heads)
+            p.lazy(f"wqkv{i}", lambda attn=attn: K.pack_motion_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, self.heads))
         self._ma_tables = {}          # (site, frames) -> (gamma fp32, beta + pe[frame] fp32), made on first use
-        p["g3_f32"], p["b3_f32"] = self.norm3.weight.detach().float().contiguous(), self.norm3.bias.detach().float().contiguous()
+        p.lazy("g3_f32", lambda: self.norm3.weight.detach().float().contiguous())
+        p.lazy("b3_f32", lambda: self.norm3.bias.detach().float().contiguous())
         return p
 
     def _fold_ok(self, t, frames):
@@ -764,10 +807,10 @@ class TransformerTemporalModel(HipModule):
         self.proj_out = nn.Linear(inner_dim, in_channels)
 
     def _pack(self):
-        p = dict(g=w16(self.norm.weight), b=w16(self.norm.bias), wi=w16(self.proj_in.weight),
-                 bi=w16(self.proj_in.bias), wo=w16(self.proj_out.weight), bo=w16(self.proj_out.bias))
+        p = LazyPack(g=w16(self.norm.weight), b=w16(self.norm.bias), wi=w16(self.proj_in.weight),
+                     bi=w16(self.proj_in.bias), wo=w16(self.proj_out.weight), bo=w16(self.proj_out.bias))
         # proj_out as the tail of the last block's fused feed-forward (the SD-1.5 64^2 width: a square 320 x 320 Linear)
-        p["tail"] = ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels)
+        p.lazy("tail", lambda: ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels))
         return p
 
     def _fwd(self, x, num_frames):

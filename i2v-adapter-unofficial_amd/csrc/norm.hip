@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
                                                        int c2, int hw, int rpc, float* __restrict__ partial,
                                                        float* __restrict__ gpartial = nullptr, int groups = 0) {
   __shared__ float red[256 * 16];
-  __shared__ float chan[2 * GN_MAXC];
+  // per-channel (mean, M2) of the chunk for the per-group merge: DYNAMIC LDS, 8 C bytes with gpartial and none without (r5, ADVICE
+  // r4: as a static 20 KB array every launch paid it -- backward and fallback passes too --, 36 KB per 256-thread block)
+  extern __shared__ float chan[];
   const int C = c1 + c2, nvec = C / 8;
   const int chunk = blockIdx.x, img = blockIdx.y, nchunk = gridDim.x;
   const int row_begin = chunk * rpc;
@@ -94,18 +96,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
       for (; r < row_end; r += rows_par) add(ld_global_16B(base + (int64_t)r * ld + coff));
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[tid * 16 + e] = s[e];
-      red[tid * 16 + 8 + e] = q[e];
+    for (int e = 0; e < 8; ++e) {      // [value][thread]: consecutive lanes on consecutive banks (r5: as [thread][16 values] every
+      red[e * 256 + tid] = s[e];       // store and load of a wave hit 4 banks 16 deep -- SQ_LDS_BANK_CONFLICT 0.71 of the LDS cycles)
+      red[(8 + e) * 256 + tid] = q[e];
     }
     __syncthreads();
     if (row_lane == 0 && col < nvec) {
       for (int rl = 1; rl < rows_par; ++rl) {
-        const int o = (rl * cols_per_pass + col_lane) * 16;
+        const int o = rl * cols_per_pass + col_lane;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          s[e] += red[o + e];
-          q[e] += red[o + 8 + e];
+          s[e] += red[e * 256 + o];
+          q[e] += red[(8 + e) * 256 + o];
         }
       }
       const float n = (float)(row_end - row_begin), inv_n = 1.0f / n;
@@ -817,8 +819,9 @@ extern "C" int i2v_groupnorm_fold_f16(const i2v_gn_params* pp, const void* w, in
   float* coef = partial + (int64_t)p.n_img * nchunk * C * 2;
   if (p.groups <= GN_MAXG && C <= GN_MAXC) {
     float* gpartial = coef + (int64_t)p.n_img * C * 2;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, reinterpret_cast<const f16*>(p.x), p.c1,
-                       reinterpret_cast<const f16*>(p.x2), p.c2, p.hw, rpc, partial, gpartial, p.groups);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), (size_t)C * 2 * sizeof(float), s,
+                       reinterpret_cast<const f16*>(p.x), p.c1, reinterpret_cast<const f16*>(p.x2), p.c2, p.hw, rpc, partial, gpartial,
+                       p.groups);
     hipLaunchKernelGGL(gn_finalize_g_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, gpartial, nchunk, C,
                        p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
                        reinterpret_cast<const f16*>(p.beta), coef);
@@ -879,8 +882,8 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   const size_t fused_lds = ((size_t)nchunk * p.groups * 2 + (size_t)p.groups * 2) * sizeof(float);
   if (!fused_off && p.frames_per_stat == 1 && !p.out_perm && p.groups <= GN_MAXG && C <= GN_MAXC && fused_lds <= 48 * 1024) {
     float* gpartial = coef + (int64_t)p.n_img * C * 2;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial, gpartial,
-                       p.groups);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), (size_t)C * 2 * sizeof(float), s, x1, p.c1, x2, p.c2, p.hw,
+                       rpc, partial, gpartial, p.groups);
     hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(nchunk, p.n_img), dim3(256), fused_lds, s, x1, p.c1, x2, p.c2, gpartial, p.groups,
                        reinterpret_cast<const f16*>(p.gamma), reinterpret_cast<const f16*>(p.beta), p.eps,
                        reinterpret_cast<f16*>(p.y), p.hw, rpc, p.silu);
@@ -888,8 +891,8 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   }
   if (!fused_off && p.groups <= GN_MAXG && C <= GN_MAXC) {
     float* gpartial = coef + (int64_t)p.n_img * C * 2;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), 0, s, x1, p.c1, x2, p.c2, p.hw, rpc, partial, gpartial,
-                       p.groups);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.n_img), dim3(256), (size_t)C * 2 * sizeof(float), s, x1, p.c1, x2, p.c2, p.hw,
+                       rpc, partial, gpartial, p.groups);
     hipLaunchKernelGGL(gn_finalize_g_kernel, dim3(p.n_img / p.frames_per_stat, p.groups), dim3(256), 0, s, gpartial, nchunk, C,
                        p.groups, p.frames_per_stat, p.hw, rpc, p.eps, reinterpret_cast<const f16*>(p.gamma),
                        reinterpret_cast<const f16*>(p.beta), coef);

@@ -18,7 +18,7 @@ from torch import nn
 
 from . import kernels as K
 from . import streams
-from .blocks import (gn_proj_in, ff_tail_operands, Attention, FeedForward, HipModule, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
+from .blocks import (gn_proj_in, ff_tail_operands, Attention, FeedForward, HipModule, LazyPack, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
                      to_tokens, w16)
 from ._lib import HipLibraryError
 from .checkpoint import PretrainedMixin
@@ -114,8 +114,8 @@ class I2VAdapterTransformerBlock(HipModule):
 
     def _pack(self):
         a1, ad = self.attn1, self.i2v_adapter
-        p = dict(g1=w16(self.norm1.weight), b1=w16(self.norm1.bias), g3=w16(self.norm3.weight),
-                 b3=w16(self.norm3.bias))
+        p = LazyPack(g1=w16(self.norm1.weight), b1=w16(self.norm1.bias), g3=w16(self.norm3.weight),
+                     b3=w16(self.norm3.bias))
         # one GEMM: [attn1.to_q | attn1.to_k | i2v_adapter.to_q] (the first 2C rows alone when the adapter is off)
         p["w_qkq"] = w16(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0))
         p["w_v1"] = w16(a1.to_v.weight)
@@ -129,22 +129,25 @@ class I2VAdapterTransformerBlock(HipModule):
             p["w_q2"] = w16(self.attn2.to_q.weight)
             p["w_o2"], p["b_o2"] = w16(self.attn2.to_out[0].weight), w16(self.attn2.to_out[0].bias)
             p["f_q2"] = fold_layernorm(self.attn2.to_q.weight, None, self.norm2.weight, self.norm2.bias)
-            # the fused LayerNorm + to_q + text cross-attention kernel's operands (64^2 level of SD-1.5, no image tokens)
-            p["wq2_frag"] = K.pack_cross_q(self.attn2.to_q.weight, self.heads)
-            p["g2_f32"], p["b2_f32"] = self.norm2.weight.detach().float().contiguous(), self.norm2.bias.detach().float().contiguous()
+            # the fused LayerNorm + to_q + text cross-attention kernel's operands (64^2 level of SD-1.5): built on first use
+            p.lazy("wq2_frag", lambda: K.pack_cross_q(self.attn2.to_q.weight, self.heads))
+            p.lazy("g2_f32", lambda: self.norm2.weight.detach().float().contiguous())
+            p.lazy("b2_f32", lambda: self.norm2.bias.detach().float().contiguous())
         # LayerNorm folded into the consuming projections (i2v:444-445 -> q | k | q_adapter and V^T; i2v:510 -> attn2.to_q;
         # i2v:539 -> GEGLU): operands (W o gamma, row sums, W beta + b) of the LayerNorm-folded GEMM
         p["f_qkq"] = fold_layernorm(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), None,
                                     self.norm1.weight, self.norm1.bias)
         p["f_v1"] = fold_layernorm(a1.to_v.weight, None, self.norm1.weight, self.norm1.bias)
         p["f_ff"] = self.ff.fold_norm(self.norm3)
-        p["g3_f32"], p["b3_f32"] = self.norm3.weight.detach().float().contiguous(), self.norm3.bias.detach().float().contiguous()
+        p.lazy("g3_f32", lambda: self.norm3.weight.detach().float().contiguous())
+        p.lazy("b3_f32", lambda: self.norm3.bias.detach().float().contiguous())
         # the one-launch LayerNorm 1 + [q | k | q_adapter] + V^T projection's operands (64^2 level of SD-1.5), with and without
-        # the adapter's query
+        # the adapter's query: built on first use
         if K.ln_qkv_supported(128, self.dim, 3 * self.dim, 128):
-            p["g1_f32"], p["b1_f32"] = self.norm1.weight.detach().float().contiguous(), self.norm1.bias.detach().float().contiguous()
-            p["w_lnqkv3"] = K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), a1.to_v.weight)
-            p["w_lnqkv2"] = K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight], dim=0), a1.to_v.weight)
+            p.lazy("g1_f32", lambda: self.norm1.weight.detach().float().contiguous())
+            p.lazy("b1_f32", lambda: self.norm1.bias.detach().float().contiguous())
+            p.lazy("w_lnqkv3", lambda: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), a1.to_v.weight))
+            p.lazy("w_lnqkv2", lambda: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight], dim=0), a1.to_v.weight))
         return p
 
     def _fold_ok(self, x, L, rows_qkq):
@@ -358,11 +361,12 @@ class I2VAdapterTransformer2DModel(HipModule):
             mine.i2v_adapter.to_out[0].bias.data.zero_()
 
     def _pack(self):
-        return dict(g=w16(self.norm.weight), b=w16(self.norm.bias),
-                    wi=w16(self.proj_in.weight.reshape(self.inner_dim, self.in_channels)), bi=w16(self.proj_in.bias),
-                    wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias),
-                    # proj_out as the tail of the last block's fused feed-forward (the SD-1.5 64^2 width)
-                    tail=ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels))
+        p = LazyPack(g=w16(self.norm.weight), b=w16(self.norm.bias),
+                     wi=w16(self.proj_in.weight.reshape(self.inner_dim, self.in_channels)), bi=w16(self.proj_in.bias),
+                     wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias))
+        # proj_out as the tail of the last block's fused feed-forward (the SD-1.5 64^2 width): built on first use
+        p.lazy("tail", lambda: ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels))
+        return p
 
     def packed(self):
         # only this module's own leaf parameters feed its pack (the transformer blocks pack themselves): a training step

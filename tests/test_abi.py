@@ -75,7 +75,7 @@ def test_bad_arguments_return_error_codes_without_a_gpu(lib):
     assert h.i2v_groupnorm_workspace_bytes(2, 300, 64) == (2 * 19 * 64 * 2 + 2 * 64 * 2 + 2 * 19 * 64 * 2) * 4
     # the fused motion-module attention: which shapes it takes, how many packed weight rows, and the refusal of the others
     assert h.i2v_motion_attn_supported(131072, 320, 8, 40, 16) == 1 and h.i2v_motion_attn_supported(131072 + 16, 320, 8, 40, 16) == 0
-    assert h.i2v_motion_attn_supported(32768, 640, 8, 80, 16) == 0 and h.i2v_motion_attn_supported(65536, 320, 8, 40, 8) == 0
+    assert h.i2v_motion_attn_supported(32768, 640, 8, 80, 16) == 0 and h.i2v_motion_attn_supported(65536, 320, 8, 40, 4) == 0
     assert h.i2v_motion_attn_pack_rows(8, 40) == 8 * 3 * 48
     assert h.i2v_motion_attn_f16(None, None) == -1
     mp = lib.MotionAttnParams()
@@ -83,7 +83,23 @@ def test_bad_arguments_return_error_codes_without_a_gpu(lib):
     assert h.i2v_motion_attn_f16(C.byref(mp), None) == -1 and b"null pointer" in h.i2v_last_error()
     assert h.i2v_cross_attn_fused_supported(131072, 320, 8, 40, 77, 65536) == 1 and h.i2v_cross_attn_fused_pack_rows(8, 40) == 8 * 48
     assert h.i2v_cross_attn_fused_supported(131072, 320, 8, 40, 81, 65536) == 0 and h.i2v_cross_attn_fused_f16(None, None) == -1
+    # (r5) 8 and 32 frames too: two pixels per MFMA tile / two tiles per pixel
+    assert h.i2v_motion_attn_supported(65536, 320, 8, 40, 8) == 1 and h.i2v_motion_attn_supported(65536, 320, 8, 40, 32) == 1
     assert h.i2v_ff_fused_supported(131072, 320, 1280) == 1 and h.i2v_ff_fused_supported(32768, 640, 2560) == 0
+    # (ABI 8) the block's closing Linear as the tail of the fused feed-forward: rows in (batch, pixel, frame) order need whole clips
+    # of a power-of-two frame count
+    assert h.i2v_ff_fused_tail_supported(131072, 320, 1280, 0, 0) == 1 and h.i2v_ff_fused_tail_supported(131072, 320, 1280, 16, 4096) == 1
+    assert h.i2v_ff_fused_tail_supported(131072, 320, 1280, 12, 4096) == 0 and h.i2v_ff_fused_tail_supported(131072, 320, 1280, 16, 4095) == 0
+    fp = lib.FfFusedParams()
+    fp.rows, fp.channels, fp.inner = 256, 320, 1280
+    assert h.i2v_ff_fused_f16(C.byref(fp), None) == -1 and b"null pointer" in h.i2v_last_error()
+    # (ABI 8) LayerNorm 1 + q | k | q_adapter + V^T in one launch
+    assert h.i2v_ln_qkv_supported(131072, 320, 960, 4096) == 1 and h.i2v_ln_qkv_supported(131072, 320, 640, 4096) == 1
+    assert h.i2v_ln_qkv_supported(131072, 320, 320, 4096) == 0 and h.i2v_ln_qkv_supported(32768, 640, 1920, 1024) == 0
+    assert h.i2v_ln_qkv_supported(131072, 320, 960, 4000) == 0 and h.i2v_ln_qkv_f16(None, None) == -1
+    qp = lib.LnQkvParams()
+    qp.rows, qp.channels, qp.n_qk, qp.rows_per_image = 256, 320, 960, 128
+    assert h.i2v_ln_qkv_f16(C.byref(qp), None) == -1 and b"null pointer" in h.i2v_last_error()
     assert h.i2v_ff_fused_f16(None, None) == -1
     assert h.i2v_colsum_workspace_bytes(1000, 70) == 4 * 70 * 4 and h.i2v_colsum_det_f32(None, 0, None, 0, None, 0, 0, None, None) == -1
 

@@ -274,3 +274,21 @@ def test_fresh_process_import_order():
                 "from i2v_adapter_unofficial_amd import streams, blocks, sharding; p.I2VAdapterPipeline; print('ok')")
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and "ok" in r.stdout, first + "\n" + r.stderr[-1500:]
+
+
+def test_lazy_pack_builds_fused_operands_on_first_use_only():
+    """blocks.LazyPack: the fused kernels' operands are registered by `_pack` but built on first access -- `in` and
+    `get` see them without building, a group of operands made together is built once."""
+    from i2v_adapter_unofficial_amd.blocks import LazyPack
+    calls = []
+    p = LazyPack(a=1)
+    p.lazy("b", lambda: calls.append("b") or 2)
+    p.lazy_group(("c", "d"), lambda: calls.append("cd") or (3, 4))
+    assert "b" in p and "c" in p and "zz" not in p and calls == []
+    assert p["a"] == 1 and calls == []
+    assert p["b"] == 2 and p["b"] == 2 and calls == ["b"]
+    assert p.get("d") == 4 and p["c"] == 3 and calls == ["b", "cd"]
+    assert p.get("zz", 7) == 7
+    import pytest
+    with pytest.raises(KeyError):
+        p["zz"]

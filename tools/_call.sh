@@ -1,15 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-: > gpurun_out/c25_configs.jsonl
-timeout -k 10 300 python bench.py --no-cpu-baseline --frames 8 --size 256 2>/dev/null >> gpurun_out/c25_configs.jsonl
-timeout -k 10 300 python bench.py --no-cpu-baseline 2>/dev/null >> gpurun_out/c25_configs.jsonl
-timeout -k 10 300 python bench.py --no-cpu-baseline --ip 2>/dev/null >> gpurun_out/c25_configs.jsonl
-timeout -k 10 600 python bench.py --no-cpu-baseline --frames 32 --size 768 --steps 10 --windows 3 2>/dev/null >> gpurun_out/c25_configs.jsonl
-I2V_MOTION_FUSED=0 timeout -k 10 600 python bench.py --no-cpu-baseline --frames 32 --size 768 --steps 10 --windows 3 2>/dev/null >> gpurun_out/c25_configs.jsonl
-python -c "
-import json
-for l in open('gpurun_out/c25_configs.jsonl'):
-    d=json.loads(l); print(d['config']['workload'][:70], round(d['value'],3), round(d['ms_per_step'],2))
-"
-timeout -k 10 1000 python bench.py --parity-only --frames 32 --size 768 2> gpurun_out/c25_p5.err | tee gpurun_out/c25_parity_config5.json | cut -c1-400
+timeout -k 10 1100 python -m pytest tests/test_kernels_gpu.py tests/test_training_gpu.py tests/test_modules_gpu.py -x -q -m gpu -k "norm or training or pipeline or train or adapter or block" 2>&1 | tail -3
+python bench.py --no-cpu-baseline --shapes gpurun_out/c27_step_shapes.txt 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],3), round(d['ms_per_step'],3), {k: v['ms'] for k, v in d['kernel_classes'].items()})"
+head -60 gpurun_out/c27_step_shapes.txt

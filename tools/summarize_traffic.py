@@ -20,8 +20,10 @@ def classify(name):
         return "splitk_reduce"
     if "ff_fused" in name:
         return "ff_fused"
-    if "motion_attn" in name:      # motion_attn_kernel<C, D, H, CROSS>: the text cross-attention form shares the template
-        return "cross_attn_fused" if re.search(r"motion_attn_kernel<[^>]*true>", name) else "motion_attn"
+    if "ln_qkv" in name:
+        return "ln_qkv"
+    if "motion_attn" in name:      # motion_attn_kernel<C, D, H, CROSS, F>: the text cross-attention form shares the template
+        return "cross_attn_fused" if re.search(r"motion_attn_kernel<[^>]*true", name) else "motion_attn"
     if "tattn" in name:
         return "temporal_attention"
     if "attn_kernel" in name:
