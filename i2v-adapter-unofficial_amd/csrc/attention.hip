@@ -190,7 +190,12 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2, const int qbw_
     const int id = tid + 256 * i;
     const int row = id / KCH, c = id - row * KCH;
     k_off[i] = 8 * c < d ? (int)((row * p.k_row_stride + 8 * c) * 2) : OOB;
-    k_lds[i] = row * KS + 8 * c;
+    // (r5) key `row` of the tile sits in LDS row 16 kt + l15 of the S^T tile (kt, l15) that reads it -- key = 32 (kt >> 1) + 8 (l15 >> 2)
+    // + 4 (kt & 1) + (l15 & 3), i.e. bit 2 of the key moves to bit 4 of the LDS row -- so that the 16 rows of a fragment read are
+    // CONSECUTIVE: with the natural order they were rows b .. b + 3, b + 8 .., b + 16 .., b + 24 .., and rows 16 apart share their
+    // banks whatever the row stride (two-way conflicts on every K fragment read; SQ_LDS_BANK_CONFLICT 0.39 of the LDS cycles)
+    const int lrow = (row & ~28) | ((row & 4) << 2) | ((row & 24) >> 1);
+    k_lds[i] = lrow * KS + 8 * c;
   }
 #pragma unroll
   for (int i = 0; i < NVC; ++i) {
@@ -262,7 +267,7 @@ void attn_kernel(const i2v_attn_params p, const float scale_log2, const int qbw_
 #endif
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const int krow = 32 * (kt >> 1) + 8 * (l15 >> 2) + 4 * (kt & 1) + (l15 & 3);
+      const int krow = 16 * kt + l15;          // (the staging permutes the keys so that a tile's 16 keys are consecutive LDS rows)
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(&sK[krow * KS + 32 * s + 8 * g]);
