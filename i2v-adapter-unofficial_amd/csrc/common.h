@@ -35,6 +35,10 @@ int i2v_check_launch(const char* what);
 // CUs of the current device after opting `func` in to `lds_bytes` of dynamic LDS there (cached per kernel and device), 0 when the
 // device refuses (runtime.hip)
 int i2v_big_lds_kernel_cus(const void* func, size_t lds_bytes);
+// grid of a persistent 128-row-tile kernel: by default every workgroup (one per CU) walks ceil(ntiles / CUs) tiles;
+// I2V_FUSED_TILES_PER_WG=n (tuning) gives every workgroup n tiles instead (1: one workgroup per tile, the hardware's workgroup
+// turnover instead of the walk)
+int i2v_persistent_grid(int ntiles, int cus);
 
 static inline int64_t i2v_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

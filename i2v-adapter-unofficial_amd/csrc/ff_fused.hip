@@ -526,8 +526,7 @@ extern "C" int i2v_ff_fused_f16(const i2v_ff_fused_params* pp, i2v_stream_t stre
   const int cus = tail ? ff_cus<true>() : ff_cus<false>();
   if (cus <= 0) I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_ff_fused_f16: %zu bytes of LDS refused by this device", FF_LDS);
   const int ntiles = (int)(p.rows / (FF_PIX * 16));
-  const int per = (ntiles + cus - 1) / cus;
-  const int grid = (ntiles + per - 1) / per;
+  const int grid = i2v_persistent_grid(ntiles, cus);
   long long* stamps = nullptr;
 #ifdef I2V_FF_STAMPS
   stamps = getenv("I2V_FF_STAMP_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("I2V_FF_STAMP_PTR"), nullptr, 0)) : nullptr;

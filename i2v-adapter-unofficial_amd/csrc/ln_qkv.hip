@@ -187,7 +187,11 @@ __global__ __launch_bounds__(64 * H) void ln_qkv_kernel(const i2v_ln_qkv_params 
     const f16* panel = panels + (it & 1) * (LQ_PIX * 16 * C);
     f16* other = panels + ((it + 1) & 1) * (LQ_PIX * 16 * C);
     const int next = tile + (int)gridDim.x;
+#ifdef LQ_SMALLOUT
+    const int64_t row0 = 0;      // (timing experiment: every tile stores to the first tile's rows -- the stores stay in L2)
+#else
     const int64_t row0 = (int64_t)tile * (LQ_PIX * 16);
+#endif
     // q | k | q_adapter tiles: D[channel][row]; lane: channels 16 t + 4 g .. + 3 of row l15.  v_permlane16_swap pairs the lane
     // groups: even g ends with tile t channels 4 g .. + 7, odd g with tile t + 1 channels 4 (g - 1) .. + 7 -- one 16-byte store
     auto store_qk = [&](const int t0, auto ntl) {
@@ -288,8 +292,7 @@ extern "C" int i2v_ln_qkv_f16(const i2v_ln_qkv_params* pp, i2v_stream_t stream) 
   const int cus = lq_cus();
   if (cus <= 0) I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_ln_qkv_f16: %zu bytes of LDS refused by this device", LQ_LDS);
   const int ntiles = (int)(p.rows / (LQ_PIX * 16));
-  const int per = (ntiles + cus - 1) / cus;
-  const int grid = (ntiles + per - 1) / per;
+  const int grid = i2v_persistent_grid(ntiles, cus);
   hipLaunchKernelGGL((ln_qkv_kernel<320, 8>), dim3((unsigned)grid), dim3(512), LQ_LDS, reinterpret_cast<hipStream_t>(stream), p, ntiles);
   return i2v_check_launch("i2v_ln_qkv_f16");
 }

@@ -471,8 +471,7 @@ int launch_ma(const ma_args& p, int64_t rows, float scale, hipStream_t s, const 
   if (cus <= 0) I2V_FAIL(I2V_ERR_UNSUPPORTED, "%s: %zu bytes of LDS refused by this device", what, lds);
   const int ntiles = (int)(rows / (MA_PIX * MA_F));
   // one workgroup per CU (160 KB of LDS each), every workgroup the same number of tiles where the count allows it
-  const int per = (ntiles + cus - 1) / cus;
-  const int grid = (ntiles + per - 1) / per;
+  const int grid = i2v_persistent_grid(ntiles, cus);
   long long* stamps = nullptr;
 #ifdef I2V_MA_STAMPS
   stamps = getenv("I2V_MA_STAMP_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("I2V_MA_STAMP_PTR"), nullptr, 0)) : nullptr;

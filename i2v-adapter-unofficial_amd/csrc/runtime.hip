@@ -1,6 +1,7 @@
 // Error plumbing and version entry points of libi2v_hip.so.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -50,6 +51,12 @@ int i2v_big_lds_kernel_cus(const void* func, size_t lds_bytes) {
   }
   table.push_back({func, dev, cus});
   return cus;
+}
+
+int i2v_persistent_grid(int ntiles, int cus) {
+  static const int forced = getenv("I2V_FUSED_TILES_PER_WG") ? atoi(getenv("I2V_FUSED_TILES_PER_WG")) : 0;
+  const int per = forced > 0 ? forced : (ntiles + cus - 1) / cus;
+  return (ntiles + per - 1) / per;
 }
 
 extern "C" const char* i2v_last_error(void) { return g_err; }
