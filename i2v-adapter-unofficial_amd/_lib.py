@@ -143,6 +143,7 @@ class LnQkvParams(C.Structure):
         ("rows", C.c_int64), ("rows_per_image", C.c_int64),
         ("channels", C.c_int32), ("n_qk", C.c_int32),
         ("eps", C.c_float),
+        ("x_image_stride", C.c_int64),
     ]
 
 

@@ -53,7 +53,12 @@ __global__ __launch_bounds__(64 * H) void ln_qkv_kernel(const i2v_ln_qkv_params 
   // ---- LayerNorm of the wave's 16 rows into a panel (as motion_attn.hip: raw rows by LDS-DMA into the wave's own 10 KB, then
   // normalised in place)
   auto fetch_rows = [&](const int tile, f16* panel) {
-    const f16* base = X + ((int64_t)tile * (LQ_PIX * 16) + 16 * wave) * p.ldx;
+    int64_t r0 = (int64_t)tile * (LQ_PIX * 16) + 16 * wave;            // (images are whole tiles: a wave's 16 rows are in one)
+    const f16* base = X + r0 * p.ldx;
+    if (p.x_image_stride > 0) {                                         // images at their own stride (frame-0 rows in place)
+      const int64_t img = r0 / p.rows_per_image;
+      base = X + img * p.x_image_stride + (r0 - img * p.rows_per_image) * p.ldx;
+    }
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)((15 * p.ldx + C) * 2), 0x00020000);
     const int ln = lq_opaque(lane);
     const unsigned voff = (unsigned)(((ln >> 3) * p.ldx + (ln & 7) * 8) * 2);
@@ -272,7 +277,7 @@ int lq_cus() { return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(ln_qk
 
 extern "C" int32_t i2v_ln_qkv_supported(int64_t rows, int32_t channels, int32_t n_qk, int64_t rows_per_image) {
   return rows > 0 && rows % (LQ_PIX * 16) == 0 && rows / (LQ_PIX * 16) < (1 << 24) && channels == 320 &&
-         (n_qk == 2 * channels || n_qk == 3 * channels) && rows_per_image > 0 && rows_per_image % (LQ_PIX * 16) == 0 &&
+         (n_qk == channels || n_qk == 2 * channels || n_qk == 3 * channels) && rows_per_image > 0 && rows_per_image % (LQ_PIX * 16) == 0 &&
          rows % rows_per_image == 0 && lq_cus() > 0;
 }
 
@@ -285,7 +290,8 @@ extern "C" int i2v_ln_qkv_f16(const i2v_ln_qkv_params* pp, i2v_stream_t stream) 
                 (long long)p.rows, p.channels, p.n_qk, (long long)p.rows_per_image);
   I2V_CHECK_ARG(p.ldx >= p.channels && p.ldx % 8 == 0 && p.ldx < (1 << 24) && p.ld_qk >= p.n_qk && p.ld_qk % 8 == 0 &&
                     p.vt_row_stride >= p.rows_per_image && p.vt_row_stride % 8 == 0 &&
-                    p.vt_batch_stride >= (int64_t)p.channels * p.vt_row_stride && p.vt_batch_stride % 8 == 0,
+                    p.vt_batch_stride >= (int64_t)p.channels * p.vt_row_stride && p.vt_batch_stride % 8 == 0 &&
+                    (p.x_image_stride == 0 || (p.x_image_stride >= p.rows_per_image * p.ldx && p.x_image_stride % 8 == 0)),
                 "i2v_ln_qkv_f16: strides");
   I2V_CHECK_ARG(al16(p.x) && al16(p.gamma) && al16(p.beta) && al16(p.w) && al16(p.qk) && al16(p.vt),
                 "i2v_ln_qkv_f16: pointers must be 16-byte aligned");

@@ -148,6 +148,8 @@ class I2VAdapterTransformerBlock(HipModule):
             p.lazy("b1_f32", lambda: self.norm1.bias.detach().float().contiguous())
             p.lazy("w_lnqkv3", lambda: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), a1.to_v.weight))
             p.lazy("w_lnqkv2", lambda: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight], dim=0), a1.to_v.weight))
+            # ... and the adapter's K0 | V0^T over the frame-0 rows (i2v:484-492) the same way
+            p.lazy("w_lnkv_ad", lambda: K.pack_ln_qkv(ad.to_k.weight, ad.to_v.weight))
         return p
 
     def _fold_ok(self, x, L, rows_qkq):
@@ -209,7 +211,12 @@ class I2VAdapterTransformerBlock(HipModule):
                     vt1 = K.project_vt(x, wv, L, bias=cv, ln=(sv, self.eps))
                 else:
                     vt1 = K.project_vt(n, p["w_v1"], L)
-                if enable_cross_frame_attn:
+                if enable_cross_frame_attn and fused_qkv and K.ln_qkv_supported(n_img // num_frames * L, c, c, L):
+                    # LayerNorm 1 of the frame-0 rows (read in place), K0 and V0^T in ONE launch instead of three
+                    clips = n_img // num_frames
+                    k0, v0t = K.ln_qkv(x, p["g1_f32"], p["b1_f32"], p["w_lnkv_ad"], n_qk=c, rows_per_image=L, eps=self.eps,
+                                       images=clips, x_image_stride=num_frames * L * x.stride(0))
+                elif enable_cross_frame_attn:
                     clips = n_img // num_frames
                     if n is None:
                         # LayerNorm 1 folded away: normalise just the frame-0 rows of every clip (1 / num_frames of the

@@ -451,12 +451,17 @@ def pack_ln_qkv(w_qk, w_v):
     return w.view(n // 16, 16, c // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(n, c)     # [tile, s, g, l15, j]
 
 
-def ln_qkv(x, gamma32, beta32, w_packed, *, n_qk, rows_per_image, eps, qk=None, vt=None):
+def ln_qkv(x, gamma32, beta32, w_packed, *, n_qk, rows_per_image, eps, qk=None, vt=None, images=None, x_image_stride=0):
     """(qk [rows, n_qk], vt [rows / rows_per_image, C, pad8(rows_per_image)]) = projections of LayerNorm(x) in one launch
-    (i2v_ln_qkv_f16); w_packed = `pack_ln_qkv(w_qk, w_v)`."""
+    (i2v_ln_qkv_f16); w_packed = `pack_ln_qkv(w_qk, w_v)`.  images / x_image_stride: only `images` blocks of rows_per_image rows
+    of x are taken, block i starting at row i * x_image_stride / ldx (the frame-0 rows of every clip, read in place)."""
     lib = _lib.load()
     x, ldx = _mat(x, "x")
     rows, c = x.shape
+    if images is not None:
+        if x_image_stride % ldx or (images - 1) * (x_image_stride // ldx) + rows_per_image > rows:
+            raise ValueError(f"ln_qkv: {images} images of {rows_per_image} rows at stride {x_image_stride} do not fit x {tuple(x.shape)}")
+        rows = images * rows_per_image
     _req(w_packed, "w")
     for name, t in (("gamma32", gamma32), ("beta32", beta32)):
         _req(t, name, dtype=torch.float32)
@@ -481,6 +486,7 @@ def ln_qkv(x, gamma32, beta32, w_packed, *, n_qk, rows_per_image, eps, qk=None, 
     p.qk, p.ld_qk = _p(qk), ld_qk
     p.vt, p.vt_batch_stride, p.vt_row_stride = _p(vt), c * ld, ld
     p.rows, p.rows_per_image, p.channels, p.n_qk, p.eps = rows, rows_per_image, c, n_qk, float(eps)
+    p.x_image_stride = int(x_image_stride) if images is not None else 0
     _lib.check(lib.i2v_ln_qkv_f16(C.byref(p), _stream()), "i2v_ln_qkv_f16")
     return qk, vt
 

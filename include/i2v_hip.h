@@ -269,7 +269,7 @@ int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* p, i2v_stream_t 
 /* ------------------------------------------------------------------------------------------------
  * (ABI 8) LayerNorm 1 and the projections in front of the spatial block's self- / cross-frame attention in one launch
  * (i2v:444-445 `norm1`, 468-473 `attn1` to_q / to_k / to_v, 483-492 the adapter's to_q):
- *     n = LayerNorm(x) gamma + beta;   qk[r, :] = n[r] W_qk^T  (n_qk = 2 C: [q | k], or 3 C: [q | k | q_adapter]);
+ *     n = LayerNorm(x) gamma + beta;   qk[r, :] = n[r] W_qk^T  (n_qk = 2 C: [q | k], 3 C: [q | k | q_adapter], or C: [k] alone);
  *     vt[r / rows_per_image][c][r % rows_per_image] = (n[r] W_v^T)[c]     (the V^T operand of i2v_attention_f16)
  * replaces native_layer_norm + three / four aten addmm (+ the transpose SDPA does internally).  LayerNorm output rounded to fp16
  * where the un-fused kernels store it; statistics and accumulation in fp32.  gamma, beta: fp32 [channels].
@@ -287,6 +287,9 @@ typedef struct i2v_ln_qkv_params {
   int64_t rows, rows_per_image;
   int32_t channels, n_qk;
   float eps;
+  /* > 0: image i's rows_per_image rows start at x + i * x_image_stride elements instead of following image i - 1 -- the frame-0
+     rows of every clip read in place for the adapter's K0 | V0^T (n_qk = C: [k] only; i2v:484-492, no gathered copy) */
+  int64_t x_image_stride;
 } i2v_ln_qkv_params;
 
 int32_t i2v_ln_qkv_supported(int64_t rows, int32_t channels, int32_t n_qk, int64_t rows_per_image);

@@ -95,7 +95,8 @@ def test_bad_arguments_return_error_codes_without_a_gpu(lib):
     assert h.i2v_ff_fused_f16(C.byref(fp), None) == -1 and b"null pointer" in h.i2v_last_error()
     # (ABI 8) LayerNorm 1 + q | k | q_adapter + V^T in one launch
     assert h.i2v_ln_qkv_supported(131072, 320, 960, 4096) == 1 and h.i2v_ln_qkv_supported(131072, 320, 640, 4096) == 1
-    assert h.i2v_ln_qkv_supported(131072, 320, 320, 4096) == 0 and h.i2v_ln_qkv_supported(32768, 640, 1920, 1024) == 0
+    assert h.i2v_ln_qkv_supported(8192, 320, 320, 4096) == 1 and h.i2v_ln_qkv_supported(32768, 640, 1920, 1024) == 0      # (n_qk = C: the adapter's K0 | V0^T)
+    assert h.i2v_ln_qkv_supported(131072, 320, 1280, 4096) == 0
     assert h.i2v_ln_qkv_supported(131072, 320, 960, 4000) == 0 and h.i2v_ln_qkv_f16(None, None) == -1
     qp = lib.LnQkvParams()
     qp.rows, qp.channels, qp.n_qk, qp.rows_per_image = 256, 320, 960, 128

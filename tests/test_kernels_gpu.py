@@ -621,7 +621,7 @@ def test_layernorm_qkv_projection_fused(dev, n_img, L, adapter, strided, amp):
     k = K()
     c, eps = 320, 1e-5
     rows, n_qk = n_img * L, (3 if adapter else 2) * c
-    assert k.ln_qkv_supported(rows, c, n_qk, L) and not k.ln_qkv_supported(rows, 640, 3 * 640, L) and not k.ln_qkv_supported(rows, c, c, L)
+    assert k.ln_qkv_supported(rows, c, n_qk, L) and not k.ln_qkv_supported(rows, 640, 3 * 640, L) and not k.ln_qkv_supported(rows, c, 4 * c, L)
     assert not k.ln_qkv_supported(rows + 16, c, n_qk, L) and not k.ln_qkv_supported(rows, c, n_qk, L + 64)
     g = torch.Generator().manual_seed(rows + n_qk)
     ld = c + 64 if strided else c
@@ -646,6 +646,31 @@ def test_layernorm_qkv_projection_fused(dev, n_img, L, adapter, strided, amp):
     assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
     with pytest.raises(Exception, match="not a fused shape"):          # images of 64 rows: not whole 128-row tiles
         k.ln_qkv(xd, D(gamma).float(), D(beta).float(), wp, n_qk=n_qk, rows_per_image=64, eps=eps)
+
+
+@pytest.mark.parametrize("clips,frames,L", [(2, 4, 128), (3, 16, 256), (1, 2, 4096)])
+def test_layernorm_k0_v0t_of_the_frame0_rows_fused(dev, clips, frames, L):
+    """i2v_ln_qkv_f16 with n_qk = C and x_image_stride: LayerNorm 1 of the FRAME-0 rows of every clip (read in place from the
+    [clips x frames x L, C] token matrix), the adapter's K0 (row-major) and V0^T in one launch (i2v:484-492) -- against fp32 torch
+    and against the three launches it replaces (batched LayerNorm over the row blocks -> GEMM, project_vt)."""
+    k = K()
+    c, eps = 320, 1e-5
+    g = torch.Generator().manual_seed(clips * frames + L)
+    x = h(torch.randn(clips * frames * L, c, generator=g) * 1.3 + 0.4)
+    gamma, beta = h(1 + 0.2 * torch.randn(c, generator=g)), h(0.1 * torch.randn(c, generator=g))
+    w_k, w_v = h(torch.randn(c, c, generator=g) * c ** -0.5), h(torch.randn(c, c, generator=g) * c ** -0.5)
+    first = x.view(clips, frames * L, c)[:, :L].reshape(-1, c)
+    n = h(F.layer_norm(first, (c,), gamma, beta, eps))
+    D = lambda t: t.half().to(dev)
+    xd = D(x)
+    k0, v0t = k.ln_qkv(xd, D(gamma).float(), D(beta).float(), k.pack_ln_qkv(D(w_k), D(w_v)), n_qk=c, rows_per_image=L, eps=eps,
+                       images=clips, x_image_stride=frames * L * c)
+    assert tuple(k0.shape) == (clips * L, c) and tuple(v0t.shape) == (clips, c, L)
+    close(k0, n @ w_k.T, rel=3e-3, name="fused frame-0 LayerNorm + K0 vs fp32 torch")
+    close(v0t, (n @ w_v.T).view(clips, L, c).transpose(1, 2), rel=3e-3, name="fused frame-0 LayerNorm + V0^T vs fp32 torch")
+    nl = k.layernorm(xd.view(clips, frames * L, c)[:, :L], D(gamma), D(beta), eps).reshape(-1, c)
+    close(k0, k.gemm(nl, D(w_k)), rel=1e-3, name="fused K0 vs LayerNorm -> GEMM")
+    close(v0t, k.project_vt(nl, D(w_v), L), rel=1e-3, name="fused V0^T vs LayerNorm -> project_vt")
 
 
 @pytest.mark.parametrize("rows,strided", [(128, False), (128 * 300, True), (128 * 771, False)])
