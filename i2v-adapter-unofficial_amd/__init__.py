@@ -13,7 +13,7 @@ def __getattr__(name):
     # module classes are imported lazily so that `import i2v_adapter_unofficial_amd.kernels` stays light
     import importlib
     for mod in ("i2v_adapter", "unet_motion_cross_frame_attn", "pipeline_i2v_adapter", "blocks", "sharding", "vae",
-                "image_processor", "checkpoint"):
+                "image_processor", "checkpoint", "handle"):
         m = importlib.import_module(f"{__name__}.{mod}")
         if hasattr(m, name):
             return getattr(m, name)

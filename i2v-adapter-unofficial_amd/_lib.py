@@ -147,6 +147,24 @@ class LnQkvParams(C.Structure):
     ]
 
 
+class UnetConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32),
+        ("block_out_channels", C.c_int32 * 4),
+        ("layers_per_block", C.c_int32), ("num_attention_heads", C.c_int32),
+        ("cross_attention_dim", C.c_int32), ("norm_num_groups", C.c_int32),
+        ("motion_max_seq_length", C.c_int32), ("motion_num_attention_heads", C.c_int32),
+        ("use_motion_mid_block", C.c_int32), ("ip_num_tokens", C.c_int32),
+    ]
+
+
+class UnetPlan(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("frames", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("ctx_len", C.c_int32), ("has_ip", C.c_int32),
+    ]
+
+
 class GnParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("c1", C.c_int32),
@@ -240,6 +258,19 @@ SIGNATURES = {
     "i2v_select_row_f16": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P]),
     "i2v_ddim_cfg_step": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P, C.c_float, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, _P]),
+    # the model handle: configuration, weight registry, plan, one captured step
+    "i2v_unet_create": (C.c_int, [C.POINTER(UnetConfig), C.POINTER(_P)]),
+    "i2v_unet_destroy": (C.c_int, [_P]),
+    "i2v_unet_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "i2v_unet_get_weight": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int64)]),
+    "i2v_unet_num_weights": (C.c_int64, [_P]),
+    "i2v_unet_plan": (C.c_int, [_P, C.POINTER(UnetPlan)]),
+    "i2v_unet_activation_bytes": (C.c_int64, [_P]),
+    "i2v_unet_capture_step": (C.c_int, [_P, _P]),
+    "i2v_unet_end_capture": (C.c_int, [_P]),
+    "i2v_unet_replay_step": (C.c_int, [_P, _P]),
+    "i2v_unet_has_step": (C.c_int32, [_P]),
 }
 
 _lib = None

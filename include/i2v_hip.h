@@ -603,6 +603,55 @@ int i2v_adamw_guarded_f32(float* param, const float* grad, float* exp_avg, float
  * trained weights (`--use_ema`, :673-677, 888-889: a = decay, b = 1 - decay). */
 int i2v_axpby_f32(float* y, const float* x, float a, float b, int64_t n, i2v_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (ABI 8) Model handle: the thin whole-model layer of SURVEY 8(b) over the entry points above, for a host that is not this
+ * package's Python mirror (it serves the role of `self.unet = unet` + the hipGraph per DDIM step, pipe:96, 676-683).  The handle
+ * owns (a) the model's configuration, (b) a registry of the caller's weight buffers under their state-dict keys
+ * (`unet.state_dict()` names, SURVEY App. C: the library never copies or frees them), (c) the plan of one denoising step's
+ * problem and (d) ONE captured step: the host issues the step's launches -- the per-kernel entry points, in the order of
+ * unet:1289-1451 -- between i2v_unet_capture_step and i2v_unet_end_capture on its own stream, and replays them per timestep.
+ * What it deliberately does NOT contain is the layer sequencing itself (`i2v_unet_forward`): that is blocks.py + kernels.py of
+ * the host mirror, 2 200 lines that would buy no speed in C++.  Every buffer a captured launch touches must stay
+ * allocated, by the caller, until the handle is destroyed or a new step is captured.
+ * One handle per (device, stream); not thread-safe; no call synchronises the device except i2v_unet_destroy's release of the graph.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2v_unet i2v_unet;
+typedef struct i2v_unet_config {
+  int32_t in_channels, out_channels;                 /* 4, 4 (unet:701-702) */
+  int32_t block_out_channels[4];                     /* 320, 640, 1280, 1280 (unet:708) */
+  int32_t layers_per_block, num_attention_heads;     /* 2, 8 */
+  int32_t cross_attention_dim, norm_num_groups;      /* 768, 32 */
+  int32_t motion_max_seq_length, motion_num_attention_heads;   /* 32, 8 (unet:725-726) */
+  int32_t use_motion_mid_block, ip_num_tokens;       /* 1; 0 = no IP-Adapter, else 4 (unet:1284-1287) */
+} i2v_unet_config;
+typedef struct i2v_unet_plan_t {
+  int32_t batch, frames, height, width;              /* latent sizes: batch counts the CFG copies */
+  int32_t ctx_len, has_ip;
+} i2v_unet_plan_t;
+#define I2V_DTYPE_F16 0
+#define I2V_DTYPE_F32 1
+
+int i2v_unet_create(const i2v_unet_config* cfg, i2v_unet** out);
+int i2v_unet_destroy(i2v_unet* h);
+/* registers (or replaces) the caller's buffer for a state-dict key; ndim <= 4 */
+int i2v_unet_set_weight(i2v_unet* h, const char* key, const void* ptr, int32_t dtype, int32_t ndim, const int64_t* shape);
+/* the registered buffer of a key (0 and *ptr = NULL when absent); shape may be NULL */
+int i2v_unet_get_weight(const i2v_unet* h, const char* key, const void** ptr, int32_t* dtype, int32_t* ndim, int64_t* shape);
+int64_t i2v_unet_num_weights(const i2v_unet* h);
+/* validates and records the step's problem: frames <= motion_max_seq_length (unet:725), even latent sizes at every level
+ * (height, width multiples of 8: pipe:213-214 in latent units), ctx_len >= 1; a new plan drops the captured step */
+int i2v_unet_plan(i2v_unet* h, const i2v_unet_plan_t* plan);
+/* fp16 bytes of the largest activation of the planned step (batch x frames x height x width x 320 channels at the first
+ * level): what a host sizes its ping-pong buffers with */
+int64_t i2v_unet_activation_bytes(const i2v_unet* h);
+/* begin / end the capture of one step on `stream` (hipStreamBeginCapture, relaxed mode): everything launched on the stream in
+ * between becomes the handle's step */
+int i2v_unet_capture_step(i2v_unet* h, i2v_stream_t stream);
+int i2v_unet_end_capture(i2v_unet* h);
+/* launch the captured step once (asynchronous on `stream`); I2V_ERR_INVALID_ARG when nothing has been captured */
+int i2v_unet_replay_step(i2v_unet* h, i2v_stream_t stream);
+int32_t i2v_unet_has_step(const i2v_unet* h);
+
 #ifdef __cplusplus
 }
 #endif

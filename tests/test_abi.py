@@ -110,3 +110,36 @@ def test_missing_library_fails_loudly(lib, monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libi2v_hip.so")
     with pytest.raises(lib.HipLibraryError, match="no CPU fallback"):
         lib.load()
+
+
+def test_model_handle_registry_and_plan_without_a_gpu(lib):
+    """the model handle of SURVEY 8(b) (include/i2v_hip.h "Model handle"): create / set_weight / get_weight / plan / destroy and
+    their error codes work on the host alone; capture and replay need a stream (tests/test_kernels_gpu.py)."""
+    h = lib.load()
+    cfg = lib.UnetConfig(4, 4, (C.c_int32 * 4)(320, 640, 1280, 1280), 2, 8, 768, 32, 32, 8, 1, 0)
+    hd = C.c_void_p()
+    assert h.i2v_unet_create(C.byref(cfg), C.byref(hd)) == 0 and hd.value
+    assert h.i2v_unet_create(None, C.byref(hd)) == -1 and b"null argument" in h.i2v_last_error()
+    bad = lib.UnetConfig(4, 4, (C.c_int32 * 4)(320, 650, 1280, 1280), 2, 8, 768, 32, 32, 8, 1, 0)
+    other = C.c_void_p()
+    assert h.i2v_unet_create(C.byref(bad), C.byref(other)) == -1 and b"block_out_channels[1]" in h.i2v_last_error()
+    buf = (C.c_uint16 * (320 * 4 * 9))()
+    shape = (C.c_int64 * 4)(320, 4, 3, 3)
+    assert h.i2v_unet_set_weight(hd, b"conv_in.weight", C.addressof(buf), 0, 4, shape) == 0
+    assert h.i2v_unet_set_weight(hd, b"conv_in.weight", C.addressof(buf), 7, 4, shape) == -1 and b"dtype" in h.i2v_last_error()
+    assert h.i2v_unet_set_weight(hd, b"", C.addressof(buf), 0, 4, shape) == -1
+    assert h.i2v_unet_num_weights(hd) == 1
+    p, dt, nd, shp = C.c_void_p(), C.c_int32(-1), C.c_int32(-1), (C.c_int64 * 4)()
+    assert h.i2v_unet_get_weight(hd, b"conv_in.weight", C.byref(p), C.byref(dt), C.byref(nd), shp) == 0
+    assert p.value == C.addressof(buf) and dt.value == 0 and nd.value == 4 and list(shp) == [320, 4, 3, 3]
+    assert h.i2v_unet_get_weight(hd, b"nope", C.byref(p), None, None, None) == 0 and p.value is None
+    # the plan: frames within the positional table (unet:725), latent sizes that halve exactly three times (pipe:213-214)
+    assert h.i2v_unet_activation_bytes(hd) == 0 and h.i2v_unet_has_step(hd) == 0
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 77, 0))) == 0
+    assert h.i2v_unet_activation_bytes(hd) == 2 * 16 * 64 * 64 * 320 * 2
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 33, 64, 64, 77, 0))) == -1 and b"positional table" in h.i2v_last_error()
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 60, 64, 77, 0))) == -1 and b"multiples of 8" in h.i2v_last_error()
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 81, 1))) == -1 and b"image tokens" in h.i2v_last_error()
+    assert h.i2v_unet_replay_step(hd, None) == -1 and b"no captured step" in h.i2v_last_error()
+    assert h.i2v_unet_end_capture(hd) == -1 and h.i2v_unet_capture_step(hd, None) == -1
+    assert h.i2v_unet_destroy(hd) == 0 and h.i2v_unet_destroy(None) == 0
