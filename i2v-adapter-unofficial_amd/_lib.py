@@ -100,6 +100,7 @@ class MotionAttnParams(C.Structure):
         ("rows", C.c_int64),
         ("channels", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("frames", C.c_int32),
         ("eps", C.c_float), ("scale", C.c_float),
+        ("w_o", C.c_void_p), ("b_o", C.c_void_p),
     ]
 
 
@@ -114,6 +115,7 @@ class CrossAttnFusedParams(C.Structure):
         ("channels", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("ctx_len", C.c_int32),
         ("eps", C.c_float), ("scale", C.c_float),
         ("ip_frag", C.c_void_p), ("ip_len", C.c_int32), ("ip_scale", C.c_float),
+        ("w_o", C.c_void_p), ("b_o", C.c_void_p),
     ]
 
 

@@ -657,6 +657,9 @@ class SinusoidalPositionalEmbedding(nn.Module):
 FUSED_MOTION_ATTN = os.environ.get("I2V_MOTION_FUSED", "1") != "0"
 FUSED_FF = os.environ.get("I2V_FF_FUSED", "1") != "0"
 FUSED_FF_TAIL = os.environ.get("I2V_FF_TAIL", "1") != "0"       # proj_out (+ residual, row order) inside the fused feed-forward
+# to_out (+ residual) inside the fused attention launches (r5: the fourth pass costs nearly what the HBM-bound GEMM it replaces
+# does -- same-box -0.1 .. -0.3 ms per step on every configuration, profiles/r5_attn_outproj.txt)
+FUSED_ATTN_OUT = os.environ.get("I2V_ATTN_OUTP", "1") != "0"
 
 
 class TemporalTransformerBlock(HipModule):
@@ -707,6 +710,7 @@ class TemporalTransformerBlock(HipModule):
         # fp32 LayerNorm constants: built on first use (LazyPack)
         for i, attn in enumerate((self.attn1, self.attn2), 1):
             p.lazy(f"wqkv{i}", lambda attn=attn: K.pack_motion_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, self.heads))
+            p.lazy(f"wo_frag{i}", lambda attn=attn: K.pack_attn_out(attn.to_out[0].weight, attn.to_out[0].bias, self.heads))
         self._ma_tables = {}          # (site, frames) -> (gamma fp32, beta + pe[frame] fp32), made on first use
         p.lazy("g3_f32", lambda: self.norm3.weight.detach().float().contiguous())
         p.lazy("b3_f32", lambda: self.norm3.bias.detach().float().contiguous())
@@ -746,6 +750,10 @@ class TemporalTransformerBlock(HipModule):
                 tab = self._ma_tables.get((i, frames))
                 if tab is None:
                     tab = self._ma_tables[(i, frames)] = K.motion_attn_tables(p[f"g{i}"], p[f"b{i}"], p["pe"], frames)
+                if FUSED_ATTN_OUT:
+                    t = K.motion_attn(t, tab[0], tab[1], p[f"wqkv{i}"], heads=self.heads, head_dim=self.dim_head, frames=frames,
+                                      eps=self.eps, out_proj=p[f"wo_frag{i}"])
+                    continue
                 o = K.motion_attn(t, tab[0], tab[1], p[f"wqkv{i}"], heads=self.heads, head_dim=self.dim_head, frames=frames,
                                   eps=self.eps)
                 t = K.gemm(o, p[f"wo{i}"], p[f"bo{i}"], residual=t)

@@ -71,6 +71,8 @@ struct ma_args {
   int32_t lt; int32_t tiles_per_ctx;
   // CROSS, optional: the IP-Adapter's image tokens of the same rows' context (a second softmax, added with its own weight)
   const void* ip_frag; int32_t ip_len; float ip_scale;
+  // OUTP: the out-projection that follows (to_out[0]: weight fragments in the order of the q part, fp32 bias); out = x + o Wo^T + bo
+  const void* w_o; const void* b_o;
 };
 
 constexpr int MA_KT = 5;               // CROSS: key tiles of 16 (<= 80 context tokens: the 77 of CLIP)
@@ -82,7 +84,11 @@ constexpr int MA_KT = 5;               // CROSS: key tiles of 16 (<= 80 context 
 // F (motion form): frames per pixel -- 16: a 16-row MFMA tile IS one pixel's sequence; 8: a tile holds two pixels and the scores
 //   between them are masked; 32: a pixel is two tiles, its scores four 16 x 16 blocks (r5: the 8-frame / 256^2 and the 32-frame /
 //   768^2 configurations took the un-fused chain)
-template <int C, int D, int H, bool CROSS, int F = 16>
+// OUTP (r5): the sub-block's out-projection and residual in the same launch, out = x + o Wo^T + bo -- the heads'
+//   outputs meet in the tile's panel once every wave has left it (barrier), a fourth pass projects them (wave w: output channels
+//   40 w .. + 39), the residual rows are requested while the attention runs and are the accumulators' initial values.  o never
+//   goes to memory (84 MB each way at the 64^2 level) and the HBM-bound 131072 x 320 x 320 + residual GEMM launch disappears.
+template <int C, int D, int H, bool CROSS, int F = 16, bool OUTP = false>
 __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, const float scale_log2, const int ntiles,
                                                              long long* __restrict__ stamps) {
   constexpr int DT = (D + 15) / 16, DP = 16 * DT, KS = C / 32, NJ = C / 64, PARTS = CROSS ? 1 : 3;
@@ -185,22 +191,27 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
   //  and an immediate instead of one hoisted register per K step)
   const int swz[2] = {(g ^ sw) * 8, ((4 + g) ^ sw) * 8};
   f32x4 acc[MA_PIX][DT];
-  auto project = [&](const f16* panel, const int part, auto transposed) {
+  auto zero_init = [](const int, const int) { return f32x4{0.f, 0.f, 0.f, 0.f}; };
+  // (wp: byte offset of the wave's fragments of this pass in `rs`; (DP C = KS DT 512 halfs per part) + (s DT + t) 1024)
+  auto no_hook = []() {};
+  auto project = [&](const f16* panel, const __amdgpu_buffer_rsrc_t rs, const int wp, auto transposed, auto init, auto hook) {
     constexpr bool TR = decltype(transposed)::value;
-    const int wp = w_wave + part * (DP * C * 2);          // bytes; (DP C = KS DT 512 halfs per part) + (s DT + t) 1024
     auto ldw = [&](const int s, const int t) {
-      return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, wp + (s * DT + t) * 1024, 0));
+      return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, w_lane, wp + (s * DT + t) * 1024, 0));
     };
     const f16* alane = panel + l15 * C;                  // + (16 pix) C + (((4 s + g) ^ (l15 & 7)) * 8)
     f16x8 wf[MA_PD][DT];
 #pragma unroll
     for (int pix = 0; pix < MA_PIX; ++pix)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) acc[pix][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < DT; ++t) acc[pix][t] = init(pix, t);
 #pragma unroll
     for (int s = 0; s < MA_PD - 1; ++s)
 #pragma unroll
       for (int t = 0; t < DT; ++t) wf[s][t] = ldw(s, t);
+    // (r5: without this fence the scheduler may pair each of these loads with the first MFMA that takes it -- load, s_waitcnt vmcnt(0),
+    //  MFMA, three L2 round trips in series at the top of the pass: seen in the v pass of the OUTP form)
+    __builtin_amdgcn_sched_barrier(0);
     constexpr int AD = MA_AD, NI = KS * MA_PIX;
     auto lda = [&](const int i) {
       return *reinterpret_cast<const f16x8*>(alane + 16 * (i % MA_PIX) * C + 64 * ((i / MA_PIX) >> 1) + swz[(i / MA_PIX) & 1]);
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
 #pragma unroll
         for (int t = 0; t < DT; ++t) wf[(s + MA_PD - 1) % MA_PD][t] = ldw(s + MA_PD - 1, t);
       }
+      if (i == 0) hook();       // (memory requests that may return behind the first MA_PD K steps' fragments)
       if (i + AD < NI) af[(i + AD) % (AD + 1)] = lda(i + AD);
 #pragma unroll
       for (int t = 0; t < DT; ++t)
@@ -244,6 +256,59 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
     }
   };
 
+  // ---- OUTP: the tile's o into the panel (every wave its head's D channels of all rows, at the panel's swizzled places; lane (g, l15)
+  // holds channels 16 t + 4 g .. + 3 of row l15: one 8-byte write per tile), then the fourth pass: out^T[channel][row] = Wo (A operand,
+  // the wave's 40 output channels in the fragment order of the q part) x o^T (B operand from the panel), accumulators starting from
+  // the bias, the residual added at the end.
+  static_assert(D % 8 == 0, "a head's channels are whole 16-byte chunks of a panel row");
+  auto stash_o = [&](f16* pw, const int pix, const u32x2 (&oh)[DT]) {
+    const int ln = ma_opaque(lane), g2 = ln >> 4, r15 = ln & 15;
+    f16* dst = pw + (16 * pix + r15) * C + 4 * (g2 & 1);
+#pragma unroll
+    for (int t = 0; t < DT; ++t)        // (the padding channels D .. DP of the last tile belong to the next head)
+      if (16 * t + 4 * g2 < D) *reinterpret_cast<u32x2*>(dst + (((wave * (D / 8) + 2 * t + (g2 >> 1)) ^ (r15 & 7)) * 8)) = oh[t];
+  };
+  auto out_project = [&](const f16* pr, const int tile) {
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_o), 0, H * DP * C * 2, 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.b_o), 0, C * 4, 0x00020000);
+    const f16* base = X + (int64_t)tile * (MA_PIX * MA_F) * p.ldx;                      // (wave-uniform)
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)(((MA_PIX * MA_F - 1) * p.ldx + C) * 2), 0x00020000);
+    const int ln = ma_opaque(lane), sg = ln >> 4, sl15 = ln & 15;
+    f32x4 bo[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+      bo[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rs_b, 16 * t + 4 * sg < D ? (unsigned)((wave * D + 16 * t + 4 * sg) * 4) : 0x80000000u, 0, 0));
+    // the residual: this lane's slice of its rows (8 bytes per row and tile), requested BEHIND the pass's first weight fragments
+    // (loads return in order: in front of them the pass would start with an HBM round trip) and added to the finished accumulators
+    u32x2 res[MA_PIX][DT];
+    project(pr, rs_o, wave * (DP * C * 2), std::true_type{}, [&](const int, const int t) { return bo[t]; }, [&]() {
+#pragma unroll
+      for (int pix = 0; pix < MA_PIX; ++pix)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+#ifdef I2V_MA_NORES
+          res[pix][t] = u32x2{0u, 0u};
+#else
+          const unsigned voff = 16 * t + 4 * sg < D ? (unsigned)((((16 * pix + sl15) * p.ldx) + wave * D + 16 * t + 4 * sg) * 2) : 0x80000000u;
+          res[pix][t] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff, 0, 0));
+#endif
+        }
+    });
+    f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
+#pragma unroll
+    for (int pix = 0; pix < MA_PIX; ++pix) {
+      u32x2 oh[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const f16x4 r = __builtin_bit_cast(f16x4, res[pix][t]);
+        const f32x4 v = {acc[pix][t][0] + (float)r[0], acc[pix][t][1] + (float)r[1], acc[pix][t][2] + (float)r[2], acc[pix][t][3] + (float)r[3]};
+        oh[t] = __builtin_bit_cast(u32x2, to_half(v));
+      }
+      store_tiles(O + (int64_t)(16 * pix + sl15) * p.ldo, sg, oh);
+    }
+  };
+
   int tile = blockIdx.x;
   if (tile >= ntiles) return;        // (workgroup-uniform)
   MA_STAMP(0);
@@ -253,7 +318,7 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
   MA_STAMP(1);
   lds_barrier();
   for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-    const f16* panel = panels + (it & 1) * (MA_PIX * MA_F * C);
+    f16* panel = panels + (it & 1) * (MA_PIX * MA_F * C);
     const int next = tile + (int)gridDim.x;
     // (the other panel was last read in the previous iteration, which every wave has left through the barrier at its end)
     f16* other = panels + ((it + 1) & 1) * (MA_PIX * MA_F * C);
@@ -265,13 +330,14 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
 
     // q^T [channel][frame]
     f16x4 qh[MA_PIX][DT];
-    project(panel, 0, std::true_type{});
+    project(panel, rs_w, w_wave, std::true_type{}, zero_init, no_hook);
     // (CROSS: softmax scale * log2 e goes into the fp16 q, as in i2v_attention_f16 -- 24 multiplies per tile instead of 160)
 #pragma unroll
     for (int pix = 0; pix < MA_PIX; ++pix)
 #pragma unroll
       for (int t = 0; t < DT; ++t) qh[pix][t] = to_half(CROSS ? acc[pix][t] * scale_log2 : acc[pix][t]);
     MA_STAMP(3);
+    if constexpr (CROSS && OUTP) lds_barrier();      // the q pass was the panel's last reader: every wave has left it
 
     if constexpr (CROSS) {
       // ---- cross-attention against the resident context: key fragments K[key][channel] (A operand of S^T) and value
@@ -372,16 +438,23 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
         u32x2 oh[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) oh[t] = __builtin_bit_cast(u32x2, to_half(ov[t]));
-        store_tiles(O + (int64_t)(16 * pix + sl15) * p.ldo, sg, oh);
+        if constexpr (OUTP)
+          stash_o(panel, pix, oh);
+        else
+          store_tiles(O + (int64_t)(16 * pix + sl15) * p.ldo, sg, oh);
       }
       MA_STAMP(6);
       if (next < ntiles) normalise_rows(other);
+      if constexpr (OUTP) {
+        lds_barrier();                               // o of every head is in the panel
+        out_project(panel, tile);
+      }
     } else {
     // k^T, then S^T[key][query] and the softmax over the keys.  NB = 16-row tiles per pixel (F = 32: two -- the keys of a query
     // are the 8 accumulator rows of two score blocks and the 4 lane groups); ph[key tile][query tile of the same pixel]
     constexpr int NB = F == 32 ? 2 : 1;
     f16x4 ph[MA_PIX][NB];
-    project(panel, 1, std::true_type{});
+    project(panel, rs_w, w_wave + DP * C * 2, std::true_type{}, zero_init, no_hook);
 #pragma unroll
     for (int px = 0; px < MA_PIX; px += NB) {
 #pragma unroll
@@ -425,8 +498,9 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
     __builtin_amdgcn_sched_barrier(0);
 
     // v [key][channel], O^T[channel][query], stored as o[query row][head channels]
-    project(panel, 2, std::false_type{});
+    project(panel, rs_w, w_wave + 2 * (DP * C * 2), std::false_type{}, zero_init, no_hook);
     MA_STAMP(5);
+    if constexpr (OUTP) lds_barrier();               // the v pass was the panel's last reader: every wave has left it
     f16* __restrict__ O = reinterpret_cast<f16*>(p.out) + (int64_t)tile * (MA_PIX * MA_F) * p.ldo + wave * D;
     const int sln = ma_opaque(lane), sg = sln >> 4, sl15 = sln & 15;
 #pragma unroll
@@ -441,10 +515,17 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
           for (int ik = 0; ik < NB; ++ik) o = mfma16x16x16(to_half(acc[px + ik][t]), ph[px + ik][jq], o);
           oh[t] = __builtin_bit_cast(u32x2, to_half(o));
         }
-        store_tiles(O + (int64_t)(16 * (px + jq) + sl15) * p.ldo, sg, oh);
+        if constexpr (OUTP)
+          stash_o(panel, px + jq, oh);
+        else
+          store_tiles(O + (int64_t)(16 * (px + jq) + sl15) * p.ldo, sg, oh);
       }
     MA_STAMP(6);
     if (next < ntiles) normalise_rows(other);
+    if constexpr (OUTP) {
+      lds_barrier();                                 // o of every head is in the panel
+      out_project(panel, tile);
+    }
     }
     MA_STAMP(7);
 #ifdef I2V_MA_STAMPS
@@ -459,15 +540,15 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
 #undef MA_STAMP
 }
 
-template <int C, int D, int H, bool CROSS, int F = 16>
+template <int C, int D, int H, bool CROSS, int F = 16, bool OUTP = false>
 int ma_cus() {       // CUs of the current device once it has granted this kernel its two panels of LDS; 0: refused (runtime.hip)
-  return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H, CROSS, F>), 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16));
+  return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(motion_attn_kernel<C, D, H, CROSS, F, OUTP>), 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16));
 }
 
-template <int C, int D, int H, bool CROSS, int F = 16>
+template <int C, int D, int H, bool CROSS, int F = 16, bool OUTP = false>
 int launch_ma(const ma_args& p, int64_t rows, float scale, hipStream_t s, const char* what) {
   const size_t lds = 2 * (size_t)MA_PIX * MA_F * C * sizeof(f16);
-  const int cus = ma_cus<C, D, H, CROSS, F>();
+  const int cus = ma_cus<C, D, H, CROSS, F, OUTP>();
   if (cus <= 0) I2V_FAIL(I2V_ERR_UNSUPPORTED, "%s: %zu bytes of LDS refused by this device", what, lds);
   const int ntiles = (int)(rows / (MA_PIX * MA_F));
   // one workgroup per CU (160 KB of LDS each), every workgroup the same number of tiles where the count allows it
@@ -476,7 +557,7 @@ int launch_ma(const ma_args& p, int64_t rows, float scale, hipStream_t s, const 
 #ifdef I2V_MA_STAMPS
   stamps = getenv("I2V_MA_STAMP_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("I2V_MA_STAMP_PTR"), nullptr, 0)) : nullptr;
 #endif
-  hipLaunchKernelGGL((motion_attn_kernel<C, D, H, CROSS, F>), dim3((unsigned)grid), dim3(64 * H), lds, s, p, scale * 1.4426950408889634f,
+  hipLaunchKernelGGL((motion_attn_kernel<C, D, H, CROSS, F, OUTP>), dim3((unsigned)grid), dim3(64 * H), lds, s, p, scale * 1.4426950408889634f,
                      ntiles, stamps);
   return i2v_check_launch(what);
 }
@@ -508,7 +589,15 @@ extern "C" int i2v_motion_attn_f16(const i2v_motion_attn_params* pp, i2v_stream_
   ma_args a = {};
   a.x = p.x; a.ldx = p.ldx; a.gamma = p.gamma; a.shift = p.shift; a.ld_shift = p.ld_shift; a.w = p.w_qkv; a.out = p.out;
   a.ldo = p.ldo; a.eps = p.eps;
+  I2V_CHECK_ARG((p.w_o == nullptr) == (p.b_o == nullptr) && al16(p.w_o) && al16(p.b_o),
+                "i2v_motion_attn_f16: w_o and b_o come together, 16-byte aligned");
+  a.w_o = p.w_o; a.b_o = p.b_o;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.w_o != nullptr) {
+    if (p.frames == 8) return launch_ma<320, 40, 8, false, 8, true>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
+    if (p.frames == 32) return launch_ma<320, 40, 8, false, 32, true>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
+    return launch_ma<320, 40, 8, false, 16, true>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
+  }
   if (p.frames == 8) return launch_ma<320, 40, 8, false, 8>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
   if (p.frames == 32) return launch_ma<320, 40, 8, false, 32>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
   return launch_ma<320, 40, 8, false, 16>(a, p.rows, p.scale, s, "i2v_motion_attn_f16");
@@ -546,5 +635,10 @@ extern "C" int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* pp, i
   a.ctx_frag = p.ctx_frag; a.lt = p.ctx_len;
   a.ip_frag = p.ip_frag; a.ip_len = p.ip_frag ? p.ip_len : 0; a.ip_scale = p.ip_scale;
   a.tiles_per_ctx = (int32_t)(p.rows_per_ctx / (MA_PIX * MA_F));
+  I2V_CHECK_ARG((p.w_o == nullptr) == (p.b_o == nullptr) && al16(p.w_o) && al16(p.b_o),
+                "i2v_cross_attn_fused_f16: w_o and b_o come together, 16-byte aligned");
+  a.w_o = p.w_o; a.b_o = p.b_o;
+  if (p.w_o != nullptr)
+    return launch_ma<320, 40, 8, true, 16, true>(a, p.rows, p.scale, reinterpret_cast<hipStream_t>(stream), "i2v_cross_attn_fused_f16");
   return launch_ma<320, 40, 8, true>(a, p.rows, p.scale, reinterpret_cast<hipStream_t>(stream), "i2v_cross_attn_fused_f16");
 }

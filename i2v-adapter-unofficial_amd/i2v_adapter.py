@@ -71,6 +71,7 @@ class I2VAdapterModule(PretrainedMixin, nn.Module):
 
 
 FUSED_TEXT_ATTN = os.environ.get("I2V_TEXT_FUSED", "1") != "0"
+FUSED_ATTN_OUT = os.environ.get("I2V_ATTN_OUTP", "1") != "0"     # to_out + residual inside that launch (as blocks.FUSED_ATTN_OUT)
 FUSED_LN_QKV = os.environ.get("I2V_QKV_FUSED", "1") != "0"       # LayerNorm 1 + q | k | q_adapter + V^T projection in one launch
 
 
@@ -131,6 +132,7 @@ class I2VAdapterTransformerBlock(HipModule):
             p["f_q2"] = fold_layernorm(self.attn2.to_q.weight, None, self.norm2.weight, self.norm2.bias)
             # the fused LayerNorm + to_q + text cross-attention kernel's operands (64^2 level of SD-1.5): built on first use
             p.lazy("wq2_frag", lambda: K.pack_cross_q(self.attn2.to_q.weight, self.heads))
+            p.lazy("wo2_frag", lambda: K.pack_attn_out(self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, self.heads))
             p.lazy("g2_f32", lambda: self.norm2.weight.detach().float().contiguous())
             p.lazy("b2_f32", lambda: self.norm2.bias.detach().float().contiguous())
         # LayerNorm folded into the consuming projections (i2v:444-445 -> q | k | q_adapter and V^T; i2v:510 -> attn2.to_q;
@@ -259,13 +261,16 @@ class I2VAdapterTransformerBlock(HipModule):
             kv = self.attn2.context_kv(ctx_text, ctx_ip)
             _k, _vt, kip, _vtip, lt, li = kv
             use_ip = kip is not None and bool(self.attn2.ip_num_tokens)
+            fused_out2 = False
             if FUSED_TEXT_ATTN and (not use_ip or li <= 16) and \
                     K.cross_attn_fused_supported(x.shape[0], c, self.heads, self.dim_head, lt, kv_group * L):
                 # LayerNorm 2, to_q and the attention over the <= 80 context tokens (+ the IP-Adapter's image tokens) in one launch
                 frag, frag_ip = self.attn2.context_fragments(ctx_text, kv)
                 o = K.cross_attn_fused(x, p["g2_f32"], p["b2_f32"], p["wq2_frag"], frag, heads=self.heads, head_dim=self.dim_head,
                                        ctx_len=lt, rows_per_ctx=kv_group * L, eps=self.eps, scale=self.attn2.scale,
-                                       ip_frag=frag_ip, ip_len=li if use_ip else 0, ip_scale=float(self.attn2.ip_scale))
+                                       ip_frag=frag_ip, ip_len=li if use_ip else 0, ip_scale=float(self.attn2.ip_scale),
+                                       out_proj=p["wo2_frag"] if FUSED_ATTN_OUT else None)
+                fused_out2 = FUSED_ATTN_OUT
             else:
                 if fold2:
                     wf, ws, cb = p["f_q2"]
@@ -274,7 +279,10 @@ class I2VAdapterTransformerBlock(HipModule):
                     n = K.layernorm(x, p["g2"], p["b2"], self.eps)
                     q = K.gemm(n, p["w_q2"])
                 o = self.attn2._cross(q, ctx_text, ctx_ip, n_img, L, kv_group, kv=kv)
-            x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
+            if fused_out2:
+                x = o
+            else:
+                x = K.gemm(o, p["w_o2"], p["b_o2"], residual=x)
         def ret(v, applied=False):
             return v if tail is None else (v, applied)
         if self.ff.fused_supported(x):

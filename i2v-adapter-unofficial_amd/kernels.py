@@ -397,8 +397,24 @@ def pack_ctx_fragments(k, vt, heads, ctx_len, out=None):
     return out
 
 
+def pack_attn_out(w_o, b_o, heads):
+    """(w_o fragments, b_o fp32) of the out-projection inside i2v_motion_attn_f16 / i2v_cross_attn_fused_f16: to_out[0].weight's
+    rows per head-sized slice in fragment order (the layout of `pack_cross_q`), the bias in fp32."""
+    return pack_cross_q(w_o, heads), b_o.detach().float().contiguous()
+
+
+def _attn_out_operands(out_proj, c, heads, head_dim, what):
+    w_o, b_o = out_proj
+    _req(w_o, "w_o")
+    _req(b_o, "b_o", dtype=torch.float32)
+    if tuple(w_o.shape) != (_lib.load().i2v_cross_attn_fused_pack_rows(heads, head_dim), c) or not w_o.is_contiguous() or \
+            b_o.numel() != c or not b_o.is_contiguous():
+        raise ValueError(f"{what}: out_proj is {tuple(w_o.shape)} / {tuple(b_o.shape)} (pack_attn_out)")
+    return _p(w_o), _p(b_o)
+
+
 def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_len, rows_per_ctx, eps, scale=None, out=None,
-                     ip_frag=None, ip_len=0, ip_scale=1.0):
+                     ip_frag=None, ip_len=0, ip_scale=1.0, out_proj=None):
     """o = softmax((LayerNorm(x) Wq^T) K^T) V against a short context (i2v_cross_attn_fused_f16): x [rows, C]; ctx_frag from
     `pack_ctx_fragments`; rows [i * rows_per_ctx, (i + 1) * rows_per_ctx) use context i.  ip_frag (+ ip_len <= 16, ip_scale):
     the IP-Adapter's image tokens packed the same way; their softmax is added with weight ip_scale."""
@@ -433,6 +449,8 @@ def cross_attn_fused(x, gamma32, beta32, w_q, ctx_frag, *, heads, head_dim, ctx_
         if not ip_frag.is_contiguous() or ip_frag.numel() != ctx_frag.numel():
             raise ValueError(f"cross_attn_fused: ip_frag is {tuple(ip_frag.shape)} (pack_ctx_fragments of the image tokens)")
         p.ip_frag, p.ip_len, p.ip_scale = _p(ip_frag), int(ip_len), float(ip_scale)
+    if out_proj is not None:      # out = x + o Wo^T + bo in the same launch (`pack_attn_out`)
+        p.w_o, p.b_o = _attn_out_operands(out_proj, c, heads, head_dim, "cross_attn_fused")
     _lib.check(lib.i2v_cross_attn_fused_f16(C.byref(p), _stream()), "i2v_cross_attn_fused_f16")
     return out
 
@@ -577,7 +595,7 @@ def motion_attn_tables(gamma, beta, pe, frames):
             (beta.detach().float()[None, :] + pe.detach().float()[:frames]).contiguous())
 
 
-def motion_attn(x, gamma32, shift32, w_qkv, *, heads, head_dim, frames, eps, scale=None, out=None):
+def motion_attn(x, gamma32, shift32, w_qkv, *, heads, head_dim, frames, eps, scale=None, out=None, out_proj=None):
     """o = temporal attention over the `frames` rows of each pixel of LayerNorm(x) + pe, q / k / v projected inside
     (i2v_motion_attn_f16); x [rows, C] in (batch, pixel, frame) order, (gamma32, shift32) from `motion_attn_tables`,
     w_qkv from `pack_motion_qkv`."""
@@ -605,6 +623,8 @@ def motion_attn(x, gamma32, shift32, w_qkv, *, heads, head_dim, frames, eps, sca
     p.out, p.ldo = _p(out), ldo
     p.rows, p.channels, p.heads, p.head_dim, p.frames = rows, c, heads, head_dim, frames
     p.eps, p.scale = float(eps), float(head_dim) ** -0.5 if scale is None else float(scale)
+    if out_proj is not None:      # out = x + o Wo^T + bo in the same launch (`pack_attn_out`)
+        p.w_o, p.b_o = _attn_out_operands(out_proj, c, heads, head_dim, "motion_attn")
     _lib.check(lib.i2v_motion_attn_f16(C.byref(p), _stream()), "i2v_motion_attn_f16")
     return out
 

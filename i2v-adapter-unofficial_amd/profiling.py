@@ -52,15 +52,19 @@ def _work_tattn(args, kw, out):
 def _work_mattn(args, kw, out):
     x, w = args[0], args[3]
     rows, c = x.shape
-    return ("motion_attn", 2.0 * rows * c * 3 * c + 4.0 * rows * kw["frames"] * c, _numel_bytes(x, w, out),
-            f"{rows}x{c} F{kw['frames']} h{kw['heads']} d{kw['head_dim']} (LN + q,k,v + attention)")
+    op = kw.get("out_proj")          # + to_out and the residual (x is read a second time) in the same launch
+    return ("motion_attn", 2.0 * rows * c * (4 if op else 3) * c + 4.0 * rows * kw["frames"] * c,
+            _numel_bytes(x, w, out) + (_numel_bytes(x, op[0]) if op else 0),
+            f"{rows}x{c} F{kw['frames']} h{kw['heads']} d{kw['head_dim']} (LN + q,k,v + attention" + (" + to_out + residual)" if op else ")"))
 
 
 def _work_cattn(args, kw, out):
     x, w = args[0], args[3]
     rows, c = x.shape
-    return ("cross_attn_fused", 2.0 * rows * c * c + 4.0 * rows * kw["ctx_len"] * c, _numel_bytes(x, w, args[4], out),
-            f"{rows}x{c} Lk{kw['ctx_len']} h{kw['heads']} d{kw['head_dim']} (LN + q + text attention)")
+    op = kw.get("out_proj")
+    return ("cross_attn_fused", 2.0 * rows * c * (2 if op else 1) * c + 4.0 * rows * kw["ctx_len"] * c,
+            _numel_bytes(x, w, args[4], out) + (_numel_bytes(x, op[0]) if op else 0),
+            f"{rows}x{c} Lk{kw['ctx_len']} h{kw['heads']} d{kw['head_dim']} (LN + q + text attention" + (" + to_out + residual)" if op else ")"))
 
 
 def _work_ff(args, kw, out):

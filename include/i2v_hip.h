@@ -223,6 +223,11 @@ typedef struct i2v_motion_attn_params {
   int64_t rows;
   int32_t channels, heads, head_dim, frames;
   float eps, scale;
+  /* (ABI 8) optional, both or neither: the sub-block's out-projection and residual in the same launch --
+   * out = x + o to_out[0].weight^T + to_out[0].bias (what the caller otherwise does with i2v_gemm_f16 + residual).
+   * w_o: to_out[0].weight [channels, channels] in the fragment order of i2v_cross_attn_fused_f16's w_q (rows grouped per head-sized
+   * slice); b_o: fp32 [channels].  out may be x. */
+  const void* w_o; const void* b_o;
 } i2v_motion_attn_params;
 
 int32_t i2v_motion_attn_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t frames);
@@ -258,6 +263,8 @@ typedef struct i2v_cross_attn_fused_params {
   int32_t channels, heads, head_dim, ctx_len;
   float eps, scale;
   const void* ip_frag; int32_t ip_len; float ip_scale;
+  /* (ABI 8) optional, both or neither: out = x + o to_out[0].weight^T + to_out[0].bias in the same launch (as i2v_motion_attn_params) */
+  const void* w_o; const void* b_o;
 } i2v_cross_attn_fused_params;
 
 int32_t i2v_cross_attn_fused_supported(int64_t rows, int32_t channels, int32_t heads, int32_t head_dim, int32_t ctx_len,

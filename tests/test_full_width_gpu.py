@@ -148,6 +148,17 @@ def test_full_width_transformer_2d(dev, c, hw, frames):
         compare(plain, ref, rel=MODULE_REL_TOL, name=f"full-width T2D, un-fused text attention C={c}")
         compare(got, plain, rel=MODULE_REL_TOL, name=f"T2D fused vs un-fused text attention C={c}")
         assert not torch.equal(got, plain)
+        # ... and with to_out + residual as a GEMM launch behind the fused attention (I2V_ATTN_OUTP=0)
+        assert mod.FUSED_ATTN_OUT
+        mod.FUSED_ATTN_OUT = False
+        try:
+            with torch.no_grad():
+                pair = m(x.half().to(dev), enable_cross_frame_attn=True, num_frames=frames,
+                         encoder_hidden_states=ctx.half().to(dev), return_dict=False)[0]
+        finally:
+            mod.FUSED_ATTN_OUT = True
+        compare(pair, ref, rel=MODULE_REL_TOL, name=f"full-width T2D, to_out as a GEMM C={c}")
+        compare(got, pair, rel=MODULE_REL_TOL, name=f"T2D to_out inside vs behind the fused text attention C={c}")
 
 
 @pytest.mark.parametrize("c,hw,frames", [(320, 32, 16), (640, 16, 16), (1280, 8, 16), (320, 16, 32), (320, 32, 8)])
@@ -178,6 +189,15 @@ def test_full_width_motion_module(dev, c, hw, frames):
             compare(plain, ref, rel=MODULE_REL_TOL, name=f"full-width motion module, un-fused attention sub-block C={c}")
             compare(got, plain, rel=MODULE_REL_TOL, name=f"motion module fused vs un-fused C={c}")
             assert not torch.equal(got, plain)               # (different roundings: the two paths really differ)
+            # to_out + residual as a GEMM launch behind the fused attention (I2V_ATTN_OUTP=0)
+            assert blocks.FUSED_ATTN_OUT
+            blocks.FUSED_ATTN_OUT = False
+            try:
+                pair = m(x.half().to(dev), num_frames=frames)[0]
+            finally:
+                blocks.FUSED_ATTN_OUT = True
+            compare(pair, ref, rel=MODULE_REL_TOL, name=f"full-width motion module, to_out as a GEMM C={c}")
+            compare(got, pair, rel=MODULE_REL_TOL, name=f"motion module to_out inside vs behind the fused attention C={c}")
             # the one-launch feed-forward (i2v_ff_fused_f16) against the LayerNorm-folded GEGLU GEMM + output GEMM (I2V_FF_FUSED=0)
             assert blocks.FUSED_FF and m.transformer_blocks[0].ff.fused_supported(torch.empty(2 * frames * hw * hw, c))
             blocks.FUSED_FF = False

@@ -609,6 +609,21 @@ def test_motion_attention_sub_block_fused(dev, npix, amp, strided, frames):
     assert torch.equal(out, k.motion_attn(xd, g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps))
     with pytest.raises(Exception, match="not a fused shape"):
         k.motion_attn(xd[:rows - 16], g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps)
+    # to_out + bias + residual in the same launch (w_o, b_o): against fp32 torch on the kernel's own fp16 o, and against the GEMM
+    # launch it replaces (fp32 sums in another order: an fp16 ulp of the result)
+    wo, bo = h(torch.randn(c, c, generator=g) * c ** -0.5), h(0.1 * torch.randn(c, generator=g))
+    op = k.pack_attn_out(D(wo), D(bo), heads)
+    assert tuple(op[0].shape) == (8 * 48, c) and op[1].dtype == torch.float32
+    full = k.motion_attn(xd, g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps, out_proj=op)
+    ref_o = x + out.float().cpu() @ wo.T + bo
+    close(full, ref_o, rel=1e-3, name="fused motion attention + to_out + residual vs fp32 torch")
+    pair = k.gemm(out, D(wo), D(bo), residual=xd)
+    close(full, pair, rel=1e-3, name="to_out inside the launch vs the GEMM behind it")
+    assert torch.equal(full, k.motion_attn(xd, g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps, out_proj=op))
+    buf = xd.contiguous().clone()                       # in place: a tile's rows are read before they are written
+    assert torch.equal(full, k.motion_attn(buf, g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps, out_proj=op, out=buf))
+    with pytest.raises(ValueError, match="pack_attn_out"):
+        k.motion_attn(xd, g32, s32, w, heads=heads, head_dim=d, frames=frames, eps=eps, out_proj=(op[0][:-16], op[1]))
 
 
 @pytest.mark.parametrize("n_img,L,adapter,strided,amp", [(1, 128, True, False, 1.0), (3, 1024, True, True, 1.0), (2, 4096, False, False, 1.0),
@@ -812,6 +827,16 @@ def test_text_cross_attention_sub_block_fused(dev, rows, n_ctx, lt, amp):
     close(out_ip, old_ip, rel=1.5e-3 * amp * amp, name="fused text + image cross-attention vs the un-fused kernels")
     with pytest.raises(Exception, match="not a fused shape"):
         k.cross_attn_fused(xd[:rows - 16], g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps)
+    # to_out + bias + residual in the same launch, with and without the image tokens
+    wo, bo = h(torch.randn(c, c, generator=g) * c ** -0.5), h(0.1 * torch.randn(c, generator=g))
+    op = k.pack_attn_out(D(wo), D(bo), heads)
+    for o_attn, kw in ((out, {}), (out_ip, dict(ip_frag=frag_ip, ip_len=li, ip_scale=ip_scale))):
+        full = k.cross_attn_fused(xd, g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc, eps=eps, out_proj=op, **kw)
+        close(full, x + o_attn.float().cpu() @ wo.T + bo, rel=1e-3, name="fused text cross-attention + to_out + residual vs fp32 torch")
+        close(full, k.gemm(o_attn, D(wo), D(bo), residual=xd), rel=1e-3, name="to_out inside the launch vs the GEMM behind it")
+        buf = xd.clone()
+        assert torch.equal(full, k.cross_attn_fused(buf, g32, b32, w, frag, heads=heads, head_dim=d, ctx_len=lt, rows_per_ctx=rpc,
+                                                    eps=eps, out_proj=op, out=buf, **kw))
 
 
 @pytest.mark.parametrize("n,hh,ww,c1,c2,groups,fps,silu,perm", [

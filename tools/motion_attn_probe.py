@@ -10,6 +10,7 @@ import torch  # noqa: E402
 
 dev = torch.device("cuda:0")
 stamps = "--stamps" in sys.argv
+outp = "--outp" in sys.argv          # the out-projection + residual inside the launch (w_o, b_o)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 rows = int(args[0]) if args else 131072
 c, heads, d, F = 320, 8, 40, 16
@@ -49,8 +50,18 @@ def old():
     return K.temporal_attention(qk[:, :c], qk[:, c:], vt, n_pixels=rows // F, frames=F, heads=heads, head_dim=d)
 
 
+op = K.pack_attn_out(wo, torch.zeros(c, device=dev).half(), heads) if outp else None
+
+
 def new():
-    return K.motion_attn(x, g32, s32, w, heads=heads, head_dim=d, frames=F, eps=1e-5)
+    return K.motion_attn(x, g32, s32, w, heads=heads, head_dim=d, frames=F, eps=1e-5, out_proj=op)
+
+
+if outp:
+    _old = old
+
+    def old():
+        return K.gemm(_old(), wo, None, residual=x)
 
 
 a, b = old(), new()
@@ -66,7 +77,7 @@ if stamps:
     if st.abs().sum() == 0:
         print("no stamps: not a -DI2V_MA_STAMPS build")
         sys.exit(0)
-    names = ["first LN", "barrier", "pass q", "pass k+softmax", "pass v", "PV+stores", "LN next"]
+    names = ["first LN", "barrier", "pass q", "pass k+softmax", "pass v", "PV+stores", "LN next" + (" + out-proj" if outp else "")]
     tiles = min(4, (rows // 128 + nwg - 1) // nwg)
     for it in range(tiles):
         blk = st[:, it]
