@@ -226,7 +226,10 @@ __global__ __launch_bounds__(64 * H) void motion_attn_kernel(const ma_args p, co
 #pragma unroll
         for (int t = 0; t < DT; ++t) wf[(s + MA_PD - 1) % MA_PD][t] = ldw(s + MA_PD - 1, t);
       }
-      if (i == 0) hook();       // (memory requests that may return behind the first MA_PD K steps' fragments)
+#ifndef I2V_MA_HOOK_S
+#define I2V_MA_HOOK_S 0
+#endif
+      if (pix == 0 && s == I2V_MA_HOOK_S) hook();       // (memory requests that may return behind the K steps' fragments requested so far)
       if (i + AD < NI) af[(i + AD) % (AD + 1)] = lda(i + AD);
 #pragma unroll
       for (int t = 0; t < DT; ++t)

@@ -1,3 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_full_width_gpu.py -x -q -m gpu -k "motion or cross_attention_sub or transformer_2d" 2>&1 | tail -8
+for v in "" .ab_libs/ma_h6.so .ab_libs/ma_h7.so .ab_libs/ma_h8.so .ab_libs/ma_h9.so "" .ab_libs/ma_h7.so; do
+echo "--- lib '$v'" >> gpurun_out/hook.txt; I2V_LIB_PATH=$v timeout -k 10 300 python tools/attn_outproj_probe.py 131072 16 2>&1 | grep "pair" >> gpurun_out/hook.txt
+done
