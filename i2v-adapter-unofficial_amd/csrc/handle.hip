@@ -68,13 +68,22 @@ extern "C" int i2v_unet_set_weight(i2v_unet* h, const char* key, const void* ptr
     w.shape[i] = shape[i];
   }
   I2V_CHECK_ARG((reinterpret_cast<uintptr_t>(ptr) & (dtype == I2V_DTYPE_F16 ? 1 : 3)) == 0, "i2v_unet_set_weight: `%s` is misaligned", key);
-  h->weights[std::string(key)] = w;
+  try {                          // (no exception crosses the C ABI)
+    h->weights[std::string(key)] = w;
+  } catch (...) {
+    I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_unet_set_weight: out of host memory registering `%s`", key);
+  }
   return I2V_OK;
 }
 
 extern "C" int i2v_unet_get_weight(const i2v_unet* h, const char* key, const void** ptr, int32_t* dtype, int32_t* ndim, int64_t* shape) {
   I2V_CHECK_ARG(h != nullptr && key != nullptr && ptr != nullptr, "i2v_unet_get_weight: null argument");
-  const auto it = h->weights.find(std::string(key));
+  std::map<std::string, i2v_unet::weight>::const_iterator it;
+  try {
+    it = h->weights.find(std::string(key));
+  } catch (...) {
+    I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_unet_get_weight: out of host memory looking up `%s`", key);
+  }
   if (it == h->weights.end()) {
     *ptr = nullptr;
     return I2V_OK;
