@@ -456,6 +456,11 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     if (ws != 0) return ws < 0 ? ws : I2V_OK;
   }
 #endif
+  // narrow-output 3x3 convolutions (conv_out: 4 channels): a halo-tile kernel of their own (conv_thin.hip)
+  {
+    const int thin = i2v_conv_thin_try(p, reinterpret_cast<hipStream_t>(stream));
+    if (thin != 0) return thin < 0 ? thin : I2V_OK;
+  }
   // large problems whose N is a multiple of 320 go to the 8-wave LDS-DMA kernel (gemm_big.hip)
   {
     const int big = i2v_gemm_big_try(p, vec4, reinterpret_cast<hipStream_t>(stream));

@@ -275,6 +275,33 @@ def test_conv3x3(dev, n, hh, ww, cin, cout, stride, up):
     close(out.permute(0, 3, 1, 2), ref + rv[:, :, None, None] + res, name="conv3x3+temb+res")
 
 
+@pytest.mark.parametrize("n,hh,ww,cin,cout", [(3, 16, 32, 320, 4), (2, 8, 16, 128, 3), (1, 24, 48, 64, 16), (2, 8, 32, 192, 5),
+                                              (2, 64, 64, 320, 4)])
+def test_conv3x3_narrow_output(dev, n, hh, ww, cin, cout):
+    """3x3 convolutions with <= 16 output channels on images of whole 8 x 16 pixel tiles take the halo-tile kernel
+    (csrc/conv_thin.hip: the UNet's conv_out, unet:879-881, 1443; the VAE decoder's): against the exact convolution of the
+    fp16-rounded operands, fp32 and fp16 results, image borders and tile seams included (every tile has a border or a seam)."""
+    k = K()
+    g = torch.Generator().manual_seed(cout * 1000 + cin + hh)
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = h(torch.randn(cout, generator=g))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    wp = _pack_conv(w).to(dev)
+    out32 = k.conv3x3(xt, wp, b.half().to(dev), out_f32=True)
+    out16 = k.conv3x3(xt, wp, b.half().to(dev))
+    assert out32.dtype == torch.float32 and out16.dtype == torch.float16 and tuple(out32.shape) == (n, hh, ww, cout)
+    close(out32.permute(0, 3, 1, 2), ref, rel=1e-5, name="narrow conv3x3, fp32 result")
+    assert torch.equal(out32.half(), out16), "the fp16 form must be the rounding of the fp32 form"
+    # a single hot pixel lands in its nine neighbours with the nine taps (orientation of the taps, seams between tiles)
+    xi = torch.zeros(1, cin, hh, ww)
+    py, px = 7 % hh, 16 % ww              # on a tile seam where the image has more than one tile
+    xi[0, :, py, px] = 1.0
+    got = k.conv3x3(xi.permute(0, 2, 3, 1).contiguous().half().to(dev), wp, None, out_f32=True).permute(0, 3, 1, 2)
+    close(got, F.conv2d(xi.double(), w.double(), None, padding=1).float(), rel=1e-5, name="narrow conv3x3, impulse")
+
+
 @pytest.mark.parametrize("cout,cin", [(4, 320), (3, 128), (8, 64)])
 def test_conv3x3_fp32_result(dev, cout, cin):
     """narrow convolutions can keep their result in fp32 (i2v_gemm_params.c_is_f32): the UNet's 4-channel conv_out
