@@ -144,8 +144,10 @@ int i2v_conv_thin_try(const i2v_gemm_params& p, hipStream_t s) {
     return 0;
   if ((int64_t)p.in_h * p.in_w * p.lda >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.c) & (p.c_is_f32 ? 15 : 7)) != 0) return 0;
   const size_t lds = 2 * (size_t)CT_HH * CT_HW * CT_PS + (size_t)p.N * 9 * p.cin * sizeof(f16);
-  if (lds > 80 * 1024) return 0;        // (two workgroups per CU)
-  const int cus = i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(conv_thin_kernel), lds);
+  constexpr size_t CT_MAXLDS = 80 * 1024;        // (two workgroups per CU)
+  if (lds > CT_MAXLDS) return 0;
+  // (the opt-in is cached per kernel and device: asked once, for the most any problem of this kernel may use)
+  const int cus = i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(conv_thin_kernel), CT_MAXLDS);
   if (cus <= 0) return 0;
   const int tiles_x = p.in_w / CT_TW, tiles_y = p.in_h / CT_TH;
   const int64_t grid = (int64_t)p.n_img * tiles_x * tiles_y;
