@@ -44,6 +44,7 @@ class GemmParams(C.Structure):
         ("a_perm_frames", C.c_int32), ("a_perm_hw", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("c_is_f32", C.c_int32),
+        ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
     ]
 
 
@@ -177,6 +178,7 @@ class GnParams(C.Structure):
         ("eps", C.c_float), ("silu", C.c_int32),
         ("out_perm", C.c_int32), ("frames", C.c_int32),
         ("workspace", C.c_void_p),
+        ("gpartial_in", C.c_void_p), ("gpartial_rows", C.c_int32),
     ]
 
 
@@ -201,6 +203,7 @@ SIGNATURES = {
     "i2v_gemm_ln_supported": (C.c_int, [C.POINTER(GemmParams)]),
     "i2v_gemm_batch_supported": (C.c_int, [C.POINTER(GemmParams)]),
     "i2v_gemm_workspace_bytes": (C.c_int64, [C.POINTER(GemmParams)]),
+    "i2v_gemm_gn_partial_rows": (C.c_int32, [C.POINTER(GemmParams)]),
     "i2v_attention_f16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "i2v_temporal_attention_f16": (C.c_int, [C.POINTER(TAttnParams), _P]),
     "i2v_motion_attn_supported": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -287,6 +287,10 @@ class TimestepEmbedding(HipModule):
 
 
 # ---------------------------------------------------------------------------------------------------------- A2/A3
+# norm2's GroupNorm statistics written by conv1's epilogue (i2v_gemm_params.gn_partial) instead of a pass over conv1's output
+GN_FROM_CONV = os.environ.get("I2V_GN_FROM_CONV", "1") != "0"
+
+
 class ResnetBlock2D(HipModule):
     """A2.  GN+SiLU -> conv3x3 (+bias +time-embedding row add fused) -> GN+SiLU -> conv3x3 (+bias + shortcut /
     residual fused).  The skip concat of the up blocks (unet:478) is never materialised: GroupNorm reads both
@@ -342,8 +346,12 @@ class ResnetBlock2D(HipModule):
                 rowvec = (temb_act.view_for(self) if isinstance(temb_act, ProjectedTemb)
                           else K.gemm(temb_act, p["wt"], p["bt"]))
                 rpv = (n // rowvec.shape[0]) * hh * ww
-            h = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv)
-            h = K.groupnorm(h, p["g2"], p["b2"], self.groups, self.eps, silu=True)
+            # norm2's statistics come out of conv1's epilogue where that form exists (the 64^2 / 32^2 levels): no statistics pass
+            if GN_FROM_CONV:
+                h, st = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv, gn_stats_groups=self.groups)
+            else:
+                h, st = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv), None
+            h = K.groupnorm(h, p["g2"], p["b2"], self.groups, self.eps, silu=True, stats=st)
         return K.conv3x3(h, p["w2"], p["cb2"], residual=s, out_scale=1.0 / self.output_scale_factor)
 
     def forward(self, input_tensor, temb, scale: float = 1.0):

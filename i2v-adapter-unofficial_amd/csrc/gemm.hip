@@ -363,6 +363,11 @@ extern "C" int i2v_gemm_batch_supported(const i2v_gemm_params* pp) {
   return i2v_gemm_big_unsplit_ok(*pp, vector_epilogue_ok(*pp));
 }
 
+extern "C" int32_t i2v_gemm_gn_partial_rows(const i2v_gemm_params* pp) {
+  if (pp == nullptr) return 0;
+  return i2v_gemm_big_gn_rows(*pp, vector_epilogue_ok(*pp));
+}
+
 extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(pp != nullptr, "i2v_gemm_f16: null params");
   const i2v_gemm_params& p = *pp;
@@ -442,6 +447,12 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
                p.store_mode);
   }
 
+  if (p.gn_partial) {
+    I2V_CHECK_ARG(aligned_to(p.gn_partial, 8), "i2v_gemm_f16: gn_partial must be 8-byte aligned");
+    if (!i2v_gemm_big_gn_rows(p, vec4))
+      I2V_FAIL(I2V_ERR_INVALID_ARG, "i2v_gemm_f16: GroupNorm partials (gn_partial) are not implemented for this problem (M %d N %d K %d, "
+               "groups %d): ask i2v_gemm_gn_partial_rows() first", p.M, p.N, p.K, p.gn_groups);
+  }
   if (p.rows_per_w > 0 || p.a_perm_frames > 0) {
     I2V_CHECK_ARG(p.rows_per_w >= 0 && p.a_perm_frames >= 0 && p.w_batch_stride >= 0, "i2v_gemm_f16: negative batch / permutation field");
     if (!i2v_gemm_big_unsplit_ok(p, vec4))

@@ -102,7 +102,7 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
 // tile's prologue (first DMA wait) and epilogue (LayerNorm apply, GELU, transposes, stores: as long as the K loop itself
 // when K = 320) run beside the other tile's MFMAs instead of stopping the CU.
 template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true, bool LNF = false,
-          bool FAST = false, int BNT = 320, int NW = 8>
+          bool FAST = false, int BNT = 320, int NW = 8, bool GNS = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n,
                                                                             const int kps, const int ntiles) {
   static_assert(NS == 2 || (NS <= 4 && !FAST && !SPLIT && NW == 8),
@@ -762,6 +762,69 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
     }
     __builtin_amdgcn_s_barrier();                         // every wave has left the K loop: the stages are free
     float* stg = reinterpret_cast<float*>(slab_stage) + wave * (16 * LDS_LD);
+    if constexpr (GNS) {
+      // GroupNorm statistics of the tile's output for the norm that reads it next (ResnetBlock2D: conv1 -> norm2, unet:203-214):
+      // per statistics group of the tile's BN channels the partial (mean, M2) over the tile's BM rows, in the layout and with the
+      // meaning of gn_stats_kernel's per-group partials (norm.hip), so that the consumer's statistics pass -- a launch that re-reads
+      // the whole tensor -- disappears (i2v_gemm_params.gn_partial).  From the RAW accumulators a (the convolution without bias and
+      // time-embedding row k_c, which are constants of a column inside a tile: mean_c = mean(a_c) + k_c, M2_c = sum a_c^2 -
+      // (sum a_c)^2 / n is unchanged by them, and a carries no large common offset to cancel against), in fp32, before the fp16
+      // rounding of the stored result.  Host-checked: M % BM == 0, a tile lies in one image and one row of the row vector.
+      float* cst = reinterpret_cast<float*>(slab_stage) + NW * (16 * LDS_LD);      // [NW / 4][BN] (sum, sum of squares), then k_c [BN]
+      float* kst = cst + (NW / 4) * BN * 2;
+      auto row16_sum = [](float x) {          // over the 16 lanes of a DPP row (the rows l15 of one lane group)
+        x = sum_lanes8(x);
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
+      };
+      static_for<NI>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+        static_for<MI>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          s4 += acc[i][j];
+          q4 += acc[i][j] * acc[i][j];
+        });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s4[r] = row16_sum(s4[r]);
+          q4[r] = row16_sum(q4[r]);
+        }
+        if (l15 == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float2*>(cst + (wm * BN + wn * WNC + i * 16 + 4 * g + r) * 2) = float2{s4[r], q4[r]};
+        }
+      });
+      if (tid < BN) {
+        const int vrow = rowvec ? (p.rowvec_period > 0 ? (m0 & (p.rowvec_period - 1)) : fast_div(m0, p.rows_per_vec > 0 ? p.rows_per_vec : 1, inv_rpv)) : 0;
+        kst[tid] = (bias ? (float)bias[n0 + tid] : 0.f) + (rowvec ? (float)rowvec[(int64_t)vrow * p.ld_rowvec + n0 + tid] : 0.f);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int cpg = N / p.gn_groups, gpt = BN / cpg;          // channels per group, groups of this tile's BN channels
+      if (tid < gpt) {
+        constexpr int NWM = NW / 4;
+        const float nr = (float)WM, inv_nr = 1.0f / (float)WM;
+        float mg = 0.f;
+        for (int c = 0; c < cpg; ++c)
+#pragma unroll
+          for (int w = 0; w < NWM; ++w) mg += cst[(w * BN + tid * cpg + c) * 2] * inv_nr + kst[tid * cpg + c];
+        mg /= (float)(cpg * NWM);
+        float m2 = 0.f;
+        for (int c = 0; c < cpg; ++c)
+#pragma unroll
+          for (int w = 0; w < NWM; ++w) {
+            const float sc = cst[(w * BN + tid * cpg + c) * 2], qc = cst[(w * BN + tid * cpg + c) * 2 + 1];
+            const float dm = sc * inv_nr + kst[tid * cpg + c] - mg;
+            m2 += fmaxf(qc - sc * sc * inv_nr, 0.f) + nr * dm * dm;
+          }
+        const int hw = p.out_h * p.out_w, img = m0 / hw, chunk = (m0 - img * hw) / BM, nchunk = hw / BM;
+        float* dst = reinterpret_cast<float*>(p.gn_partial) + (((int64_t)img * nchunk + chunk) * p.gn_groups + n0 / cpg + tid) * 2;
+        dst[0] = mg;
+        dst[1] = m2;
+      }
+      // (the slabs below and the statistics region are disjoint; the accumulators are untouched)
+    }
     // bias (and the GEGLU gate, in place: registers 0 / 1 of each accumulator become the two outputs) first, as a
     // pure register pass: fused with the staging below, the GELU temporaries pushed accumulators into scratch
     if (LNF) {
@@ -958,6 +1021,10 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
     if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT, false);
   } else if (p.store_mode == I2V_STORE_VT_T) {
     if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_VT_T, false);
+  } else if (AMODE == I2V_A_CONV3X3 && p.gn_partial != nullptr) {      // + GroupNorm partials of the result (vetted by i2v_gemm_gn_partial_rows)
+    if constexpr (AMODE == I2V_A_CONV3X3 && !FAST)
+      hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false, true, false, false, 320, 8, true>), grid,
+                         block, 0, s, p, tiles_n, 0, ntiles);
   } else {
     I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false);
   }
@@ -1311,6 +1378,19 @@ int i2v_gemm_big_ln_ok(const i2v_gemm_params& p, int vec4) {
             (!p.rowvec || (p.rowvec_period >= 8 && (p.rowvec_period & (p.rowvec_period - 1)) == 0 && p.ld_rowvec % 8 == 0)))
                ? 1 : 0;
   return 0;
+}
+
+// rows per block of the GroupNorm partials the un-split convolution's epilogue writes (gn_partial), 0: not this problem
+int i2v_gemm_big_gn_rows(const i2v_gemm_params& p, int vec4) {
+  const int plan = big_plan(p, vec4, nullptr, nullptr);
+  if (plan != 256 && plan != 128) return 0;
+  if (p.a_mode != I2V_A_CONV3X3 || big_bn(p) != BIG_BN || p.epilogue != I2V_EPI_NONE || p.store_mode != I2V_STORE_ROWMAJOR) return 0;
+  if (p.residual || p.ln_wsum || p.c_is_f32 || p.rows_per_w > 0 || p.a_perm_frames > 0) return 0;
+  if (p.gn_groups <= 0 || p.N % p.gn_groups != 0) return 0;
+  const int cpg = p.N / p.gn_groups, hw = p.out_h * p.out_w;
+  if (cpg <= 0 || BIG_BN % cpg != 0 || p.M % plan != 0 || hw % plan != 0) return 0;
+  if (p.rowvec && (p.rowvec_period > 0 || p.rows_per_vec <= 0 || p.rows_per_vec % plan != 0)) return 0;
+  return plan;
 }
 
 // 1 if the 8-wave kernel takes this problem un-split (per-batch weights and the permuted A gather exist only there)

@@ -116,6 +116,7 @@ __device__ __forceinline__ void gemm_store4(const i2v_gemm_params& p, const int 
 // implemented in gemm_big.hip: 256-thread-pair (8-wave) LDS-DMA kernel for N % 320 == 0; returns 1 if it took the
 // problem, 0 if the caller should use the generic kernel, < 0 on error.
 int i2v_gemm_big_try(const i2v_gemm_params& p, int vec4, hipStream_t s);
+int i2v_gemm_big_gn_rows(const i2v_gemm_params& p, int vec4);
 // conv_thin.hip: 3x3 convolutions with <= 16 output channels (same return convention)
 int i2v_conv_thin_try(const i2v_gemm_params& p, hipStream_t s);
 // 1 if gemm_big.hip takes this problem AND implements the LayerNorm fold (ln_wsum) for its epilogue

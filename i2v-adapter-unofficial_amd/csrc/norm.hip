@@ -279,25 +279,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const f16* __restrict__ x1, int c1, const f16* __restrict__ x2,
                                                              int c2, const float* __restrict__ gpartial, int groups,
                                                              const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                             float eps, f16* __restrict__ y, int hw, int rpc, int silu) {
-  extern __shared__ float gsm[];                 // [nchunk * groups * 2] partials, then [groups * 2] (mean, rstd)
+                                                             float eps, f16* __restrict__ y, int hw, int rpc, int silu,
+                                                             int pchunks, int prpc) {
+  // (pchunks partials of prpc rows each per image: gn_stats_kernel's own chunks, or the row tiles of the convolution that produced
+  //  x and wrote the partials from its epilogue -- i2v_gemm_params.gn_partial; rpc / gridDim.x: the rows this launch applies)
+  extern __shared__ float gsm[];                 // [pchunks * groups * 2] partials, then [groups * 2] (mean, rstd)
   const int C = c1 + c2, nvec = C / 8, nv1 = c1 / 8;
-  const int chunk = blockIdx.x, img = blockIdx.y, nchunk = gridDim.x;
+  const int chunk = blockIdx.x, img = blockIdx.y;
   const int tid = threadIdx.x;
   const int cpg = C / groups;
-  float* stat = gsm + nchunk * groups * 2;
-  for (int i = tid; i < nchunk * groups * 2; i += 256) gsm[i] = gpartial[(int64_t)img * nchunk * groups * 2 + i];
+  float* stat = gsm + pchunks * groups * 2;
+  for (int i = tid; i < pchunks * groups * 2; i += 256) gsm[i] = gpartial[(int64_t)img * pchunks * groups * 2 + i];
   __syncthreads();
   if (tid < groups) {
     float sum = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc);
+    for (int ch = 0; ch < pchunks; ++ch) {
+      const float n_i = (float)(min(hw, (ch + 1) * prpc) - ch * prpc);
       sum += n_i * gsm[(ch * groups + tid) * 2];
     }
     const float mean = sum / (float)hw;
     float m2 = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float n_i = (float)(min(hw, (ch + 1) * rpc) - ch * rpc) * (float)cpg;
+    for (int ch = 0; ch < pchunks; ++ch) {
+      const float n_i = (float)(min(hw, (ch + 1) * prpc) - ch * prpc) * (float)cpg;
       const float dm = gsm[(ch * groups + tid) * 2] - mean;
       m2 += gsm[(ch * groups + tid) * 2 + 1] + n_i * dm * dm;
     }
@@ -855,6 +858,23 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
   I2V_CHECK_ARG(al16(p.x) && al16(p.y) && (!p.x2 || al16(p.x2)) && al16(p.workspace) && al16(p.gamma) && al16(p.beta),
                 "i2v_groupnorm_f16: pointers must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.gpartial_in != nullptr) {
+    // the statistics arrive as per-group partials from the epilogue of the convolution that wrote x: finalise + apply only
+    I2V_CHECK_ARG(p.frames_per_stat == 1 && !p.out_perm && p.x2 == nullptr && p.groups <= GN_MAXG && C <= GN_MAXC,
+                  "i2v_groupnorm_f16: gpartial_in is for per-image statistics of one source without a row permutation");
+    I2V_CHECK_ARG(p.gpartial_rows > 0 && p.hw % p.gpartial_rows == 0 && (reinterpret_cast<uintptr_t>(p.gpartial_in) & 7) == 0,
+                  "i2v_groupnorm_f16: gpartial_rows (%d) must divide hw (%d)", p.gpartial_rows, p.hw);
+    const int pchunks = p.hw / p.gpartial_rows;
+    const size_t lds = ((size_t)pchunks * p.groups * 2 + (size_t)p.groups * 2) * sizeof(float);
+    I2V_CHECK_ARG(lds <= 48 * 1024, "i2v_groupnorm_f16: %d partial blocks per image do not fit the finalise step", pchunks);
+    const int rpc = gn_rows_per_chunk(p.n_img, p.hw);
+    hipLaunchKernelGGL(gn_apply_fused_kernel, dim3((unsigned)i2v_cdiv(p.hw, rpc), p.n_img), dim3(256), lds, s,
+                       reinterpret_cast<const f16*>(p.x), p.c1, static_cast<const f16*>(nullptr), 0,
+                       reinterpret_cast<const float*>(p.gpartial_in), p.groups, reinterpret_cast<const f16*>(p.gamma),
+                       reinterpret_cast<const f16*>(p.beta), p.eps, reinterpret_cast<f16*>(p.y), p.hw, rpc, p.silu, pchunks,
+                       p.gpartial_rows);
+    return i2v_check_launch("i2v_groupnorm_f16(partials from the producer)");
+  }
   {
     size_t lds = 0;
     const int gb = gn_slab_plan(p.n_img, p.hw, C, p.groups, p.frames_per_stat, &lds);
@@ -886,7 +906,7 @@ extern "C" int i2v_groupnorm_f16(const i2v_gn_params* pp, i2v_stream_t stream) {
                        rpc, partial, gpartial, p.groups);
     hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(nchunk, p.n_img), dim3(256), fused_lds, s, x1, p.c1, x2, p.c2, gpartial, p.groups,
                        reinterpret_cast<const f16*>(p.gamma), reinterpret_cast<const f16*>(p.beta), p.eps,
-                       reinterpret_cast<f16*>(p.y), p.hw, rpc, p.silu);
+                       reinterpret_cast<f16*>(p.y), p.hw, rpc, p.silu, nchunk, rpc);
     return i2v_check_launch("i2v_groupnorm_f16(fused finalize)");
   }
   if (!fused_off && p.groups <= GN_MAXG && C <= GN_MAXC) {

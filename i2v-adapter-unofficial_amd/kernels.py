@@ -169,12 +169,15 @@ def conv_k_block(cin: int) -> int:
 
 
 def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
-            out_scale=1.0, asym_pad=False, out_f32=False):
+            out_scale=1.0, asym_pad=False, out_f32=False, gn_stats_groups=0):
     """3x3 / pad 1 convolution of a token-major image x [N, H, W, Cin] with w_packed [Cout, 9 * Cin]
     (k ordered as `blocks.pack_conv3x3` lays it out: tap-major, or channel-block-major when Cin % 64 == 0, see
     conv_k_block); optional nearest-2x upsampling of the input first.  asym_pad (stride 2): no
     padding at the top / left, one zero row / column at the bottom / right (the VAE encoder's Downsample2D(padding=0)).
-    out_f32: the result stays fp32 (narrow outputs only, Cout <= 64: the UNet's conv_out feeding the DDIM / CFG kernel)."""
+    out_f32: the result stays fp32 (narrow outputs only, Cout <= 64: the UNet's conv_out feeding the DDIM / CFG kernel).
+    gn_stats_groups > 0: returns (out, stats) -- stats = the GroupNorm statistics of `out` over that many channel groups as
+    partials written by the convolution's epilogue (i2v_gemm_params.gn_partial), to hand to `groupnorm(out, ..., stats=stats)`,
+    or None where the epilogue form is not implemented for this problem (the norm then runs its own statistics pass)."""
     lib = _lib.load()
     _req(x, "x")
     if x.dim() != 4 or not x.is_contiguous():
@@ -226,9 +229,19 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     p.asym_pad = 1 if asym_pad else 0
     p.conv_kblock = conv_k_block(cin)
     ws = _attach_splitk_workspace(lib, p, x.device)
+    stats = None
+    if gn_stats_groups:
+        p.gn_groups = int(gn_stats_groups)
+        # (asked with the split-K workspace attached: a problem that splits K keeps doing so -- its partial tiles have no epilogue
+        #  of their own -- and the norm runs its statistics pass)
+        rows = lib.i2v_gemm_gn_partial_rows(C.byref(p))
+        if rows > 0:
+            part = torch.empty((n, (oh * ow) // rows, int(gn_stats_groups), 2), dtype=torch.float32, device=x.device)
+            p.gn_partial = _p(part)
+            stats = (part, rows)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16(conv3x3)")
     del ws
-    return out
+    return (out, stats) if gn_stats_groups else out
 
 
 def project_vt(tokens, w_v, batch_len, out=None, bias=None, ln=None, pe_t=None, pe_period=0, query_ln_support=False):
@@ -630,7 +643,7 @@ def motion_attn(x, gamma32, shift32, w_qkv, *, heads, head_dim, frames, eps, sca
 
 
 # ---------------------------------------------------------------------------------------------- norms
-def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_stat=1, out_perm=False, frames=0):
+def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_stat=1, out_perm=False, frames=0, stats=None):
     """GroupNorm (+SiLU) of a token-major image batch x [N, H, W, C1] (optionally concatenated with x2 along C).
     Returns [N, H, W, C]; with out_perm the rows are written in (b, pixel, frame) order and the result is
     returned flat as [N * H * W, C]."""
@@ -659,6 +672,13 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, frames_per_st
     p.eps, p.silu = eps, 1 if silu else 0
     p.out_perm, p.frames = (1 if out_perm else 0), frames
     p.workspace = _p(ws)
+    if stats is not None:       # (partials, rows per partial block) from `conv3x3(..., gn_stats_groups=groups)`: no statistics pass
+        part, rows = stats
+        _req(part, "stats", dtype=torch.float32)
+        if x2 is not None or frames_per_stat != 1 or out_perm or tuple(part.shape) != (n, (h * w) // rows, groups, 2) or \
+                not part.is_contiguous():
+            raise ValueError(f"groupnorm: stats {tuple(part.shape)} / rows {rows} do not describe x {tuple(x.shape)} in {groups} groups")
+        p.gpartial_in, p.gpartial_rows = _p(part), int(rows)
     _lib.check(lib.i2v_groupnorm_f16(C.byref(p), _stream()), "i2v_groupnorm_f16")
     return y
 

@@ -30,10 +30,14 @@ def _work_gemm(args, kw, out):
 
 def _work_conv(args, kw, out):
     x, w = args[0], args[1]
+    stats = None
+    if isinstance(out, tuple):        # (result, GroupNorm partials from the epilogue or None): gn_stats_groups
+        out, stats = out
     M = out.shape[0] * out.shape[1] * out.shape[2]
     return ("conv3x3", 2.0 * M * w.shape[0] * w.shape[1], _numel_bytes(x, w, kw.get("residual"), out),
             f"{M}x{w.shape[0]}x{w.shape[1]}" + (" s2" if kw.get("stride", 1) == 2 else "")
-            + (" up" if kw.get("upsample") else "") + (" +res" if kw.get("residual") is not None else ""))
+            + (" up" if kw.get("upsample") else "") + (" +res" if kw.get("residual") is not None else "")
+            + (" +gn stats" if stats is not None else ""))
 
 
 def _work_attn(args, kw, out):
@@ -88,6 +92,8 @@ def _work_lnqkv(args, kw, out):
 
 
 def _work_gn(args, kw, out):
+    if kw.get("stats") is not None:   # statistics from the producer's epilogue: one read, one write
+        return "groupnorm", 0.0, 2 * _numel_bytes(out), "x".join(map(str, out.shape)) + " (stats given)"
     return "groupnorm", 0.0, 3 * _numel_bytes(out), "x".join(map(str, out.shape))
 
 

@@ -140,6 +140,14 @@ typedef struct i2v_gemm_params {
      i2v_ddim_cfg_step without an fp16 rounding that the CFG combine (pipe:686-688) would amplify by up to
      2 * guidance_scale - 1. */
   int32_t c_is_f32;
+  /* (ABI 8) optional: GroupNorm statistics of the result for the norm that consumes it (ResnetBlock2D conv1 -> norm2, unet:203-214;
+     diffusers ResnetBlock2D), written by the epilogue so that i2v_groupnorm_f16 needs no statistics pass over the tensor:
+     fp32 [n_img][out_h * out_w / R][gn_groups][2] = per (image, block of R consecutive rows, group) the mean and the sum of squared
+     deviations over the block's rows x the group's channels, R = i2v_gemm_gn_partial_rows(p) (> 0 where implemented: un-split
+     I2V_A_CONV3X3 problems of the 8-wave kernel, no residual, images of whole row blocks).  Hand the buffer and R to
+     i2v_gn_params.gpartial_in / gpartial_rows.  NULL: none. */
+  void* gn_partial;
+  int32_t gn_groups;
 } i2v_gemm_params;
 
 int i2v_gemm_f16(const i2v_gemm_params* p, i2v_stream_t stream);
@@ -149,6 +157,9 @@ int i2v_gemm_ln_supported(const i2v_gemm_params* p);
 int i2v_gemm_batch_supported(const i2v_gemm_params* p);
 /* bytes of `workspace` with which i2v_gemm_f16 would split K for this problem (0: it would not split). */
 int64_t i2v_gemm_workspace_bytes(const i2v_gemm_params* p);
+/* rows per block of the GroupNorm partials i2v_gemm_f16 would write for this problem with gn_partial set (gn_groups must be set;
+   pointers are not dereferenced); 0: not implemented for it. */
+int32_t i2v_gemm_gn_partial_rows(const i2v_gemm_params* p);
 
 /* ------------------------------------------------------------------------------------------------
  * Flash-style attention forward (MFMA QK^T / PV, wavefront-shuffle online softmax).
@@ -365,6 +376,9 @@ typedef struct i2v_gn_params {
   int32_t silu;
   int32_t out_perm; int32_t frames; /* out_perm: images are (b, f); output row = (b*hw + p)*frames + f */
   void* workspace;
+  /* (ABI 8) optional: the statistics as per-group partials written by the producing convolution (i2v_gemm_params.gn_partial) --
+     fp32 [n_img][hw / gpartial_rows][groups][2]; the statistics pass over x is skipped.  frames_per_stat 1, no out_perm, no x2. */
+  const void* gpartial_in; int32_t gpartial_rows;
 } i2v_gn_params;
 
 int64_t i2v_groupnorm_workspace_bytes(int32_t n_img, int32_t hw, int32_t channels);

@@ -260,9 +260,20 @@ def test_full_width_resnet(dev, cin, cout, hw):
     n = 32 if hw <= 16 else 8
     x = h(torch.randn(n, cin, hw, hw, generator=g))
     temb = h(torch.randn(n, 1280, generator=g))
+    from i2v_adapter_unofficial_amd import blocks
     with torch.no_grad():
-        compare(m(x.half().to(dev), temb.half().to(dev)), o(x, temb), rel=MODULE_REL_TOL,
-                name=f"full-width ResnetBlock2D {cin}->{cout} {hw}x{hw}")
+        ref = o(x, temb)
+        got = m(x.half().to(dev), temb.half().to(dev))
+        compare(got, ref, rel=MODULE_REL_TOL, name=f"full-width ResnetBlock2D {cin}->{cout} {hw}x{hw}")
+        # norm2's statistics from conv1's epilogue (default where the form exists) against the norm's own statistics pass
+        assert blocks.GN_FROM_CONV
+        blocks.GN_FROM_CONV = False
+        try:
+            own = m(x.half().to(dev), temb.half().to(dev))
+        finally:
+            blocks.GN_FROM_CONV = True
+        compare(own, ref, rel=MODULE_REL_TOL, name=f"full-width ResnetBlock2D, norm2 with its own statistics pass {cin}->{cout}")
+        compare(got, own, rel=MODULE_REL_TOL, name=f"ResnetBlock2D statistics from the epilogue vs own pass {cin}->{cout}")
 
 
 # ------------------------------------------------------------------------------------------------ full-size properties

@@ -879,6 +879,51 @@ def test_groupnorm(dev, n, hh, ww, c1, c2, groups, fps, silu, perm):
     _groupnorm_case(dev, n, hh, ww, c1, c2, groups, fps, silu, perm, mean=0.5, std=2.0)
 
 
+@pytest.mark.parametrize("n,hh,cin,cout,mean", [(16, 32, 320, 320, 0.0), (4, 64, 320, 320, 3.0), (32, 32, 640, 640, 0.5), (32, 32, 320, 640, -2.0),
+                                                 (32, 16, 320, 1280, 0.0)])
+def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, hh, cin, cout, mean):
+    """conv1 -> norm2 of ResnetBlock2D (unet:203-214): the convolution's epilogue writes the GroupNorm partials of its result
+    (i2v_gemm_params.gn_partial: per image, row tile and group the mean and M2 of the fp32 accumulators + bias + time-embedding
+    row), the norm skips its statistics pass (i2v_gn_params.gpartial_in).  Against fp32 torch on the convolution's own fp16
+    output, and against the norm's statistics pass on the same tensor.  A large per-channel offset (bias + time embedding `mean`
+    standard deviations away) must not cost digits: the column constants never enter the sums of squares."""
+    k = K()
+    g = torch.Generator().manual_seed(n + hh + cout)
+    x = h(torch.randn(n, cin, hh, hh, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = h(torch.randn(cout, generator=g) * 0.3 + mean * 10)
+    tv = h(torch.randn(2, cout, generator=g) + mean * 10)
+    ga, be = h(1 + 0.3 * torch.randn(cout, generator=g)), h(0.3 * torch.randn(cout, generator=g))
+    D = lambda t: t.half().to(dev)
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    wp = _pack_conv(w).to(dev)
+    rpv = (n // 2) * hh * hh
+    out, st = k.conv3x3(xt, wp, D(b), rowvec=D(tv), rows_per_vec=rpv, gn_stats_groups=32)
+    plain = k.conv3x3(xt, wp, D(b), rowvec=D(tv), rows_per_vec=rpv)
+    assert torch.equal(out, plain), "the statistics must not change the convolution's result"
+    assert st is not None, "an un-split 3x3 convolution of whole row tiles writes the partials"
+    part, rows = st
+    assert rows in (128, 256) and tuple(part.shape) == (n, hh * hh // rows, 32, 2) and torch.isfinite(part).all()
+    y = k.groupnorm(out, D(ga), D(be), 32, 1e-6, silu=True, stats=st)
+    ref = F.silu(F.group_norm(out.float().cpu().permute(0, 3, 1, 2), 32, ga, be, eps=1e-6)).permute(0, 2, 3, 1)
+    close(y, ref, rel=2e-3, name="GroupNorm from the convolution's partials vs fp32 torch")
+    close(y, k.groupnorm(out, D(ga), D(be), 32, 1e-6, silu=True), rel=2e-3, name="... vs the norm's own statistics pass")
+    # the merged statistics themselves: mean and variance per (image, group) from the partials against torch on the fp16 output
+    cpg = cout // 32
+    xo = out.float().cpu().view(n, hh * hh, 32, cpg)
+    mean_ref, var_ref = xo.mean(dim=(1, 3)), xo.var(dim=(1, 3), unbiased=False)
+    pm, pm2 = part[..., 0].cpu().double(), part[..., 1].cpu().double()
+    mean_got = pm.mean(dim=1)
+    var_got = (pm2.sum(dim=1) + (rows * cpg) * ((pm - mean_got[:, None]) ** 2).sum(dim=1)) / (hh * hh * cpg)
+    assert (mean_got - mean_ref).abs().max() < 2e-3 * (1 + mean_ref.abs().max()), "group means from the partials"
+    assert ((var_got - var_ref).abs() / var_ref).max() < 5e-3, "group variances from the partials"
+    # where the form does not exist (a convolution that splits K, a residual epilogue) the caller is told so
+    small = k.conv3x3(xt[:1, :8, :8].contiguous(), wp, D(b), gn_stats_groups=32)
+    assert small[1] is None and tuple(small[0].shape) == (1, 8, 8, cout)
+    with pytest.raises(ValueError, match="stats"):
+        k.groupnorm(out, D(ga), D(be), 32, 1e-6, silu=True, stats=(part[:, :1].contiguous(), rows))
+
+
 @pytest.mark.parametrize("mean,std", [(30.0, 0.5), (-200.0, 1.0), (1000.0, 4.0)])
 def test_groupnorm_large_mean(dev, mean, std):
     """|mean| >> std (real SD activations have such channels): the statistics must not lose their digits to
