@@ -42,6 +42,10 @@ HBM_PEAK_GBPS = 8000.0
 # max-abs error of the HIP CFG forward against the fp32 CPU oracle above which the run is a FAILURE (exit code 3):
 # tests/test_full_width_gpu.py FWD_ABS_TOL
 PARITY_ABS_TOL = 4.0e-3
+# ... and its RMS error: the maximum over 524 288 outputs is an extreme-value statistic that wanders +- 15 % between equivalent
+# rounding patterns, the RMS is stable to 1 % (3.6 - 3.7e-4 on the config-2 forward since round 3) -- the gate that catches a real
+# numerical regression
+PARITY_RMS_TOL = 4.5e-4
 
 SD15 = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
             layers_per_block=2, cross_attention_dim=768, num_attention_heads=8, norm_num_groups=32,
@@ -128,9 +132,16 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev, n_forwards=3):
                 ref = ou(x, t, True, ctx, added_cond_kwargs=added).sample
                 times.append(time.time() - t0)
             dt = sorted(times)[len(times) // 2]
-            from i2v_adapter_unofficial_amd import pipeline_i2v_adapter as pl
-            got = model(x.to(dev), t.to(dev), True, ctx.to(dev), added_cond_kwargs=added_d,
-                        cross_attention_kwargs={"cfg_shared_prefix": pl.CFG_SHARED}).sample.float().cpu()
+            from i2v_adapter_unofficial_amd import blocks as hblocks, pipeline_i2v_adapter as pl
+            fwd = lambda: model(x.to(dev), t.to(dev), True, ctx.to(dev), added_cond_kwargs=added_d,
+                                cross_attention_kwargs={"cfg_shared_prefix": pl.CFG_SHARED}).sample.float().cpu()
+            got = fwd()
+            # the same forward in the OTHER residual-stream mode (blocks.set_precise_stream), against the same oracle forward
+            prev = hblocks.set_precise_stream(not hblocks.precise_stream())
+            try:
+                got_other = fwd()
+            finally:
+                hblocks.set_precise_stream(prev)
     finally:
         oblocks.Attention._sdpa = orig
     err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
@@ -145,6 +156,11 @@ def cpu_baseline_and_parity(model, ip_sd, frames, h_lat, dev, n_forwards=3):
               "rms_err": (got - ref).pow(2).mean().sqrt().item(), "rms_ref": ref.pow(2).mean().sqrt().item(),
               "what": ("HIP UNet forward of the CFG batch [latents ; latents] x [negative ; positive prompt], routed as the "
                        "timed step routes it, vs the fp32 CPU oracle forward timed above (same weights, same inputs)")}
+    mode = lambda on: "precise" if on else "default"
+    d_o = got_other - ref
+    parity["stream_mode"] = mode(hblocks.precise_stream())
+    parity["other_stream_mode"] = {"stream_mode": mode(not hblocks.precise_stream()), "max_abs_err": d_o.abs().max().item(),
+                                   "rms_err": d_o.pow(2).mean().sqrt().item()}
     return base, parity
 
 
@@ -415,6 +431,10 @@ def main():
                     help="no timing: ONE CFG UNet forward of this workload (--frames / --size / --ip) through the HIP model and "
                          "through the CPU oracle on the same weights and inputs, one JSON line with the errors (builder-run: "
                          "minutes of host time at 32 f x 768^2; profiles/r5_parity_configs.jsonl)")
+    ap.add_argument("--precise", action="store_true",
+                    help="time the step with the PRECISE residual stream (fp16 hi + lo pairs between the modules, DESIGN 2.1; "
+                         "blocks.set_precise_stream); without it the default single-GPU run times the default stream and adds "
+                         "the precise mode's ms_per_step and parity beside it (`stream_modes`)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-rank plumbing on a box WITHOUT GPUs: launcher, rendezvous, gloo group, flat "
                          "weight broadcast, pair sharding, timed loop with a stub step, MAX all-reduce, JSON line "
@@ -439,7 +459,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import i2v_adapter_unofficial_amd as pkg
+    from i2v_adapter_unofficial_amd import blocks as hblocks
     from i2v_adapter_unofficial_amd.profiling import KernelProfile
+    if args.precise:
+        hblocks.set_precise_stream(True)
     from i2v_adapter_unofficial_amd.sharding import broadcast_model_weights
 
     # ---- weights: rank 0 draws them on its GPU, one flat RCCL broadcast to the other ranks
@@ -471,8 +494,8 @@ def main():
         threading.Thread(target=heartbeat, daemon=True).start()
         base, parity = cpu_baseline_and_parity(model, ip_sd, args.frames, args.size // 8, dev, n_forwards=1)
         done.set()
-        parity["tolerance"] = PARITY_ABS_TOL
-        parity["parity_ok"] = bool(parity["max_abs_err"] <= PARITY_ABS_TOL)
+        parity["tolerance"], parity["rms_tolerance"] = PARITY_ABS_TOL, PARITY_RMS_TOL
+        parity["parity_ok"] = bool(parity["max_abs_err"] <= PARITY_ABS_TOL and parity["rms_err"] <= PARITY_RMS_TOL)
         print(json.dumps({"parity_only": True, "workload": f"{args.frames}f x {args.size}x{args.size}, CFG batch (B = 2), IP "
                           f"{'on' if ip else 'off'}, SD-1.5 width", "parity": parity, "cpu_oracle": base,
                           "library_source_stamp": source_stamp()}), flush=True)
@@ -598,14 +621,39 @@ def main():
                     roof["peak_measured_source"] = f"profiles/{name} (MFMA-saturating loop / stream copy, this pool)"
                     break
 
+        # ---- the OTHER residual-stream mode, timed the same way over two windows (default single-GPU run only): the line
+        #      carries ms_per_step and parity of both modes
+        other_mode = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_graph:
+            prev = hblocks.set_precise_stream(not hblocks.precise_stream())
+            try:
+                load_group(groups[0])
+                pipe._step(st)
+                load_group(groups[0])
+                torch.cuda.synchronize()
+                graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph2):
+                    pipe._step(st)
+                load_group(groups[0])
+                for _ in range(args.warmup):
+                    graph2.replay()
+                w2 = run_windows(groups, args.steps, 2, n_tab, load_group, graph2.replay, lambda: st["step_idx"].zero_(),
+                                 torch.cuda.synchronize, world, dev)
+                other_mode = {"stream_mode": "precise" if hblocks.precise_stream() else "default",
+                              "ms_per_step": min(w2) / (len(groups) * args.steps) * 1e3,
+                              "finite": bool(torch.isfinite(st["latents"]).all().item())}
+                graph2 = None
+            finally:
+                hblocks.set_precise_stream(prev)
+
     used_graph = graph is not None
     graph = None
     t_gpu_done = time.time()
     cpu_base, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base, parity = cpu_baseline_and_parity(model, ip_sd, F, h_lat, dev, n_forwards=args.cpu_forwards)
-        parity["tolerance"] = PARITY_ABS_TOL
-        parity["parity_ok"] = bool(parity["max_abs_err"] <= PARITY_ABS_TOL)
+        parity["tolerance"], parity["rms_tolerance"] = PARITY_ABS_TOL, PARITY_RMS_TOL
+        parity["parity_ok"] = bool(parity["max_abs_err"] <= PARITY_ABS_TOL and parity["rms_err"] <= PARITY_RMS_TOL)
         if not parity["parity_ok"]:
             print(f"# PARITY FAILURE: {parity}", file=sys.stderr)
     if rank == 0:
@@ -627,6 +675,17 @@ def main():
                     "configs[0] shape" if (F, args.size) == (8, 256) else
                     "configs[2]" if ip and (F, args.size) == (16, 512) else
                     "configs[1]" if (F, args.size) == (16, 512) else "no BASELINE config")
+        # both residual-stream modes side by side: ms_per_step (this line's `ms_per_step` is the timed mode's median window; the other
+        # mode's is the faster of two windows) and the forward's error against the oracle
+        this_mode = "precise" if hblocks.precise_stream() else "default"
+        stream_modes = {this_mode: {"ms_per_step": ms, "timed": f"median of {len(windows)} windows"}}
+        if parity is not None:
+            stream_modes[this_mode].update(max_abs_err=parity["max_abs_err"], rms_err=parity["rms_err"])
+        if other_mode is not None:
+            om = {"ms_per_step": other_mode["ms_per_step"], "timed": "faster of 2 windows", "finite": other_mode["finite"]}
+            if parity is not None:
+                om.update(max_abs_err=parity["other_stream_mode"]["max_abs_err"], rms_err=parity["other_stream_mode"]["rms_err"])
+            stream_modes[other_mode["stream_mode"]] = om
         out = {
             "metric": ("denoising steps/sec @ 16fx512x512 SD1.5+I2V-Adapter" if (F, args.size) == (16, 512) else
                        f"denoising steps/sec @ {F}fx{args.size}x{args.size} SD1.5+I2V-Adapter"), "value": value,
@@ -647,7 +706,7 @@ def main():
                                               "time_proj -> time_embedding -> silu -> 22 time_emb_proj for all timesteps of the schedule"],
                        "samples_total": n_pairs_total, "samples_per_replay": B, "graph": used_graph, "finite": finite,
                        "unet_forwards_per_cfg_half_per_sec": 2 * value,
-                       "cfg_shared_prefix": bool(pl.CFG_SHARED),
+                       "cfg_shared_prefix": bool(pl.CFG_SHARED), "residual_stream": this_mode,
                        "step_tflops": None if step_flops is None else step_flops / 1e12,
                        "executed_tflops_per_step": None if exec_flops is None else exec_flops / 1e12,
                        "achieved_tflops_per_gpu": None if rate_flops is None else
@@ -655,6 +714,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu_base,
             "parity": parity,
+            "stream_modes": stream_modes,
             "kernel_classes": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                                for k, v in (classes or {}).items()},
         }

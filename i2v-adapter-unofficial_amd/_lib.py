@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # I2V_LIB_PATH selects another build of the same ABI (same-box A/B of two kernels, tools/ab_bench.sh); the in-tree
 # library is never overwritten by tooling
 LIB_PATH = os.environ.get("I2V_LIB_PATH") or os.path.join(_HERE, "libi2v_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 I2V_EPI_NONE, I2V_EPI_GELU, I2V_EPI_GEGLU = 0, 1, 2
 I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM, I2V_STORE_VT, I2V_STORE_VT_T = 0, 1, 2, 3
@@ -45,6 +45,7 @@ class GemmParams(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("c_is_f32", C.c_int32),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
+        ("residual_lo", C.c_void_p), ("c_lo", C.c_void_p),
     ]
 
 
@@ -133,6 +134,7 @@ class FfFusedParams(C.Structure):
         ("w3", C.c_void_p), ("b3", C.c_void_p),
         ("res2", C.c_void_p), ("ld_res2", C.c_int64),
         ("perm_frames", C.c_int32), ("perm_hw", C.c_int32),
+        ("res2_lo", C.c_void_p), ("out_lo", C.c_void_p),
     ]
 
 

@@ -286,6 +286,27 @@ class TimestepEmbedding(HipModule):
         return K.gemm(h, p["w2"], p["b2"])
 
 
+# ---------------------------------------------------------------------------------------------------------- precise stream
+# The residual stream BETWEEN modules (outputs of conv_in, every ResnetBlock2D, spatial transformer, motion module and sampler) as
+# an fp16 pair hi + lo (kernels.lo_of; i2v_gemm_params.residual_lo / c_lo): the identity path of every module's residual add is
+# then exact to 2^-22 instead of re-rounding the stream to fp16 at each of the 66 modules, which alone is 1.36e-3 max-abs /
+# 0.78 of the 0.89e-3 relative rms of the config-2 forward (pipe:666-697 runs the reference's CPU path in fp32).
+# What a module's branch reads as an MFMA / norm operand stays the fp16 high half.  OFF by default: +4 bytes of traffic per stream
+# element and module; `set_precise_stream(True)` / I2V_STREAM_PRECISE=1 (a captured hipGraph keeps the mode it was captured in).
+_PRECISE_STREAM = os.environ.get("I2V_STREAM_PRECISE", "0") != "0"
+
+
+def precise_stream() -> bool:
+    return _PRECISE_STREAM
+
+
+def set_precise_stream(on: bool) -> bool:
+    """switch the precise residual stream on / off for forwards issued from now on; returns the previous setting"""
+    global _PRECISE_STREAM
+    prev, _PRECISE_STREAM = _PRECISE_STREAM, bool(on)
+    return prev
+
+
 # ---------------------------------------------------------------------------------------------------------- A2/A3
 # norm2's GroupNorm statistics written by conv1's epilogue (i2v_gemm_params.gn_partial) instead of a pass over conv1's output
 GN_FROM_CONV = os.environ.get("I2V_GN_FROM_CONV", "1") != "0"
@@ -339,7 +360,7 @@ class ResnetBlock2D(HipModule):
             if self.conv_shortcut is not None:
                 with fk.side():
                     a2 = None if x2 is None else x2.view(-1, x2.shape[3])
-                    s = K.gemm(x.view(-1, c1), p["ws"], p["bs"], a2=a2).view(n, hh, ww, self.out_channels)
+                    s = K.sview(K.gemm(x.view(-1, c1), p["ws"], p["bs"], a2=a2, precise=precise_stream()), n, hh, ww, self.out_channels)
             h = K.groupnorm(x, p["g1"], p["b1"], self.groups, self.eps, x2=x2, silu=True)
             rowvec, rpv = None, 0
             if self.time_emb_proj is not None and temb_act is not None:
@@ -352,7 +373,7 @@ class ResnetBlock2D(HipModule):
             else:
                 h, st = K.conv3x3(h, p["w1"], p["cb1"], rowvec=rowvec, rows_per_vec=rpv), None
             h = K.groupnorm(h, p["g2"], p["b2"], self.groups, self.eps, silu=True, stats=st)
-        return K.conv3x3(h, p["w2"], p["cb2"], residual=s, out_scale=1.0 / self.output_scale_factor)
+        return K.conv3x3(h, p["w2"], p["cb2"], residual=s, out_scale=1.0 / self.output_scale_factor, precise=precise_stream())
 
     def forward(self, input_tensor, temb, scale: float = 1.0):
         x = to_tokens(input_tensor)
@@ -377,7 +398,7 @@ class Downsample2D(HipModule):
 
     def _fwd(self, x):
         p = self.packed()
-        return K.conv3x3(x, p["w"], p["b"], stride=2, asym_pad=self.padding == 0)
+        return K.conv3x3(x, p["w"], p["b"], stride=2, asym_pad=self.padding == 0, precise=precise_stream())
 
     def forward(self, hidden_states, scale: float = 1.0):
         return from_tokens(self._fwd(to_tokens(hidden_states)), hidden_states.dtype)
@@ -401,7 +422,7 @@ class Upsample2D(HipModule):
             raise NotImplementedError("Upsample2D: only exact 2x nearest upsampling is implemented "
                                       "(latent sizes must be divisible by 2**num_upsamplers)")
         p = self.packed()
-        return K.conv3x3(x, p["w"], p["b"], upsample=True)
+        return K.conv3x3(x, p["w"], p["b"], upsample=True)          # (read by conv_shortcut resnets only: no low half needed)
 
     def forward(self, hidden_states, output_size=None, scale: float = 1.0):
         return from_tokens(self._fwd(to_tokens(hidden_states), output_size), hidden_states.dtype)
@@ -605,7 +626,7 @@ class FeedForward(HipModule):
         """x + FF(LayerNorm(x)) in one launch: the inner activation never leaves the CU.  `tail` (see `tail_supported`): the
         Linear that follows the block -- the spatial transformer's / the motion module's proj_out with its residual -- in the
         same launch."""
-        return K.ff_fused(x2d, gamma32, beta32, self.packed()["fused"], eps=eps, tail=tail)
+        return K.ff_fused(x2d, gamma32, beta32, self.packed()["fused"], eps=eps, tail=tail, precise=precise_stream())
 
     def tail_supported(self, x2d, tail):
         """tail = (pack_ff_tail(w, b), residual rows in output order, perm_frames, perm_hw): can the fused launch take it?"""
@@ -839,14 +860,14 @@ class TransformerTemporalModel(HipModule):
         applied = False
         for j, blk in enumerate(self.transformer_blocks):
             if j + 1 == len(self.transformer_blocks):
-                t, applied = blk._fwd(t, n_pixels, num_frames, tail=(p["tail"], x.view(-1, c), num_frames, hh * ww))
+                t, applied = blk._fwd(t, n_pixels, num_frames, tail=(p["tail"], K.sview(x, -1, c), num_frames, hh * ww))
             else:
                 t = blk._fwd(t, n_pixels, num_frames)
         if applied:                                                         # proj_out + residual ran inside the feed-forward
-            return t.view(n, hh, ww, c)
-        out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c), store=I2V_STORE_ROWPERM, frames=num_frames,
-                     hw=hh * ww)                                            # rows back in (b, frame, pixel)
-        return out.view(n, hh, ww, c)
+            return K.sview(t, n, hh, ww, c)
+        out = K.gemm(t, p["wo"], p["bo"], residual=K.sview(x, -1, c), store=I2V_STORE_ROWPERM, frames=num_frames,
+                     hw=hh * ww, precise=precise_stream())                  # rows back in (b, frame, pixel)
+        return K.sview(out, n, hh, ww, c)
 
     def forward(self, hidden_states, encoder_hidden_states=None, num_frames: int = 1, return_dict=False, **_unused):
         return (from_tokens(self._fwd(to_tokens(hidden_states), num_frames), hidden_states.dtype),)

@@ -140,7 +140,7 @@ int i2v_conv_thin_try(const i2v_gemm_params& p, hipStream_t s) {
   if (off || p.a_mode != I2V_A_CONV3X3 || p.N > CT_MAXCOUT || p.stride != 1 || p.upsample || p.asym_pad) return 0;
   if (p.cin % CT_CB != 0 || (p.conv_kblock != 0 && p.conv_kblock != 64) || p.in_h % CT_TH != 0 || p.in_w % CT_TW != 0) return 0;
   if (p.epilogue != I2V_EPI_NONE || p.store_mode != I2V_STORE_ROWMAJOR || p.residual || p.rowvec || p.ln_wsum || p.rows_per_w > 0 ||
-      p.a_perm_frames > 0 || p.a2)
+      p.a_perm_frames > 0 || p.a2 || p.residual_lo || p.c_lo)
     return 0;
   if ((int64_t)p.in_h * p.in_w * p.lda >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.c) & (p.c_is_f32 ? 15 : 7)) != 0) return 0;
   const size_t lds = 2 * (size_t)CT_HH * CT_HW * CT_PS + (size_t)p.N * 9 * p.cin * sizeof(f16);

@@ -52,10 +52,13 @@ constexpr int FF_U = 2;                // W1 tiles per wave and chunk: a panel f
 constexpr int FF_PD = 3;               // W1 fragments in flight (K steps ahead)
 constexpr int FF_AD = 4;               // panel fragments in flight
 
-template <int C, int INNER, int H, bool PROJ>
+// HILO (PROJ only; i2v_ff_fused_params.res2_lo / out_lo): the module's residual stream as an fp16 pair -- the low halves of the outer
+// residual rows are added with the high ones and the low half of the result is stored beside it (see i2v_gemm_params.residual_lo).
+template <int C, int INNER, int H, bool PROJ, bool HILO = false>
 __global__ __launch_bounds__(64 * H) void ff_fused_kernel(const i2v_ff_fused_params p, const int ntiles, long long* __restrict__ stamps) {
   constexpr int KS = C / 32, NJ = C / 64, NCH = INNER / FF_CH, DN = C / H, DT = (DN + 15) / 16;
   static_assert(C % 64 == 0 && H == 8 && INNER % FF_CH == 0 && DT == 3 && DN == 40, "SD-1.5 64^2 level: C = 320, inner = 1280");
+  static_assert(PROJ || !HILO, "the precise stream enters and leaves through the tail");
   extern __shared__ __attribute__((aligned(16))) f16 lds[];
   f16* panel = lds;                                   // [128][C], 16-byte chunk index ^= row & 7
   f16* hbuf = lds + FF_PIX * 16 * C;                  // 2 x [128][128], 16-byte chunk index ^= row & 15
@@ -379,6 +382,22 @@ __global__ __launch_bounds__(64 * H) void ff_fused_kernel(const i2v_ff_fused_par
           r2[h][q] = (eg == 0) ? *reinterpret_cast<const u32x4*>(rrow + 32) : u32x4{0u, 0u, 0u, 0u};
         }
       };
+      // HILO: the low halves of the same rows, four rows at a time after the projection (all eight held beside the accumulators and
+      // the high halves spilled 60 registers): the second four are requested when the first four rows have been stored -- one
+      // exposed round trip per tile
+      const f16* __restrict__ R2L = reinterpret_cast<const f16*>(HILO ? p.res2_lo : p.res2) + wave * DN;
+      f16* __restrict__ OL = reinterpret_cast<f16*>(HILO ? p.out_lo : p.out) + wave * DN;
+      u32x4 l01[HP], l2[HP];
+      auto load_res2_lo = [&](const int h) {
+        if constexpr (HILO) {
+#pragma unroll
+          for (int q = 0; q < HP; ++q) {
+            const f16* rrow = R2L + (int64_t)orow[h * HP + q] * p.ld_res2;
+            l01[q] = *reinterpret_cast<const u32x4*>(rrow + c01);
+            l2[q] = (eg == 0) ? *reinterpret_cast<const u32x4*>(rrow + 32) : u32x4{0u, 0u, 0u, 0u};
+          }
+        }
+      };
       out_rows(tile, el15, orow);
       // the block's output y = x + FF(LayerNorm(x)), rounded to fp16 as the un-fused kernel stores it, replaces x in the panel
       // in place (each wave touches its own 40 channels only)
@@ -443,8 +462,13 @@ __global__ __launch_bounds__(64 * H) void ff_fused_kernel(const i2v_ff_fused_par
       }
       FF_T(t_p);
       load_res2(1);       // (all 16 loads held across the projection's tail spilled 100 registers)
+      load_res2_lo(0);
 #pragma unroll
       for (int pix = 0; pix < FF_PIX; ++pix) {
+        if (pix == HP) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_res2_lo(1);
+        }
         // the same v_permlane16_swap that assembles the stores takes the residual's 16-byte pieces apart (it is its own inverse)
         const u32x4 q01 = r01[pix / HP][pix % HP], q2 = r2[pix / HP][pix % HP];
         u32x2 xa = {q01[0], q01[1]}, xb = {q01[2], q01[3]}, xc = {q2[0], q2[1]}, xd = {q2[2], q2[3]};
@@ -452,15 +476,38 @@ __global__ __launch_bounds__(64 * H) void ff_fused_kernel(const i2v_ff_fused_par
                      "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
                      : "+v"(xa[0]), "+v"(xb[0]), "+v"(xa[1]), "+v"(xb[1]), "+v"(xc[0]), "+v"(xd[0]), "+v"(xc[1]), "+v"(xd[1]));
         const f16x4 xres[DT] = {__builtin_bit_cast(f16x4, xa), __builtin_bit_cast(f16x4, xb), __builtin_bit_cast(f16x4, xc)};
-        u32x2 oh[DT];
+        f16x4 xlo[DT] = {};
+        if constexpr (HILO) {
+          const u32x4 p01 = l01[pix % HP], p2 = l2[pix % HP];
+          u32x2 la = {p01[0], p01[1]}, lb = {p01[2], p01[3]}, lc = {p2[0], p2[1]}, ld = {p2[2], p2[3]};
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                       "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+                       : "+v"(la[0]), "+v"(lb[0]), "+v"(la[1]), "+v"(lb[1]), "+v"(lc[0]), "+v"(ld[0]), "+v"(lc[1]), "+v"(ld[1]));
+          xlo[0] = __builtin_bit_cast(f16x4, la);
+          xlo[1] = __builtin_bit_cast(f16x4, lb);
+          xlo[2] = __builtin_bit_cast(f16x4, lc);
+        }
+        u32x2 oh[DT], ol[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
           f32x4 o = acc3[pix][t];
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] += (float)xres[t][r];
-          oh[t] = __builtin_bit_cast(u32x2, to_half(o));
+          if constexpr (HILO) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += (float)xlo[t][r];
+          }
+          const f16x4 o16 = to_half(o);
+          oh[t] = __builtin_bit_cast(u32x2, o16);
+          if constexpr (HILO) {
+            f32x4 d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = o[r] - (float)o16[r];
+            ol[t] = __builtin_bit_cast(u32x2, to_half(d));
+          }
         }
         store_row(O + (int64_t)orow[pix] * p.ldo, oh);
+        if constexpr (HILO) store_row(OL + (int64_t)orow[pix] * p.ldo, ol);
       }
     }
     lds_barrier();            // the panel is free for the next tile's normalised rows
@@ -478,8 +525,8 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 constexpr size_t FF_LDS = 2 * (size_t)FF_PIX * 16 * 320 * sizeof(f16);      // panel + (chunk buffers | raw rows): 160 KB
 
-template <bool PROJ>
-int ff_cus() { return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(ff_fused_kernel<320, 1280, 8, PROJ>), FF_LDS); }
+template <bool PROJ, bool HILO = false>
+int ff_cus() { return i2v_big_lds_kernel_cus(reinterpret_cast<const void*>(ff_fused_kernel<320, 1280, 8, PROJ, HILO>), FF_LDS); }
 
 }  // namespace
 
@@ -519,11 +566,14 @@ extern "C" int i2v_ff_fused_f16(const i2v_ff_fused_params* pp, i2v_stream_t stre
                   "i2v_ff_fused_f16: perm_frames %d / perm_hw %d do not describe rows %lld (i2v_ff_fused_tail_supported)", p.perm_frames,
                   p.perm_hw, (long long)p.rows);
     I2V_CHECK_ARG(!(p.perm_frames > 0 && p.out == p.x), "i2v_ff_fused_f16: out must not alias x when the tail permutes the rows");
+    I2V_CHECK_ARG((p.res2_lo == nullptr) == (p.out_lo == nullptr) && al16(p.res2_lo) && al16(p.out_lo) && (p.out_lo == nullptr || p.out_lo != p.out),
+                  "i2v_ff_fused_f16: res2_lo and out_lo come together, 16-byte aligned");
   } else {
-    I2V_CHECK_ARG(p.b3 == nullptr && p.res2 == nullptr && p.perm_frames == 0 && p.perm_hw == 0,
+    I2V_CHECK_ARG(p.b3 == nullptr && p.res2 == nullptr && p.perm_frames == 0 && p.perm_hw == 0 && p.res2_lo == nullptr && p.out_lo == nullptr,
                   "i2v_ff_fused_f16: tail fields set without w3");
   }
-  const int cus = tail ? ff_cus<true>() : ff_cus<false>();
+  const bool hilo = tail && p.out_lo != nullptr;
+  const int cus = hilo ? ff_cus<true, true>() : tail ? ff_cus<true>() : ff_cus<false>();
   if (cus <= 0) I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_ff_fused_f16: %zu bytes of LDS refused by this device", FF_LDS);
   const int ntiles = (int)(p.rows / (FF_PIX * 16));
   const int grid = i2v_persistent_grid(ntiles, cus);
@@ -532,7 +582,9 @@ extern "C" int i2v_ff_fused_f16(const i2v_ff_fused_params* pp, i2v_stream_t stre
   stamps = getenv("I2V_FF_STAMP_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("I2V_FF_STAMP_PTR"), nullptr, 0)) : nullptr;
 #endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (tail)
+  if (hilo)
+    hipLaunchKernelGGL((ff_fused_kernel<320, 1280, 8, true, true>), dim3((unsigned)grid), dim3(512), FF_LDS, s, p, ntiles, stamps);
+  else if (tail)
     hipLaunchKernelGGL((ff_fused_kernel<320, 1280, 8, true>), dim3((unsigned)grid), dim3(512), FF_LDS, s, p, ntiles, stamps);
   else
     hipLaunchKernelGGL((ff_fused_kernel<320, 1280, 8, false>), dim3((unsigned)grid), dim3(512), FF_LDS, s, p, ntiles, stamps);

@@ -212,6 +212,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
     const f16* rv = rowvec ? rowvec + (int64_t)(p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : m / p.rows_per_vec) * p.ld_rowvec
                            : nullptr;
     const f16* rs = resid ? resid + m_out * p.ldr : nullptr;
+    // the precise residual stream (i2v_gemm_params.residual_lo / c_lo)
+    const f16* rl = (resid && p.residual_lo) ? reinterpret_cast<const f16*>(p.residual_lo) + m_out * p.ldr : nullptr;
+    f16* cl = p.c_lo ? reinterpret_cast<f16*>(p.c_lo) + m_out * p.ldc : nullptr;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int n = n0 + wn * WN + i * 16 + g * 4;
@@ -232,6 +235,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
           const f16x4 r4 = *reinterpret_cast<const f16x4*>(rs + n);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
+          if (rl) {
+            const f16x4 l4 = *reinterpret_cast<const f16x4*>(rl + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)l4[r];
+          }
         }
       } else {
 #pragma unroll
@@ -240,6 +248,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
             if (bias) v[r] += (float)bias[n + r];
             if (rv) v[r] += (float)rv[n + r];
             if (rs) v[r] += (float)rs[n + r];
+            if (rl) v[r] += (float)rl[n + r];
           }
         }
       }
@@ -297,10 +306,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
         if (vec4) {
           f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
           *reinterpret_cast<f16x4*>(dst) = o;
+          if (cl) *reinterpret_cast<f16x4*>(cl + n) = f16x4{lo_half(v[0], o[0]), lo_half(v[1], o[1]), lo_half(v[2], o[2]), lo_half(v[3], o[3])};
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n + r < N) dst[r] = (f16)v[r];
+            if (n + r < N) {
+              dst[r] = (f16)v[r];
+              if (cl) cl[n + r] = lo_half(v[r], (f16)v[r]);
+            }
         }
       }
     }
@@ -330,6 +343,7 @@ int vector_epilogue_ok(const i2v_gemm_params& p) {
   int vec4 = (p.N % 4 == 0) ? 1 : 0;
   if (p.bias && !aligned_to(p.bias, 8)) vec4 = 0;
   if (p.residual && (!aligned_to(p.residual, 8) || p.ldr % 4 != 0)) vec4 = 0;
+  if ((p.residual_lo && !aligned_to(p.residual_lo, 8)) || (p.c_lo && !aligned_to(p.c_lo, 8))) vec4 = 0;
   if (p.rowvec && (!aligned_to(p.rowvec, 8) || p.ld_rowvec % 4 != 0)) vec4 = 0;
   if (p.store_mode == I2V_STORE_VT) {
     if (p.vt_len % 4 != 0 || p.vt_ld % 4 != 0 || !aligned_to(p.c, 8)) vec4 = 0;
@@ -421,6 +435,12 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     I2V_CHECK_ARG(p.c_is_f32 == 1 && p.epilogue != I2V_EPI_GEGLU && p.store_mode == I2V_STORE_ROWMAJOR && p.ln_wsum == nullptr &&
                       p.rows_per_w == 0 && p.a_perm_frames == 0 && p.N <= 64 && aligned_to(p.c, 4),
                   "i2v_gemm_f16: an fp32 result (c_is_f32) is a row-major store of a narrow (N <= 64), plain problem");
+  if (p.residual_lo || p.c_lo) {
+    I2V_CHECK_ARG(p.residual_lo == nullptr || p.residual != nullptr, "i2v_gemm_f16: residual_lo needs residual");
+    I2V_CHECK_ARG(p.epilogue == I2V_EPI_NONE && (p.store_mode == I2V_STORE_ROWMAJOR || p.store_mode == I2V_STORE_ROWPERM) && !p.c_is_f32 &&
+                      p.ln_wsum == nullptr && p.gn_partial == nullptr,
+                  "i2v_gemm_f16: the precise residual stream (residual_lo / c_lo) takes plain row-major / row-permuted fp16 stores only");
+  }
   if (p.rowvec) I2V_CHECK_ARG(p.rows_per_vec > 0 || p.rowvec_period > 0, "i2v_gemm_f16: rows_per_vec must be positive");
   if (p.store_mode == I2V_STORE_ROWPERM) {
     I2V_CHECK_ARG(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0,

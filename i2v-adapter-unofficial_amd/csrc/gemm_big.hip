@@ -102,7 +102,7 @@ __device__ __forceinline__ int big_lds_addr(int row, int kchunk) {
 // tile's prologue (first DMA wait) and epilogue (LayerNorm apply, GELU, transposes, stores: as long as the K loop itself
 // when K = 320) run beside the other tile's MFMAs instead of stopping the CU.
 template <int BM, int BK, int NS, int AMODE, int EPI, int STORE, bool SPLIT = false, bool STAGGER = true, bool LNF = false,
-          bool FAST = false, int BNT = 320, int NW = 8, bool GNS = false>
+          bool FAST = false, int BNT = 320, int NW = 8, bool GNS = false, bool HILO = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const i2v_gemm_params p, const int tiles_n,
                                                                             const int kps, const int ntiles) {
   static_assert(NS == 2 || (NS <= 4 && !FAST && !SPLIT && NW == 8),
@@ -742,8 +742,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
 #endif
     // (behind a folded LayerNorm the added operand can only be a small row-vector table that sits in L2: fetched at the top
     //  of its own block, under the block's LDS transpose, so the accumulator-bound LayerNorm kernels keep their registers)
-    constexpr int RES_AHEAD = LNF ? 0 : I2V_RES_AHEAD;
+    // HILO (i2v_gemm_params.residual_lo / c_lo, the precise residual stream): the low halves of the residual rows travel with
+    // the high ones (same offsets, a descriptor of size 0 when there is no residual_lo), one block ahead instead of three so that
+    // the two sets of prefetch registers together are what the one set was
+    constexpr int RES_AHEAD = LNF ? 0 : (HILO ? 1 : I2V_RES_AHEAD);
+    static_assert(!HILO || (!LNF && !GNS && EPI == I2V_EPI_NONE), "the precise stream is a plain row-major / row-permuted store");
+    const auto rs_xl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HILO && has_res && p.residual_lo ? p.residual_lo : p.c), 0,
+                                                         (HILO && has_res && p.residual_lo) ? (int)(((add_rows - 1) * add_ld + N) * 2) : 0, 0x00020000);
+    const auto rs_cl = __builtin_amdgcn_make_buffer_rsrc(HILO && p.c_lo ? p.c_lo : p.c, 0,
+                                                         (HILO && p.c_lo) ? (int)((((int64_t)M - 1) * p.ldc + n_out_cols) * 2) : 0, 0x00020000);
     f16x8 xpre[MI][QN];
+    f16x8 xlo[HILO ? MI : 1][QN];
     auto fetch_rows = [&](auto jc) {
       constexpr int j = decltype(jc)::value;
 #pragma unroll
@@ -754,6 +763,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
         if (!has_res) xrow = p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : fast_div(m, p.rows_per_vec > 0 ? p.rows_per_vec : 1, inv_rpv);
         const unsigned off = ok ? (unsigned)((xrow * add_ld + n) * 2) : EOOB;
         xpre[j][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+        if constexpr (HILO) xlo[j][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_xl, off, 0, 0));
       }
     };
     // (no residual behind a folded LayerNorm: those GEMMs feed q / k / v / the feed-forward; i2v_gemm_big_ln_ok refuses it)
@@ -885,6 +895,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
           if (has_add) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)xpre[j][q][e];
+            if constexpr (HILO) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)xlo[j][q][e];
+            }
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= oscale;
@@ -894,6 +908,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
         for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
         const unsigned off = ok ? (unsigned)((m_out * (int)p.ldc + n) * 2) : EOOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_c, off, 0, 0);
+        if constexpr (HILO) {       // what the rounding to o dropped (a descriptor of size 0 without c_lo: the store is dropped)
+          f16x8 ol;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ol[e] = (f16)(v[e] - (float)o[e]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), rs_cl, off, 0, 0);
+        }
       }
     });
 #if defined(I2V_PROBE) && I2V_PROBE == 5
@@ -999,6 +1019,10 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   const dim3 grid(FAST ? persistent_grid(ntiles) : ntiles), block(512);
 #define I2V_BIG_LAUNCH(EPI, STORE, LNF) \
   hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, EPI, STORE, false, true, LNF, FAST>), grid, block, 0, s, p, tiles_n, 0, ntiles)
+#define I2V_BIG_LAUNCH_HILO(STORE) \
+  hipLaunchKernelGGL((gemm_big_kernel<BM, BK, NS, AMODE, I2V_EPI_NONE, STORE, false, true, false, false, 320, 8, false, true>), grid, block, 0, s, \
+                     p, tiles_n, 0, ntiles)
+  const bool hilo = p.residual_lo != nullptr || p.c_lo != nullptr;      // (vetted by i2v_gemm_f16: EPI_NONE, row-major / row-permuted)
   if (p.ln_wsum != nullptr) {   // LayerNorm-folded epilogues (i2v_gemm_big_ln_ok has vetted the combination)
     if constexpr (AMODE == I2V_A_PLAIN) {
       if (p.epilogue == I2V_EPI_GEGLU)
@@ -1015,6 +1039,14 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
   }
   if (p.epilogue == I2V_EPI_GEGLU) {
     if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_GEGLU, I2V_STORE_ROWMAJOR, false);
+  } else if (hilo) {               // the precise residual stream (residual_lo / c_lo): plain row-major / row-permuted stores
+    if constexpr (!FAST) {
+      if (p.store_mode == I2V_STORE_ROWPERM) {
+        if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH_HILO(I2V_STORE_ROWPERM);
+      } else {
+        I2V_BIG_LAUNCH_HILO(I2V_STORE_ROWMAJOR);
+      }
+    }
   } else if (p.store_mode == I2V_STORE_ROWPERM) {
     if constexpr (AMODE == I2V_A_PLAIN) I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWPERM, false);
   } else if (p.store_mode == I2V_STORE_VT) {
@@ -1029,6 +1061,7 @@ int launch_big_mode(const i2v_gemm_params& p, hipStream_t s) {
     I2V_BIG_LAUNCH(I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false);
   }
 #undef I2V_BIG_LAUNCH
+#undef I2V_BIG_LAUNCH_HILO
   const int rc = i2v_check_launch("i2v_gemm_f16(big)");
   return rc < 0 ? rc : 1;
 }
@@ -1103,7 +1136,7 @@ template <int BM>
 int launch_big(const i2v_gemm_params& p, int vec4, hipStream_t s) {
   (void)vec4;
   if (p.a_mode == I2V_A_CONV3X3) return launch_big_mode<BM, 64, 2, I2V_A_CONV3X3, false>(p, s);
-  if (p.a2 == nullptr && p.M % BM == 0 && want_persistent(p) && persistent_grid(1 << 20) != (1 << 20))
+  if (p.a2 == nullptr && p.M % BM == 0 && want_persistent(p) && persistent_grid(1 << 20) != (1 << 20) && !p.residual_lo && !p.c_lo)
     return launch_big_mode<BM, 64, 2, I2V_A_PLAIN, true>(p, s);
   return launch_big_mode<BM, 64, 2, I2V_A_PLAIN, false>(p, s);
 }
@@ -1234,7 +1267,14 @@ int launch_deep(const i2v_gemm_params& p, hipStream_t s) {
 #define I2V_DEEP_LAUNCH(STORE) \
   hipLaunchKernelGGL((gemm_big_kernel<128, 64, NS, I2V_A_PLAIN, I2V_EPI_NONE, STORE, false, true, false, false, BN>), \
                      dim3(ntiles), dim3(512), 0, s, p, tiles_n, 0, ntiles)
-  if (p.store_mode == I2V_STORE_ROWPERM)
+  if (p.residual_lo != nullptr || p.c_lo != nullptr) {
+    if (p.store_mode == I2V_STORE_ROWPERM)
+      hipLaunchKernelGGL((gemm_big_kernel<128, 64, NS, I2V_A_PLAIN, I2V_EPI_NONE, I2V_STORE_ROWPERM, false, true, false, false, BN, 8, false, true>),
+                         dim3(ntiles), dim3(512), 0, s, p, tiles_n, 0, ntiles);
+    else
+      hipLaunchKernelGGL((gemm_big_kernel<128, 64, NS, I2V_A_PLAIN, I2V_EPI_NONE, I2V_STORE_ROWMAJOR, false, true, false, false, BN, 8, false, true>),
+                         dim3(ntiles), dim3(512), 0, s, p, tiles_n, 0, ntiles);
+  } else if (p.store_mode == I2V_STORE_ROWPERM)
     I2V_DEEP_LAUNCH(I2V_STORE_ROWPERM);
   else if (p.store_mode == I2V_STORE_VT)
     I2V_DEEP_LAUNCH(I2V_STORE_VT);
@@ -1263,7 +1303,7 @@ int big_bn(const i2v_gemm_params& p) {
   if (p.N % BIG_BN == 0) return BIG_BN;
   if (p.a_mode == I2V_A_PLAIN) return deep_plan(p, 1) ? -1 : 0;   // -1: the deep-pipeline form (128 / 256 columns) or nothing
   static const int vae = getenv("I2V_GEMM_BIG_VAE") ? atoi(getenv("I2V_GEMM_BIG_VAE")) : 1;
-  if (vae && p.a_mode == I2V_A_CONV3X3 && p.epilogue == I2V_EPI_NONE && p.store_mode == I2V_STORE_ROWMAJOR) {
+  if (vae && p.a_mode == I2V_A_CONV3X3 && p.epilogue == I2V_EPI_NONE && p.store_mode == I2V_STORE_ROWMAJOR && !p.residual_lo && !p.c_lo) {
     if (p.N % 256 == 0) return 256;
     if (p.N % 128 == 0) return 128;
   }
@@ -1295,6 +1335,7 @@ int big_plan(const i2v_gemm_params& p, int vec4, int* splits_out, int* kps_out) 
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (p.ldc % 8 != 0 || !a16(p.c)) return 0;
     if (p.residual && (p.ldr % 8 != 0 || !a16(p.residual))) return 0;
+    if (!a16(p.residual_lo) || !a16(p.c_lo)) return 0;
     if (p.rowvec && (p.ld_rowvec % 8 != 0 || !a16(p.rowvec))) return 0;
   }
   if (p.rowvec && p.M >= (1 << 24)) return 0;   // the epilogue's reciprocal division of the row index is exact below 2^24

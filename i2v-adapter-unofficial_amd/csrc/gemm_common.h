@@ -12,7 +12,13 @@ struct GemmRow {
   int64_t m_out;
   const f16* rv;  // time-embedding row vector (already offset to the row's vector)
   const f16* rs;  // residual row
+  const f16* rl;  // ... and its low half (i2v_gemm_params.residual_lo: the precise residual stream), or null
+  f16* cl;        // low half of the output row (c_lo), or null
 };
+
+// the precise residual stream (i2v_gemm_params.residual_lo / c_lo): a value v as the fp16 pair (hi, lo), hi = fp16(v) the tensor every
+// MFMA operand reads, lo = fp16(v - hi) the bits that rounding dropped (|lo| <= ulp(hi) / 2: exact to 2^-22 |v|, 6e-8 absolute)
+__device__ __forceinline__ f16 lo_half(const float v, const f16 hi) { return (f16)(v - (float)hi); }
 
 __device__ __forceinline__ GemmRow gemm_make_row(const i2v_gemm_params& p, int m) {
   GemmRow r;
@@ -29,6 +35,8 @@ __device__ __forceinline__ GemmRow gemm_make_row(const i2v_gemm_params& p, int m
   r.rv = rowvec ? rowvec + (int64_t)(p.rowvec_period > 0 ? (m & (p.rowvec_period - 1)) : m / p.rows_per_vec) * p.ld_rowvec
                 : nullptr;
   r.rs = resid ? resid + r.m_out * p.ldr : nullptr;
+  r.rl = (resid && p.residual_lo) ? reinterpret_cast<const f16*>(p.residual_lo) + r.m_out * p.ldr : nullptr;
+  r.cl = p.c_lo ? reinterpret_cast<f16*>(p.c_lo) + r.m_out * p.ldc : nullptr;
   return r;
 }
 
@@ -55,6 +63,11 @@ __device__ __forceinline__ void gemm_store4(const i2v_gemm_params& p, const int 
       const f16x4 r4 = *reinterpret_cast<const f16x4*>(row.rs + n);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
+      if (row.rl) {
+        const f16x4 l4 = *reinterpret_cast<const f16x4*>(row.rl + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)l4[r];
+      }
     }
   } else {
 #pragma unroll
@@ -63,6 +76,7 @@ __device__ __forceinline__ void gemm_store4(const i2v_gemm_params& p, const int 
         if (bias) v[r] += (float)bias[n + r];
         if (row.rv) v[r] += (float)row.rv[n + r];
         if (row.rs) v[r] += (float)row.rs[n + r];
+        if (row.rl) v[r] += (float)row.rl[n + r];
       }
     }
   }
@@ -105,10 +119,14 @@ __device__ __forceinline__ void gemm_store4(const i2v_gemm_params& p, const int 
     if (vec4) {
       f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
       *reinterpret_cast<f16x4*>(dst) = o;
+      if (row.cl) *reinterpret_cast<f16x4*>(row.cl + n) = f16x4{lo_half(v[0], o[0]), lo_half(v[1], o[1]), lo_half(v[2], o[2]), lo_half(v[3], o[3])};
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < N) dst[r] = (f16)v[r];
+        if (n + r < N) {
+          dst[r] = (f16)v[r];
+          if (row.cl) row.cl[n + r] = lo_half(v[r], (f16)v[r]);
+        }
     }
   }
 }

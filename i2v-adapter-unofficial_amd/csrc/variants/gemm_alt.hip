@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void gemm_alt_kernel(const i2v_gemm_params 
 // 1 = launched, 0 = not for this kernel, < 0 error
 int i2v_gemm_alt_try(const i2v_gemm_params& p, hipStream_t s) {
   static const int mode = getenv("I2V_GEMM_ALT") ? atoi(getenv("I2V_GEMM_ALT")) : 0;
-  if (mode == 0) return 0;
+  if (mode == 0 || p.residual_lo || p.c_lo) return 0;
   if (p.a_mode != I2V_A_PLAIN || p.a2 != nullptr || p.c_is_f32 || p.store_mode != I2V_STORE_ROWMAJOR) return 0;
   if (p.M % ABM != 0 || p.N % ABN != 0 || (p.K != 320 && p.K != 640)) return 0;   // NKT = 5 / 10 instantiations
   if (p.rows_per_w > 0 || p.a_perm_frames > 0 || p.workspace_bytes < 0) return 0;

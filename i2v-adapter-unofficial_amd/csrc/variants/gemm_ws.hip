@@ -375,7 +375,7 @@ inline bool ws_al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15
 int i2v_gemm_ws_ok(const i2v_gemm_params& p) {
   // OFF unless I2V_GEMM_WS=1: measured equal or slower than the 8-wave tile kernel on every flavour (profiles/r4_gemm_ws_ab.txt)
   static const int enabled = getenv("I2V_GEMM_WS") ? atoi(getenv("I2V_GEMM_WS")) : 0;
-  if (!enabled) return 0;
+  if (!enabled || p.residual_lo || p.c_lo) return 0;
   if (p.a_mode != I2V_A_PLAIN || p.a2 != nullptr || p.K != WS_K || p.N % WS_BN != 0 || p.N / WS_BN > 32) return 0;
   if (p.M % WS_BM != 0 || p.M < 16384) return 0;                      // >= 1 row block for each of the 256 workgroups
   if (p.store_mode != I2V_STORE_ROWMAJOR || p.c_is_f32) return 0;

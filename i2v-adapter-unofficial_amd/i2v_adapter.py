@@ -18,8 +18,8 @@ from torch import nn
 
 from . import kernels as K
 from . import streams
-from .blocks import (gn_proj_in, ff_tail_operands, Attention, FeedForward, HipModule, LazyPack, LnFoldPlan, _as_f16_matrix, fold_layernorm, from_tokens,
-                     to_tokens, w16)
+from .blocks import (gn_proj_in, ff_tail_operands, precise_stream, Attention, FeedForward, HipModule, LazyPack, LnFoldPlan, _as_f16_matrix,
+                     fold_layernorm, from_tokens, to_tokens, w16)
 from ._lib import HipLibraryError
 from .checkpoint import PretrainedMixin
 
@@ -412,13 +412,13 @@ class I2VAdapterTransformer2DModel(HipModule):
                 n_img, x = 2 * n_img, K.duplicate_batch(x)                                   # the residual of proj_out
             if j + 1 == len(self.transformer_blocks):
                 t, applied = blk._fwd(t, n_in, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip,
-                                      cfg_expand=expand, tail=(p["tail"], x.view(-1, c), 0, 0))
+                                      cfg_expand=expand, tail=(p["tail"], K.sview(x, -1, c), 0, 0))
             else:
                 t = blk._fwd(t, n_in, hh * ww, enable_cross_frame_attn, num_frames, ctx_text, ctx_ip, cfg_expand=expand)
         if applied:                                                                          # i2v:298-314 ran inside the feed-forward
-            return t.view(n_img, hh, ww, c)
-        out = K.gemm(t, p["wo"], p["bo"], residual=x.view(-1, c))                            # i2v:298-314
-        return out.view(n_img, hh, ww, c)
+            return K.sview(t, n_img, hh, ww, c)
+        out = K.gemm(t, p["wo"], p["bo"], residual=K.sview(x, -1, c), precise=precise_stream())   # i2v:298-314
+        return K.sview(out, n_img, hh, ww, c)
 
     def forward(self, hidden_states, enable_cross_frame_attn: bool = False, encoder_hidden_states=None,
                 num_frames: Optional[int] = None, timestep=None, added_cond_kwargs=None, class_labels=None,

@@ -53,11 +53,44 @@ def pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
+# ---------------------------------------------------------------------------------------------- the precise residual stream
+# (i2v_gemm_params.residual_lo / c_lo)  The stream between the UNet's modules as an fp16 pair: the tensor every kernel
+# reads as before (hi) carries its low half -- the bits its fp16 rounding dropped -- as an attribute.  A producer called with
+# `precise=True` adds the residual's low half (when the residual has one) and attaches the result's.
+def lo_of(t):
+    """the low half that travels with a stream tensor, or None"""
+    return None if t is None else getattr(t, "_i2v_lo", None)
+
+
+def sview(t, *shape):
+    """t.view(*shape) that keeps the low half attached"""
+    v, lo = t.view(*shape), lo_of(t)
+    if lo is not None:
+        v._i2v_lo = lo.view(*shape)
+    return v
+
+
+def _attach_lo(p_res_lo_setter, residual, out):
+    """(residual's low half or None after checking it is laid out like the residual, fresh low half for `out`)"""
+    rl = lo_of(residual)
+    if rl is not None and (rl.shape != residual.shape or rl.stride() != residual.stride() or rl.dtype != f16):
+        raise ValueError("the low half of a stream tensor must be laid out like the tensor")
+    cl = torch.empty_like(out)
+    if cl.stride() != out.stride():
+        raise ValueError("precise stream: `out` must be dense")
+    p_res_lo_setter(rl, cl)
+    out._i2v_lo = cl
+    return rl, cl
+
+
 # ---------------------------------------------------------------------------------------------- GEMM / conv
 def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0, epilogue=I2V_EPI_NONE,
          out=None, store=I2V_STORE_ROWMAJOR, frames=0, hw=0, vt_len=0, vt_ld=0, out_scale=1.0, ln=None,
-         rowvec_period=0, query_ln_support=False, w_rows=0, a_perm=None, query_batch_support=False):
+         rowvec_period=0, query_ln_support=False, w_rows=0, a_perm=None, query_batch_support=False, precise=False):
     """C = epi(A W^T + bias + rowvec + residual) * out_scale   (see i2v_gemm_f16).
+
+    precise: the result is a tensor of the precise residual stream -- its low half is written beside it (`lo_of(out)`), and the
+    residual's low half, if it has one, is added with it (row-major / row-permuted plain stores only).
 
     w may be a stack [S, N, K] of weight matrices with w_rows = rows of A per matrix (GroupNorm folded into proj_in,
     groupnorm_fold).  a_perm = (frames, hw): A's rows are (batch, frame, pixel) and are read as (batch, pixel, frame).
@@ -145,9 +178,17 @@ def gemm(a, w, bias=None, *, a2=None, residual=None, rowvec=None, rows_per_vec=0
         return bool(lib.i2v_gemm_ln_supported(C.byref(p)))
     if query_batch_support:
         return bool(lib.i2v_gemm_batch_supported(C.byref(p)))
+    keep = None
+    if precise:
+        if epilogue != I2V_EPI_NONE or store not in (I2V_STORE_ROWMAJOR, I2V_STORE_ROWPERM) or ln is not None:
+            raise ValueError("precise=True needs a plain row-major / row-permuted store")
+
+        def set_lo(rl, cl):
+            p.residual_lo, p.c_lo = _p(rl), _p(cl)
+        keep = _attach_lo(set_lo, residual, out)
     ws = _attach_splitk_workspace(lib, p, a.device)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16")
-    del ws
+    del ws, keep
     return out
 
 
@@ -169,7 +210,7 @@ def conv_k_block(cin: int) -> int:
 
 
 def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
-            out_scale=1.0, asym_pad=False, out_f32=False, gn_stats_groups=0):
+            out_scale=1.0, asym_pad=False, out_f32=False, gn_stats_groups=0, precise=False):
     """3x3 / pad 1 convolution of a token-major image x [N, H, W, Cin] with w_packed [Cout, 9 * Cin]
     (k ordered as `blocks.pack_conv3x3` lays it out: tap-major, or channel-block-major when Cin % 64 == 0, see
     conv_k_block); optional nearest-2x upsampling of the input first.  asym_pad (stride 2): no
@@ -177,7 +218,8 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     out_f32: the result stays fp32 (narrow outputs only, Cout <= 64: the UNet's conv_out feeding the DDIM / CFG kernel).
     gn_stats_groups > 0: returns (out, stats) -- stats = the GroupNorm statistics of `out` over that many channel groups as
     partials written by the convolution's epilogue (i2v_gemm_params.gn_partial), to hand to `groupnorm(out, ..., stats=stats)`,
-    or None where the epilogue form is not implemented for this problem (the norm then runs its own statistics pass)."""
+    or None where the epilogue form is not implemented for this problem (the norm then runs its own statistics pass).
+    precise: as `gemm` (the result and the residual are tensors of the precise residual stream)."""
     lib = _lib.load()
     _req(x, "x")
     if x.dim() != 4 or not x.is_contiguous():
@@ -228,6 +270,14 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     p.out_h, p.out_w, p.stride, p.upsample = oh, ow, stride, 1 if upsample else 0
     p.asym_pad = 1 if asym_pad else 0
     p.conv_kblock = conv_k_block(cin)
+    keep = None
+    if precise:
+        if out_f32 or gn_stats_groups:
+            raise ValueError("precise=True is an fp16 result without GroupNorm partials")
+
+        def set_lo(rl, cl):
+            p.residual_lo, p.c_lo = _p(rl), _p(cl)
+        keep = _attach_lo(set_lo, residual, out)
     ws = _attach_splitk_workspace(lib, p, x.device)
     stats = None
     if gn_stats_groups:
@@ -240,7 +290,7 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
             p.gn_partial = _p(part)
             stats = (part, rows)
     _lib.check(lib.i2v_gemm_f16(C.byref(p), _stream()), "i2v_gemm_f16(conv3x3)")
-    del ws
+    del ws, keep
     return (out, stats) if gn_stats_groups else out
 
 
@@ -558,11 +608,12 @@ def pack_ff_tail(w3, b3):
     return pack_cross_q(w3, 8), b3.detach().float().contiguous()
 
 
-def ff_fused(x, gamma32, beta32, packed, *, eps, out=None, tail=None):
+def ff_fused(x, gamma32, beta32, packed, *, eps, out=None, tail=None, precise=False):
     """out = x + GEGLU-FF(LayerNorm(x)) in one launch (i2v_ff_fused_f16); packed = `pack_ff_fused(...)`.
     tail = (packed_tail, res2, perm_frames, perm_hw): the block's proj_out in the same launch --
     out[perm(r)] = res2[perm(r)] + (x + FF(LN(x)))[r] W3^T + b3, packed_tail = `pack_ff_tail(w3, b3)`; perm_frames > 0: rows are
-    in (batch, pixel, frame) order and leave in (batch, frame, pixel) order (res2 is read in that order too)."""
+    in (batch, pixel, frame) order and leave in (batch, frame, pixel) order (res2 is read in that order too).
+    precise (with a tail whose res2 carries a low half, `lo_of`): res2 + its low half is added and the result's low half is written."""
     lib = _lib.load()
     x, ldx = _mat(x, "x")
     rows, c = x.shape
@@ -585,6 +636,7 @@ def ff_fused(x, gamma32, beta32, packed, *, eps, out=None, tail=None):
     p.w1, p.b1, p.w2, p.b2 = _p(w1f), _p(b1f), _p(w2f), _p(b2f)
     p.out, p.ldo = _p(out), ldo
     p.rows, p.channels, p.inner, p.eps = rows, c, inner, float(eps)
+    keep = None
     if tail is not None:
         (w3f, b3f), res2, perm_frames, perm_hw = tail
         _req(w3f, "w3")
@@ -598,7 +650,12 @@ def ff_fused(x, gamma32, beta32, packed, *, eps, out=None, tail=None):
             raise ValueError("ff_fused: out must not alias x when the tail permutes the rows")
         p.w3, p.b3, p.res2, p.ld_res2 = _p(w3f), _p(b3f), _p(res2), ld2
         p.perm_frames, p.perm_hw = int(perm_frames), int(perm_hw)
+        if precise and lo_of(res2) is not None:
+            def set_lo(rl, cl):
+                p.res2_lo, p.out_lo = _p(rl), _p(cl)
+            keep = _attach_lo(set_lo, res2, out)
     _lib.check(lib.i2v_ff_fused_f16(C.byref(p), _stream()), "i2v_ff_fused_f16")
+    del keep
     return out
 
 
@@ -869,11 +926,14 @@ def copy3d(src, dst):
 def duplicate_batch(x):
     """[x ; x] along the leading dimension (the second CFG half of a tensor computed once for both, unet._fwd_tokens)."""
     _req(x, "x")
+    lo = lo_of(x)
     x = x.contiguous()
     rows = x.shape[0]
     y = torch.empty((2 * rows,) + tuple(x.shape[1:]), dtype=f16, device=x.device)
     c = x.shape[-1]
     copy3d(x.view(1, -1, c).expand(2, -1, c), y.view(2, -1, c))
+    if lo is not None:                      # a tensor of the precise residual stream: its low half travels with it
+        y._i2v_lo = duplicate_batch(lo)
     return y
 
 

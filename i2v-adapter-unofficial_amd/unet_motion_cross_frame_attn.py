@@ -18,7 +18,7 @@ from . import kernels as K
 from ._lib import HipLibraryError
 from .blocks import (Attention, DownBlockMotion, Downsample2D, HipModule, ImageProjection, MotionAdapter,
                      ProjectedContext, ProjectedTemb, ResnetBlock2D, TimestepEmbedding, Timesteps, UpBlockMotion,
-                     Upsample2D, _as_f16_matrix, _motion, from_tokens, pack_conv3x3, to_tokens, w16)
+                     Upsample2D, _as_f16_matrix, _motion, from_tokens, pack_conv3x3, precise_stream, to_tokens, w16)
 from .checkpoint import PretrainedMixin
 from .i2v_adapter import I2VAdapterModule, I2VAdapterTransformer2DModel
 
@@ -669,7 +669,7 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
                       isinstance(self.down_blocks[0], CrossFrameAttnDownBlockMotion))
         if cfg_shared:
             x = x[: x.shape[0] // 2]
-        x = K.conv3x3(x, p["w_in"], p["b_in"])                                          # unet:1359
+        x = K.conv3x3(x, p["w_in"], p["b_in"], precise=precise_stream())                # unet:1359
         res = (K.duplicate_batch(x) if cfg_shared else x,)
         for bi, blk in enumerate(self.down_blocks):                                     # unet:1362-1377
             if getattr(blk, "has_cross_attention", False):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define I2V_ABI_VERSION 8
+#define I2V_ABI_VERSION 9
 
 #define I2V_OK 0
 #define I2V_ERR_INVALID_ARG (-1)
@@ -148,6 +148,15 @@ typedef struct i2v_gemm_params {
      i2v_gn_params.gpartial_in / gpartial_rows.  NULL: none. */
   void* gn_partial;
   int32_t gn_groups;
+  /* (ABI 9) the PRECISE residual stream: the stream between modules (outputs of conv_in, every ResnetBlock2D, spatial transformer,
+     motion module, down sampler; pipe:666-697 runs it in fp32 on the reference's CPU path) as an fp16 PAIR hi + lo, hi = fp16(x),
+     lo = fp16(x - hi): hi is the tensor every MFMA / LDS-DMA operand reads as before, lo carries the 11 bits the rounding dropped, so
+     the identity path of a residual add no longer re-rounds the stream at every module (0.78 of the 0.89e-3 rms).
+       residual_lo  fp16 [M, N] (ld = ldr), needs `residual`: the value added is (float)residual + (float)residual_lo
+       c_lo         fp16 [M, N] (ld = ldc, row order of c): receives fp16(v - (float)fp16(v)) of the fp32 result v that c rounds
+     Row-major / row-permuted fp16 stores without GEGLU / GELU, no LayerNorm fold, no GroupNorm partials.  NULL: none. */
+  const void* residual_lo;
+  void* c_lo;
 } i2v_gemm_params;
 
 int i2v_gemm_f16(const i2v_gemm_params* p, i2v_stream_t stream);
@@ -349,6 +358,10 @@ typedef struct i2v_ff_fused_params {
   const void* w3; const void* b3;
   const void* res2; int64_t ld_res2;
   int32_t perm_frames, perm_hw;
+  /* (ABI 9) the precise residual stream through the tail (see i2v_gemm_params.residual_lo / c_lo): res2_lo [rows of ld_res2] is
+     added with res2, out_lo [rows of ldo] receives the low half of the result.  Tail only; both or neither. */
+  const void* res2_lo;
+  void* out_lo;
 } i2v_ff_fused_params;
 
 int32_t i2v_ff_fused_supported(int64_t rows, int32_t channels, int32_t inner);

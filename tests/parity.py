@@ -205,3 +205,64 @@ def smoke_check():
         got = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
     err, scale = compare(got, ref, rel=REL_TOL_UNET, name="smoke: small UNet forward")
     print(f"smoke ok: small UNet forward max abs err {err:.3e} (max|ref| {scale:.3e})")
+
+
+# ---------------------------------------------------------------------------------------------- full-size oracle fixtures (r6)
+# tests/golden/oracle_full_*.safetensors (oracle/make_full_fixtures.py): fp32 outputs of the CPU oracle at BASELINE's FULL sizes on
+# weights that are re-created from a seed with the CPU generator -- the same numbers in the build container and on the GPU box --
+# so that the driver's `-m gpu` run checks every configuration against the oracle in seconds (the oracle forward of config 5 alone
+# takes minutes of host time).  `weights_checksum` pins the re-created weights to the ones the fixture was made with.
+FULL_SEED, FULL_SEED_IP = 1234, 4321
+
+
+def oracle_full_width_cpu_seeded(seed=FULL_SEED, ip=False, norm_jitter=0.1):
+    """SD-1.5-width ORACLE UNet with weights drawn by torch's default initialisers under `torch.manual_seed(seed)` on the CPU
+    (+ jittered norm affines, adapter to_out ~ N(0, 0.02^2), every value rounded to fp16); ip: + the synthetic IP-Adapter."""
+    from oracle.unet_motion_cross_frame_attn import UNetMotionCrossFrameAttnModel as OracleUNet
+    torch.manual_seed(seed)
+    ou = OracleUNet(**SD15)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in ou.modules():
+            if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)) and m.weight is not None:
+                m.weight.add_(torch.randn(m.weight.shape, generator=g) * norm_jitter)
+                m.bias.add_(torch.randn(m.bias.shape, generator=g) * norm_jitter)
+    randomize_adapter_out_(ou)
+    round_fp16_(ou)
+    if ip:
+        ou._load_ip_adapter_weights(sd15_ip_state_dict(ou))
+    return ou.eval()
+
+
+def weights_checksum(module):
+    """a few numbers that change when any weight does: fp64 sums of |w| over (every 7th parameter, all of them weighted by index)."""
+    with torch.no_grad():
+        ps = list(module.parameters())
+        a = sum(p.double().abs().sum() for p in ps[::7])
+        b = sum((i % 13 + 1) * p.double().sum() for i, p in enumerate(ps))
+    return torch.tensor([float(a), float(b), float(len(ps))], dtype=torch.float64)
+
+
+def full_forward_inputs(frames, h_lat, ip, seed=11):
+    """the CFG-shaped batch bench.py's `parity` uses: the SAME latents twice against two prompts, one timestep (pipe:672-673)."""
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(1, frames, 4, h_lat, h_lat, generator=g).half().float()
+    d = dict(sample=torch.cat([lat, lat]), ctx=torch.randn(2, 77, 768, generator=g).half().float(), t=torch.tensor([481, 481]))
+    if ip:
+        d["image_embeds"] = torch.randn(2, 1024, generator=g).half().float()
+    return d
+
+
+def trajectory_inputs(frames, h_lat, seed=21):
+    """(pipeline kwargs, generator factory) of the 25-step DDIM trajectory fixture (pipe:629-700)."""
+    g = torch.Generator().manual_seed(seed)
+    h16 = lambda t: t.half().float()
+    kw = dict(prompt_embeds=h16(torch.randn(1, 77, 768, generator=g)), negative_prompt_embeds=h16(torch.randn(1, 77, 768, generator=g)),
+              condition_image_latents=torch.randn(1, 4, h_lat, h_lat, generator=g), num_frames=frames, num_inference_steps=25,
+              guidance_scale=7.5, blur_sigma=1.0, frame_similarity_sample_ratio=1.0)
+    gens = lambda: dict(generator=torch.Generator().manual_seed(5), prior_mask_generator=torch.Generator().manual_seed(6),
+                        prior_noise_generator=torch.Generator().manual_seed(7))
+    return kw, gens
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")

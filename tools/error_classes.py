@@ -12,6 +12,12 @@ applied ONLY at chosen places (everything else exact fp32):
   blocks   additionally the token stream inside the transformers (output of every transformer block = after its last
            residual add, and proj_in's output)
   everyop  every aten op's result rounded (oracle/fp16_emulation.py: the reference's own fp16 op graph)
+  (r6) the precise-stream forms -- the stream is kept as an fp16 hi + lo pair, so the IDENTITY path of every residual add is
+  exact and only what a module's branch reads as an MFMA / norm operand is the rounded hi part:
+  hilo     inputs of every branch rounded (ResnetBlock2D.norm1 and .conv_shortcut, the entry GroupNorm of the spatial
+           transformers and motion modules, the samplers' convs, conv_norm_out); the residual adds see the exact stream
+  hilo_sc  the same, but conv_shortcut reads the exact stream too (the 1x1 shortcut GEMM over hi AND lo)
+  hilo_blocks  hilo + the token stream inside the transformers rounded (what the fused 64^2 kernels keep in fp16)
 
   python tools/error_classes.py [--frames 16 --size 512] [--modes outer,blocks,everyop] [--out profiles/r4_error_classes.jsonl]
 Test infrastructure only (imports oracle/)."""
@@ -77,8 +83,25 @@ def main():
                  ob.Upsample2D)
     block_cls = (ob.BasicTransformerBlock,)
 
+    def pre16(mod, a):
+        return tuple(r16(e) for e in a)
+
     def run(mode):
         handles = []
+        if mode.startswith("hilo"):
+            for n, m in ou.named_modules():
+                if isinstance(m, ob.ResnetBlock2D):
+                    handles.append(m.norm1.register_forward_pre_hook(pre16))
+                    if m.conv_shortcut is not None and mode != "hilo_sc":
+                        handles.append(m.conv_shortcut.register_forward_pre_hook(pre16))
+                elif isinstance(m, (oi.I2VAdapterTransformer2DModel, ob.TransformerTemporalModel)):
+                    handles.append(m.norm.register_forward_pre_hook(pre16))
+                elif isinstance(m, (ob.Downsample2D, ob.Upsample2D)):
+                    handles.append(m.conv.register_forward_pre_hook(pre16))
+                elif n == "conv_norm_out":
+                    handles.append(m.register_forward_pre_hook(pre16))
+                elif mode == "hilo_blocks" and (isinstance(m, block_cls) or n.endswith(".proj_in")):
+                    handles.append(m.register_forward_hook(lambda mod, a, o: r16(o)))
         if mode in ("outer", "blocks"):
             for n, m in ou.named_modules():
                 if isinstance(m, outer_cls) or n == "conv_in":
