@@ -232,6 +232,8 @@ SIGNATURES = {
     "i2v_repeat_rows_f16": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int32, _P]),
     "i2v_copy3d_f16": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_int64, _P]),
+    "i2v_pack_ctx_fragments_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "i2v_pack_ctx_fragments_f16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_ddim_prep": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_gaussian_sample_f32": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "i2v_first_frame_prior_f32": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -273,7 +275,14 @@ SIGNATURES = {
                                       C.POINTER(C.c_int64)]),
     "i2v_unet_num_weights": (C.c_int64, [_P]),
     "i2v_unet_plan": (C.c_int, [_P, C.POINTER(UnetPlan)]),
+    "i2v_unet_set_plan": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "i2v_unet_activation_bytes": (C.c_int64, [_P]),
+    "i2v_unet_plan_launches": (C.c_int32, [_P]),
+    "i2v_unet_plan_num_keys": (C.c_int32, [_P]),
+    "i2v_unet_plan_key": (C.c_char_p, [_P, C.c_int32]),
+    "i2v_unet_set_workspace": (C.c_int, [_P, _P, C.c_int64]),
+    "i2v_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "i2v_unet_abort_capture": (C.c_int, [_P]),
     "i2v_unet_capture_step": (C.c_int, [_P, _P]),
     "i2v_unet_end_capture": (C.c_int, [_P]),
     "i2v_unet_replay_step": (C.c_int, [_P, _P]),

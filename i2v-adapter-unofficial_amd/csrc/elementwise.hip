@@ -223,6 +223,46 @@ __global__ void bump_step_kernel(int32_t* step_index, int n_steps) {
   }
 }
 
+// `ctx_frag` of i2v_cross_attn_fused_f16 (i2v:527-532, unet:1263-1279): this layer's K / V of the context as the MFMA operand
+// fragments the fused kernel keeps in registers, [n_ctx][heads][KT * DT + DT * KT][64 lanes][4], zero beyond the context's length and
+// the head's width.  K fragment (kt, t): lane l holds K[key = 16 kt + (l & 15)][channel = 16 t + 4 (l >> 4) + j]; V fragment (t, kt): lane l
+// holds V^T[channel = 16 t + (l & 15)][key = 16 kt + 4 (l >> 4) + j].  One thread per (fragment, lane): a gather of <= 80 keys.
+__global__ __launch_bounds__(256) void pack_ctx_fragments_kernel(const f16* __restrict__ k, int64_t ldk, const f16* __restrict__ vt,
+                                                                 int64_t vt_row_stride, int64_t vt_batch_stride, f16* __restrict__ out,
+                                                                 int n_ctx, int heads, int d, int ctx_len) {
+  constexpr int KT = 5;
+  const int dt = (d + 15) / 16, nf = 2 * KT * dt;
+  const int64_t total = (int64_t)n_ctx * heads * nf * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    int64_t r = i >> 6;
+    const int f = (int)(r % nf);
+    r /= nf;
+    const int h = (int)(r % heads), n = (int)(r / heads);
+    f16x4 v = {0, 0, 0, 0};
+    if (f < KT * dt) {
+      const int kt = f / dt, t = f - kt * dt;
+      const int key = 16 * kt + (lane & 15), ch0 = 16 * t + 4 * (lane >> 4);
+      if (key < ctx_len) {
+        const f16* src = k + ((int64_t)n * ctx_len + key) * ldk + h * d + ch0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ch0 + j < d) v[j] = src[j];
+      }
+    } else {
+      const int g = f - KT * dt, t = g / KT, kt = g - t * KT;
+      const int ch = 16 * t + (lane & 15), key0 = 16 * kt + 4 * (lane >> 4);
+      if (ch < d) {
+        const f16* src = vt + (int64_t)n * vt_batch_stride + (int64_t)(h * d + ch) * vt_row_stride + key0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (key0 + j < ctx_len) v[j] = src[j];
+      }
+    }
+    *reinterpret_cast<f16x4*>(out + i * 4) = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int i2v_nchw_to_tokens(const void* src, int32_t src_is_f32, void* dst, int32_t n, int32_t c, int32_t hw,
@@ -361,4 +401,25 @@ extern "C" int i2v_gaussian_sample_f32(const float* moments, const float* eps, f
   hipLaunchKernelGGL(gaussian_sample_kernel, dim3(ew_blocks((int64_t)n * c * hw)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), moments, eps, out, n, c, hw);
   return i2v_check_launch("i2v_gaussian_sample_f32");
+}
+
+extern "C" int64_t i2v_pack_ctx_fragments_elems(int32_t n_ctx, int32_t heads, int32_t head_dim) {
+  if (n_ctx <= 0 || heads <= 0 || head_dim <= 0) return 0;
+  return (int64_t)n_ctx * heads * (2 * 5 * ((head_dim + 15) / 16)) * 256;
+}
+
+extern "C" int i2v_pack_ctx_fragments_f16(const void* k, int64_t ldk, const void* vt, int64_t vt_row_stride, int64_t vt_batch_stride,
+                                          void* out, int32_t n_ctx, int32_t heads, int32_t head_dim, int32_t ctx_len,
+                                          i2v_stream_t stream) {
+  I2V_CHECK_ARG(k && vt && out, "i2v_pack_ctx_fragments_f16: null pointer");
+  I2V_CHECK_ARG(n_ctx > 0 && heads > 0 && head_dim > 0 && ctx_len > 0 && ctx_len <= 80,
+                "i2v_pack_ctx_fragments_f16: n_ctx %d heads %d head_dim %d ctx_len %d (1 .. 80 keys)", n_ctx, heads, head_dim, ctx_len);
+  I2V_CHECK_ARG(ldk >= (int64_t)heads * head_dim && vt_row_stride >= ctx_len && vt_batch_stride >= (int64_t)heads * head_dim * vt_row_stride,
+                "i2v_pack_ctx_fragments_f16: strides");
+  I2V_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 7) == 0, "i2v_pack_ctx_fragments_f16: out must be 8-byte aligned");
+  const int64_t total = i2v_pack_ctx_fragments_elems(n_ctx, heads, head_dim) / 4;
+  hipLaunchKernelGGL(pack_ctx_fragments_kernel, dim3(ew_blocks(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(k), ldk, reinterpret_cast<const f16*>(vt), vt_row_stride, vt_batch_stride,
+                     reinterpret_cast<f16*>(out), n_ctx, heads, head_dim, ctx_len);
+  return i2v_check_launch("i2v_pack_ctx_fragments_f16");
 }

@@ -1,12 +1,265 @@
-"""The library's model handle (include/i2v_hip.h "Model handle") seen from Python: what a host that is NOT this package's
-module mirror binds -- configuration, the weight registry under the reference's state-dict keys, the plan of one denoising step
-and one captured step (pipe:96, 676-683).  The package's own pipeline keeps torch's graph capture (its step allocates through
-torch's allocator, which must know about the capture); this wrapper exists for hosts with their own buffers, and for the tests."""
+"""The library's model handle (include/i2v_hip.h "Model handle") seen from Python, and the RECORDER that turns one forward
+of the host mirror into the launch plan `i2v_unet_forward` executes in C (unet:1289-1451; pipe:96, 676-683).
+
+    blob, weights = record_forward_plan(unet, sample, timesteps, ctx, image_embeds=None)      # once per (problem, switches)
+    h = UNetHandle(unet); h.plan(...); h.set_plan(blob); h.set_weights(weights)
+    h.set_workspace(torch.empty(h.activation_bytes, dtype=torch.uint8, device=dev))
+    h.forward(sample, timesteps, ctx, image_embeds, out, stream)                                # ONE ctypes call: the launches are issued in C
+
+What a host that is NOT this package binds is exactly those C entry points; `save_plan` / `save_weights` write the two files such a
+host loads (tests/c_host/unet_forward_host.c is one).  The package's own pipeline keeps torch's graph
+capture (its step allocates through torch's allocator, which must know about the capture).
+
+How the recording works: `UNetMotionCrossFrameAttnModel.forward` is run once with `_lib.load()` replaced by a proxy that logs every
+launch entry point it calls -- entry id, the bytes of its parameter struct / its flat arguments -- and then calls it.  Afterwards every
+device pointer in the log is classified: inside one of the forward's arguments (io slot), inside a persistent tensor of the model
+(kernel-layout packs, parameters, buffers: a weight key), or inside the private memory pool the forward allocated from (the arena:
+the pool's segments laid end to end, so the plan inherits torch's own buffer reuse).  Anything else is an error, not a guess.
+"""
+import bisect
 import ctypes as C
+import struct
 
 import torch
 
 from . import _lib
+
+PLAN_MAGIC, PLAN_VERSION = 0x50563249, 1
+# entry points a recorded forward may contain, in the order of csrc/handle.hip `enum Entry`
+ENTRY_IDS = {name: i for i, name in enumerate((
+    "i2v_gemm_f16", "i2v_attention_f16", "i2v_temporal_attention_f16", "i2v_motion_attn_f16", "i2v_cross_attn_fused_f16", "i2v_ln_qkv_f16",
+    "i2v_ff_fused_f16", "i2v_groupnorm_f16", "i2v_layernorm_f16", "i2v_groupnorm_fold_f16", "i2v_nchw_to_tokens", "i2v_tokens_to_nchw",
+    "i2v_timestep_embedding", "i2v_silu_f16", "i2v_repeat_rows_f16", "i2v_copy3d_f16", "i2v_select_row_f16",
+    "i2v_pack_ctx_fragments_f16"))}
+IO_SAMPLE, IO_TIMESTEPS, IO_CONTEXT, IO_IMAGE_EMBEDS, IO_OUT = range(5)
+RELOC_ARENA, RELOC_WEIGHT, RELOC_IO = range(3)
+_INT_TYPES = (C.c_int32, C.c_int64, C.c_int)
+
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+class _RecordingLib:
+    """stands in for the ctypes library while a forward is recorded: launch entry points are logged and then executed, everything
+    else (the *_supported / *_bytes / *_rows queries) passes through."""
+
+    def __init__(self, real):
+        self._real = real
+        self.ops = []            # (entry id, struct bytes, [slot values], [(payload offset, pointer value)])
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not name.startswith("i2v_") or name not in _lib.SIGNATURES:
+            return fn
+        res, argtypes = _lib.SIGNATURES[name]
+        launches = bool(argtypes) and argtypes[-1] is C.c_void_p and res is C.c_int and not name.startswith("i2v_unet_")
+        if not launches:
+            return fn
+        if name not in ENTRY_IDS:
+            def refuse(*a, _n=name):
+                raise _lib.HipLibraryError(f"{_n} is not an entry point a launch plan can carry (handle.ENTRY_IDS / csrc/handle.hip)")
+            return refuse
+
+        def call(*args, _n=name, _fn=fn, _at=argtypes):
+            self._log(_n, args, _at)
+            return _fn(*args)
+        return call
+
+    def _log(self, name, args, argtypes):
+        if len(args) != len(argtypes):
+            raise TypeError(f"{name}: {len(args)} arguments for {len(argtypes)} parameters")
+        sbytes, slots, ptrs = b"", [], []
+        for arg, at in zip(args[:-1], argtypes[:-1]):          # the last parameter is the stream
+            if isinstance(at, type) and issubclass(at, C._Pointer) and issubclass(at._type_, C.Structure):
+                st = arg._obj                                   # C.byref(params)
+                if sbytes or slots:
+                    raise TypeError(f"{name}: the parameter struct must come first")
+                sbytes = bytes(st)
+                for fname, ftype in st._fields_:
+                    if ftype is C.c_void_p:
+                        v = getattr(st, fname)
+                        if v:
+                            ptrs.append((getattr(type(st), fname).offset, int(v), f"{name}.{fname}"))
+            elif at is C.c_void_p:
+                v = arg.value if isinstance(arg, C.c_void_p) else arg
+                v = int(v) if v else 0
+                if v:
+                    ptrs.append((_pad8(len(sbytes)) + 8 * len(slots), v, f"{name} argument {len(slots)}"))
+                slots.append(v)
+            elif at in _INT_TYPES:
+                slots.append(int(arg))
+            else:
+                raise TypeError(f"{name}: a launch plan carries pointers and integers, not {at}")
+        self.ops.append((ENTRY_IDS[name], sbytes, slots, ptrs))
+
+
+def persistent_tensors(unet):
+    """name -> tensor of everything a forward may read that outlives it: the kernel-layout packs of every module
+    (`<module path>#<pack name>[#i]`), the fused motion attention's LayerNorm tables, the concatenated time-embedding projection,
+    and the parameters / buffers themselves (state-dict keys)."""
+    out = {}
+
+    def add(name, v):
+        if torch.is_tensor(v):
+            if v.is_cuda and v.numel():
+                out[name] = v
+        elif isinstance(v, (tuple, list)):
+            for i, e in enumerate(v):
+                add(f"{name}#{i}", e)
+
+    for mname, m in unet.named_modules():
+        packed = getattr(m, "_packed", None)
+        if isinstance(packed, dict):
+            for k, v in dict.items(packed):
+                add(f"{mname}#{k}", v)
+        for (site, frames), tab in getattr(m, "_ma_tables", {}).items():
+            add(f"{mname}#ma_table{site}_{frames}", tab)
+    tp = getattr(unet, "_temb_packed", None)
+    if tp is not None:
+        add("#temb_proj", tp[:2])
+    for k, v in unet.state_dict().items():
+        add(k, v)
+    return out
+
+
+def _storage_range(t):
+    st = t.untyped_storage()
+    return st.data_ptr(), st.data_ptr() + st.nbytes()
+
+
+def record_forward_plan(unet, sample, timesteps, encoder_hidden_states, image_embeds=None, enable_cross_frame_attn=True,
+                        cfg_shared_prefix=False):
+    """One `unet.forward` (unet:1289-1451) as a launch plan.  Arguments as `i2v_unet_forward` takes them: sample fp16 / fp32
+    [B, F, C, H, W], timesteps fp32 [B], encoder_hidden_states fp16 [B, L, D], image_embeds fp16 [B, clip] or None -- all contiguous
+    on the model's device.  Returns (blob, weights): the plan and {key: tensor} of exactly the persistent tensors it names (register
+    each with `UNetHandle.set_weights`, or `save_weights` them for another host).  The plan holds for this problem size, these
+    switches (I2V_* environment, `blocks.set_precise_stream`) and this library build only."""
+    dev = sample.device
+    io = {IO_SAMPLE: sample, IO_TIMESTEPS: timesteps, IO_CONTEXT: encoder_hidden_states}
+    if image_embeds is not None:
+        io[IO_IMAGE_EMBEDS] = image_embeds
+    if sample.dim() != 5 or sample.dtype not in (torch.float16, torch.float32) or timesteps.dtype != torch.float32 or \
+            tuple(timesteps.shape) != (sample.shape[0],) or encoder_hidden_states.dtype != torch.float16 or \
+            (image_embeds is not None and image_embeds.dtype != torch.float16):
+        raise ValueError("record_forward_plan: sample [B, F, C, H, W] fp16 / fp32, timesteps fp32 [B], context / image_embeds fp16")
+    for s, t in io.items():
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("record_forward_plan: the forward's arguments must be contiguous device tensors")
+    kw = dict(added_cond_kwargs={"image_embeds": image_embeds} if image_embeds is not None else None,
+              cross_attention_kwargs={"cfg_shared_prefix": True} if cfg_shared_prefix else None)
+    with torch.no_grad():
+        unet(sample, timesteps, enable_cross_frame_attn, encoder_hidden_states, **kw)      # builds every lazily packed operand
+        torch.cuda.synchronize(dev)
+        real = _lib.load()
+        rec = _RecordingLib(real)
+        pool = torch.cuda.MemPool()
+        saved = _lib._lib
+        _lib._lib = rec
+        try:
+            with torch.cuda.use_mem_pool(pool, device=dev):
+                out = unet(sample, timesteps, enable_cross_frame_attn, encoder_hidden_states, **kw).sample
+        finally:
+            _lib._lib = saved
+        torch.cuda.synchronize(dev)
+    if not out.is_contiguous() or out.dtype != sample.dtype:
+        raise RuntimeError("record_forward_plan: unexpected output layout")
+    io[IO_OUT] = out
+    segments = sorted((s["address"], s["total_size"]) for s in pool.snapshot())
+    seg_off, arena_bytes = {}, 0
+    for addr, size in segments:
+        seg_off[addr] = arena_bytes
+        arena_bytes += (size + 255) & ~255
+    seg_starts = [a for a, _ in segments]
+    # io ranges are the tensors themselves (the C caller passes the tensor's first byte); `out` lives in the pool and is claimed first
+    io_ranges = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), s) for s, t in io.items()]
+    pers = persistent_tensors(unet)
+    spans = {}
+    for name in sorted(pers):                                   # one name per storage: the first in sorted order
+        lo, hi = _storage_range(pers[name])
+        spans.setdefault((lo, hi), name)
+    span_list = sorted((lo, hi, name) for (lo, hi), name in spans.items())
+    span_starts = [s[0] for s in span_list]
+
+    keys, key_index, relocs, ops_bin, payload = [], {}, [], [], bytearray()
+    io_mask = 0
+    for op_i, (entry, sbytes, slots, ptrs) in enumerate(rec.ops):
+        blockb = bytearray(sbytes) + bytearray(_pad8(len(sbytes)) - len(sbytes))
+        for v in slots:
+            blockb += struct.pack("<q", v)
+        begin = len(relocs)
+        last = op_i == len(rec.ops) - 1
+        for off, v, what in ptrs:
+            # (`out` was allocated from the pool at the end of the forward: an earlier, already freed activation may have had its
+            #  address, so only the LAST launch -- unet:1446, tokens -> NCHW -- can mean it)
+            hit = next(((RELOC_IO, s, v - lo) for lo, hi, s in io_ranges if lo <= v < hi and (s != IO_OUT or last)), None)
+            if hit is None:
+                i = bisect.bisect_right(span_starts, v) - 1
+                if i >= 0 and v < span_list[i][1]:
+                    name = span_list[i][2]
+                    if name not in key_index:
+                        key_index[name] = len(keys)
+                        keys.append(name)
+                    hit = (RELOC_WEIGHT, key_index[name], v - pers[name].untyped_storage().data_ptr())
+            if hit is None:
+                i = bisect.bisect_right(seg_starts, v) - 1
+                if i >= 0 and v < segments[i][0] + segments[i][1]:
+                    hit = (RELOC_ARENA, 0, seg_off[segments[i][0]] + v - segments[i][0])
+            if hit is None:
+                raise RuntimeError(f"record_forward_plan: {what} = {v:#x} is neither an argument, a persistent tensor of the model nor "
+                                   "memory the forward allocated -- a buffer the plan cannot name")
+            if hit[0] == RELOC_IO:
+                io_mask |= 1 << hit[1]
+            blockb[off: off + 8] = b"\0" * 8
+            relocs.append(struct.pack("<IIIIQ", off, hit[0], hit[1], 0, hit[2]))
+        ops_bin.append(struct.pack("<IIIIII", entry, len(payload), len(blockb), begin, len(relocs) - begin, len(sbytes)))
+        payload += blockb
+    b, f, _c, hh, ww = sample.shape
+    key_tab = bytearray()
+    for k in keys:
+        kb = k.encode()
+        key_tab += struct.pack("<I", len(kb)) + kb + b"\0" * (-len(kb) % 4)
+    key_tab += b"\0" * (-len(key_tab) % 8)
+    hdr_size = struct.calcsize("<6I6iQ2I6Q")
+    keys_off = hdr_size
+    ops_off = keys_off + len(key_tab)
+    relocs_off = ops_off + 24 * len(ops_bin)
+    payload_off = relocs_off + 24 * len(relocs)
+    total = payload_off + len(payload)
+    hdr = struct.pack("<6I6iQ2I6Q", PLAN_MAGIC, PLAN_VERSION, _lib.ABI_VERSION, len(ops_bin), len(keys), len(relocs),
+                      b, f, hh, ww, encoder_hidden_states.shape[1], int(image_embeds is not None), arena_bytes, io_mask, 0,
+                      keys_off, ops_off, relocs_off, payload_off, len(payload), total)
+    if not (io_mask >> IO_OUT) & 1:
+        raise RuntimeError("record_forward_plan: the last launch does not write the forward's result")
+    blob = bytes(hdr + key_tab + b"".join(ops_bin) + b"".join(relocs) + payload)
+    assert len(blob) == total
+    weights = {k: pers[k] for k in keys}
+    return blob, weights
+
+
+def base_tensor(t):
+    """the whole storage of a persistent tensor as a flat tensor of its dtype (what a weight key's relocation offsets are relative to)"""
+    st = t.untyped_storage()
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(st, 0, (st.nbytes() // t.element_size(),))
+
+
+def save_plan(blob, path):
+    with open(path, "wb") as f:
+        f.write(blob)
+
+
+def save_weights(weights, path):
+    """the plan's persistent tensors for a host without torch: "I2VW", u32 count, then per tensor u32 key length, key, u32 dtype
+    (0 fp16 / 1 fp32), u64 bytes, padding to 16, the bytes (whole storage, as `base_tensor`)."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sI", b"I2VW", len(weights)))
+        for k, t in weights.items():
+            bt = base_tensor(t).cpu().contiguous()
+            kb = k.encode()
+            raw = bt.numpy().tobytes()
+            f.write(struct.pack("<I", len(kb)) + kb + struct.pack("<IQ", 0 if bt.dtype == torch.float16 else 1, len(raw)))
+            f.write(b"\0" * (-f.tell() % 16))
+            f.write(raw)
 
 
 class UNetHandle:
@@ -33,15 +286,16 @@ class UNetHandle:
 
     __del__ = close
 
-    def set_weights(self, state_dict):
-        """register every fp16 / fp32 tensor of a (device) state dict under its key (unet.state_dict() names)"""
-        for k, t in state_dict.items():
-            if t.dtype not in (torch.float16, torch.float32) or t.dim() > 4:
+    def set_weights(self, tensors):
+        """register every fp16 / fp32 tensor of {key: device tensor} -- a state dict, or the `weights` of `record_forward_plan`
+        (registered as the WHOLE storage behind each tensor: a plan's offsets are relative to it)"""
+        for k, t in tensors.items():
+            if t.dtype not in (torch.float16, torch.float32):
                 continue
-            t = t.detach().contiguous()
-            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            t = base_tensor(t.detach())
+            shape = (C.c_int64 * 1)(t.numel())
             _lib.check(self._lib.i2v_unet_set_weight(self._h, k.encode(), C.c_void_p(t.data_ptr()),
-                                                     0 if t.dtype == torch.float16 else 1, t.dim(), shape), "i2v_unet_set_weight")
+                                                     0 if t.dtype == torch.float16 else 1, 1, shape), "i2v_unet_set_weight")
             self._keep[k] = t
         return int(self._lib.i2v_unet_num_weights(self._h))
 
@@ -54,19 +308,43 @@ class UNetHandle:
     def plan(self, batch, frames, height, width, ctx_len=77, has_ip=False):
         pl = _lib.UnetPlan(batch, frames, height, width, ctx_len, int(has_ip))
         _lib.check(self._lib.i2v_unet_plan(self._h, C.byref(pl)), "i2v_unet_plan")
+
+    def set_plan(self, blob: bytes):
+        """install a launch plan (`record_forward_plan`) for the planned problem; returns (launches, weight keys it names)"""
+        self._blob = bytes(blob)
+        _lib.check(self._lib.i2v_unet_set_plan(self._h, self._blob, len(self._blob)), "i2v_unet_set_plan")
+        n = int(self._lib.i2v_unet_plan_num_keys(self._h))
+        return int(self._lib.i2v_unet_plan_launches(self._h)), [self._lib.i2v_unet_plan_key(self._h, i).decode() for i in range(n)]
+
+    @property
+    def activation_bytes(self):
         return int(self._lib.i2v_unet_activation_bytes(self._h))
+
+    def set_workspace(self, arena):
+        _lib.check(self._lib.i2v_unet_set_workspace(self._h, C.c_void_p(arena.data_ptr()) if arena is not None else None,
+                                                    arena.numel() * arena.element_size() if arena is not None else 0), "i2v_unet_set_workspace")
+        self._arena = arena
+
+    def forward(self, sample, timesteps, context, image_embeds, out, stream=None):
+        """unet:1289-1451 through the C ABI alone: one call, the launches are issued by the library from the installed plan"""
+        s = stream if stream is not None else torch.cuda.current_stream(sample.device)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _lib.check(self._lib.i2v_unet_forward(self._h, p(sample), p(timesteps), p(context), p(image_embeds), p(out),
+                                              C.c_void_p(s.cuda_stream)), "i2v_unet_forward")
+        return out
 
     def capture(self, stream, launch):
         """capture what `launch()` issues on `stream` (a torch.cuda.Stream made current for the call) as the handle's step.
-        `launch` must not allocate through torch (pass every kernel wrapper its `out=`)."""
+        `launch` must not allocate through torch: `self.forward` and kernel wrappers given their `out=`."""
         s = C.c_void_p(stream.cuda_stream)
         with torch.cuda.stream(stream):
             _lib.check(self._lib.i2v_unet_capture_step(self._h, s), "i2v_unet_capture_step")
             try:
                 launch()
-            finally:
-                rc = self._lib.i2v_unet_end_capture(self._h)
-            _lib.check(rc, "i2v_unet_end_capture")
+            except BaseException:
+                self._lib.i2v_unet_abort_capture(self._h)
+                raise
+            _lib.check(self._lib.i2v_unet_end_capture(self._h), "i2v_unet_end_capture")
 
     def replay(self, stream):
         _lib.check(self._lib.i2v_unet_replay_step(self._h, C.c_void_p(stream.cuda_stream)), "i2v_unet_replay_step")

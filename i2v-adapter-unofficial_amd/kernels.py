@@ -436,27 +436,27 @@ def cross_attn_fused_supported(rows, channels, heads, head_dim, ctx_len, rows_pe
 def pack_ctx_fragments(k, vt, heads, ctx_len, out=None):
     """`ctx_frag` of i2v_cross_attn_fused_f16 from the projected context as the other kernels take it -- k [n_ctx * ctx_len, C],
     vt [n_ctx, C, >= ctx_len] (V^T) -- as MFMA operand fragments [n_ctx][heads][30][64][4], zero beyond the context's length
-    and the head's width.  A handful of small torch ops: done once per prompt (`ProjectedContext`), not per step.
+    and the head's width (i2v_pack_ctx_fragments_f16; once per prompt with a `ProjectedContext`, else once per forward).
     `out`: a previous result to overwrite in place (a captured hipGraph keeps reading that memory for the next prompt)."""
+    lib = _lib.load()
+    k, ldk = _mat(k, "k")
+    _req(vt, "vt")
+    if vt.dim() != 3 or vt.stride(2) != 1:
+        raise ValueError(f"pack_ctx_fragments: vt must be [n_ctx, C, >= ctx_len] with unit stride along the keys, got {tuple(vt.shape)}")
     n_ctx, c = vt.shape[0], vt.shape[1]
     d = c // heads
     dt, kt_n = (d + 15) // 16, 5
-    if ctx_len > 16 * kt_n or k.shape[0] != n_ctx * ctx_len:
-        raise ValueError(f"pack_ctx_fragments: k {tuple(k.shape)} / ctx_len {ctx_len}")
-    kp = torch.zeros((n_ctx, 16 * kt_n, heads, 16 * dt), dtype=f16, device=k.device)
-    kp[:, :ctx_len, :, :d] = k[:, :c].reshape(n_ctx, ctx_len, heads, d)
-    kf = kp.view(n_ctx, kt_n, 16, heads, dt, 4, 4).permute(0, 3, 1, 4, 5, 2, 6)               # [n, h, kt, t, g, r, j]
-    vp = torch.zeros((n_ctx, heads, 16 * dt, 16 * kt_n), dtype=f16, device=k.device)
-    vp[:, :, :d, :ctx_len] = vt[:, :, :ctx_len].reshape(n_ctx, heads, d, ctx_len)
-    vf = vp.view(n_ctx, heads, dt, 16, kt_n, 4, 4).permute(0, 1, 2, 4, 5, 3, 6)               # [n, h, t, kt, g, r, j]
-    new = torch.cat([kf.reshape(n_ctx, heads, kt_n * dt, 64, 4), vf.reshape(n_ctx, heads, dt * kt_n, 64, 4)], dim=2).contiguous()
-    if new.numel() != _lib.load().i2v_cross_attn_fused_ctx_elems(n_ctx, heads, d):
+    if ctx_len > 16 * kt_n or k.shape[0] != n_ctx * ctx_len or k.shape[1] < c or vt.shape[2] < ctx_len or c % heads:
+        raise ValueError(f"pack_ctx_fragments: k {tuple(k.shape)} / vt {tuple(vt.shape)} / ctx_len {ctx_len}")
+    shape = (n_ctx, heads, 2 * kt_n * dt, 64, 4)
+    if n_ctx * heads * 2 * kt_n * dt * 256 != lib.i2v_cross_attn_fused_ctx_elems(n_ctx, heads, d):
         raise RuntimeError("pack_ctx_fragments: size differs from i2v_cross_attn_fused_ctx_elems")
     if out is None:
-        return new
-    if out.shape != new.shape or out.dtype != new.dtype:
-        raise ValueError(f"pack_ctx_fragments: out is {tuple(out.shape)}, expected {tuple(new.shape)}")
-    out.copy_(new)
+        out = torch.empty(shape, dtype=f16, device=k.device)
+    elif tuple(out.shape) != shape or out.dtype != f16 or not out.is_contiguous():
+        raise ValueError(f"pack_ctx_fragments: out is {tuple(out.shape)}, expected {shape}")
+    _lib.check(lib.i2v_pack_ctx_fragments_f16(_p(k), ldk, _p(vt), vt.stride(1), vt.stride(0), _p(out), n_ctx, heads, d, ctx_len,
+                                              _stream()), "i2v_pack_ctx_fragments_f16")
     return out
 
 

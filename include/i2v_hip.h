@@ -466,6 +466,15 @@ int i2v_repeat_rows_f16(const void* x, void* y, int64_t rows_in, int64_t cols, i
 int i2v_copy3d_f16(const void* src, int64_t src_batch_stride, int64_t ld_src, void* dst, int64_t dst_batch_stride,
                    int64_t ld_dst, int64_t batches, int64_t rows, int64_t cols, i2v_stream_t stream);
 
+/* (ABI 9) `ctx_frag` of i2v_cross_attn_fused_f16 from the projected context as the other kernels take it: k fp16 [n_ctx * ctx_len, ldk]
+ * (head h in columns h * head_dim ..), vt fp16 V^T[n_ctx][heads * head_dim][>= ctx_len] (row / batch strides in elements) ->
+ * out fp16 [n_ctx][heads][2 * 5 * ceil(head_dim / 16)][64][4] (i2v_pack_ctx_fragments_elems() elements), zero beyond ctx_len (<= 80)
+ * and head_dim.  Serves i2v:527-532 / unet:1263-1279 (to_k / to_v of the prompt and of the IP-Adapter's image tokens); until ABI 9
+ * the host mirror assembled it with torch index ops, which kept a whole-model forward from being library launches only. */
+int64_t i2v_pack_ctx_fragments_elems(int32_t n_ctx, int32_t heads, int32_t head_dim);
+int i2v_pack_ctx_fragments_f16(const void* k, int64_t ldk, const void* vt, int64_t vt_row_stride, int64_t vt_batch_stride, void* out,
+                               int32_t n_ctx, int32_t heads, int32_t head_dim, int32_t ctx_len, i2v_stream_t stream);
+
 /* One DDIM step around the UNet call, pipe:666-691, split in the two halves that bracket it.
  *   prep : latents[:, 0] = cond (pipe:669); model_in = tokens(cat([latents] * cfg_copies)) fp16, channels
  *          padded to c_pad (pipe:672-673; scale_model_input is the identity for DDIM).
@@ -638,15 +647,29 @@ int i2v_adamw_guarded_f32(float* param, const float* grad, float* exp_avg, float
 int i2v_axpby_f32(float* y, const float* x, float a, float b, int64_t n, i2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * (ABI 8) Model handle: the thin whole-model layer of SURVEY 8(b) over the entry points above, for a host that is not this
- * package's Python mirror (it serves the role of `self.unet = unet` + the hipGraph per DDIM step, pipe:96, 676-683).  The handle
- * owns (a) the model's configuration, (b) a registry of the caller's weight buffers under their state-dict keys
- * (`unet.state_dict()` names, SURVEY App. C: the library never copies or frees them), (c) the plan of one denoising step's
- * problem and (d) ONE captured step: the host issues the step's launches -- the per-kernel entry points, in the order of
- * unet:1289-1451 -- between i2v_unet_capture_step and i2v_unet_end_capture on its own stream, and replays them per timestep.
- * What it deliberately does NOT contain is the layer sequencing itself (`i2v_unet_forward`): that is blocks.py + kernels.py of
- * the host mirror, 2 200 lines that would buy no speed in C++.  Every buffer a captured launch touches must stay
- * allocated, by the caller, until the handle is destroyed or a new step is captured.
+ * Model handle (ABI 8; whole-model forward since ABI 9): the layer of SURVEY 8(b) over the entry points above for a host that is
+ * NOT this package's Python mirror -- it serves `self.unet = unet`, `self.unet(latent_model_input, t, ...)` and the hipGraph per
+ * DDIM step (pipe:96, 676-683; unet:1289-1451).
+ *
+ * The handle owns (a) the model's configuration, (b) a registry of the caller's weight buffers by key, (c) the step's problem
+ * (i2v_unet_plan), (d) a LAUNCH PLAN of one forward for that problem and (e) optionally one captured step.
+ *
+ * The launch plan (i2v_unet_set_plan) is the forward of unet:1289-1451 as data: the exact sequence of this header's entry points
+ * one `UNetMotionCrossFrameAttnModel.forward` issues for the planned problem -- entry-point id + its parameter struct (or flat
+ * arguments) per launch -- with every device pointer replaced by a relocation:
+ *     weight  (key index, byte offset)   resolved through the registry (i2v_unet_set_weight), so `set_weight` decides what the
+ *                                        forward reads.  Keys are the KERNEL-LAYOUT packs of the host mirror
+ *                                        (`<module path>#<pack name>`: conv weights in contraction order, GEGLU rows interleaved,
+ *                                        LayerNorm-folded projections, MFMA-fragment-ordered operands of the fused kernels ...),
+ *                                        exported once, offline, with the plan (handle.py `record_forward_plan`,
+ *                                        `export_weights`); no packing arithmetic happens at run time
+ *     arena   (byte offset)              an activation / workspace inside ONE caller-owned arena of i2v_unet_activation_bytes()
+ *                                        bytes (i2v_unet_set_workspace): the recorded allocation pattern of the forward
+ *     io      (slot, byte offset)        one of the forward's arguments (I2V_IO_*)
+ * i2v_unet_forward resolves them and issues the launches in C on the caller's stream: no Python, no torch, no allocation, no
+ * synchronisation -- capturable between i2v_unet_capture_step and i2v_unet_end_capture together with the host's own DDIM update
+ * (i2v_ddim_prep / i2v_ddim_cfg_step).  The plan is made by recording the host mirror once per (problem, switches) in the build
+ * environment -- the sequencing logic of blocks.py / kernels.py is not duplicated in C++.
  * One handle per (device, stream); not thread-safe; no call synchronises the device except i2v_unet_destroy's release of the graph.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct i2v_unet i2v_unet;
@@ -664,24 +687,45 @@ typedef struct i2v_unet_plan_t {
 } i2v_unet_plan_t;
 #define I2V_DTYPE_F16 0
 #define I2V_DTYPE_F32 1
+/* the forward's arguments as relocation slots of a launch plan */
+enum { I2V_IO_SAMPLE = 0, I2V_IO_TIMESTEPS = 1, I2V_IO_CONTEXT = 2, I2V_IO_IMAGE_EMBEDS = 3, I2V_IO_OUT = 4, I2V_IO_SLOTS = 5 };
 
 int i2v_unet_create(const i2v_unet_config* cfg, i2v_unet** out);
 int i2v_unet_destroy(i2v_unet* h);
-/* registers (or replaces) the caller's buffer for a state-dict key; ndim <= 4 */
+/* registers (or replaces) the caller's buffer for a key; ndim <= 4.  The library never copies or frees it. */
 int i2v_unet_set_weight(i2v_unet* h, const char* key, const void* ptr, int32_t dtype, int32_t ndim, const int64_t* shape);
 /* the registered buffer of a key (0 and *ptr = NULL when absent); shape may be NULL */
 int i2v_unet_get_weight(const i2v_unet* h, const char* key, const void** ptr, int32_t* dtype, int32_t* ndim, int64_t* shape);
 int64_t i2v_unet_num_weights(const i2v_unet* h);
 /* validates and records the step's problem: frames <= motion_max_seq_length (unet:725), even latent sizes at every level
- * (height, width multiples of 8: pipe:213-214 in latent units), ctx_len >= 1; a new plan drops the captured step */
+ * (height, width multiples of 8: pipe:213-214 in latent units), ctx_len >= 1; a new problem drops the launch plan and the
+ * captured step */
 int i2v_unet_plan(i2v_unet* h, const i2v_unet_plan_t* plan);
-/* fp16 bytes of the largest activation of the planned step (batch x frames x height x width x 320 channels at the first
- * level): what a host sizes its ping-pong buffers with */
+/* (ABI 9) installs a launch plan (the blob handle.py `record_forward_plan` writes; copied).  Checked: magic / version, the ABI
+ * version it was recorded against, sizeof of every parameter struct it carries, entry-point ids, relocation targets inside their
+ * payloads, and that it was recorded for exactly the planned problem (i2v_unet_plan first).  Drops the captured step. */
+int i2v_unet_set_plan(i2v_unet* h, const void* blob, int64_t bytes);
+/* bytes of the ONE arena the installed plan's activations and workspaces live in (0 without a plan) */
 int64_t i2v_unet_activation_bytes(const i2v_unet* h);
+/* launches of the installed plan / distinct weight keys it names (0 without a plan); the i-th key (NULL out of range) */
+int32_t i2v_unet_plan_launches(const i2v_unet* h);
+int32_t i2v_unet_plan_num_keys(const i2v_unet* h);
+const char* i2v_unet_plan_key(const i2v_unet* h, int32_t i);
+/* the caller's arena: >= i2v_unet_activation_bytes() bytes, 256-byte aligned, alive as long as forwards / a captured step use it */
+int i2v_unet_set_workspace(i2v_unet* h, void* arena, int64_t bytes);
+/* (ABI 9) unet:1289-1451 for the planned problem: sample fp16 [batch, frames, in_channels, height, width], timesteps fp32 [batch],
+ * context fp16 [batch, ctx_len, cross_attention_dim], image_embeds fp16 [batch, clip_dim] or NULL (needed iff the plan was
+ * recorded with the IP-Adapter), out [batch, frames, out_channels, height, width] in the sample's dtype.  Asynchronous on `stream`.
+ * I2V_ERR_INVALID_ARG: no plan / arena, a weight key of the plan that is not registered (named in i2v_last_error), a NULL
+ * argument the plan reads; errors of the launches themselves are returned as they come. */
+int i2v_unet_forward(i2v_unet* h, const void* sample, const void* timesteps, const void* context, const void* image_embeds,
+                     void* out, i2v_stream_t stream);
 /* begin / end the capture of one step on `stream` (hipStreamBeginCapture, relaxed mode): everything launched on the stream in
- * between becomes the handle's step */
+ * between -- i2v_unet_forward and the host's DDIM kernels -- becomes the handle's step; i2v_unet_abort_capture ends a capture
+ * whose launches failed and discards it */
 int i2v_unet_capture_step(i2v_unet* h, i2v_stream_t stream);
 int i2v_unet_end_capture(i2v_unet* h);
+int i2v_unet_abort_capture(i2v_unet* h);
 /* launch the captured step once (asynchronous on `stream`); I2V_ERR_INVALID_ARG when nothing has been captured */
 int i2v_unet_replay_step(i2v_unet* h, i2v_stream_t stream);
 int32_t i2v_unet_has_step(const i2v_unet* h);

@@ -135,11 +135,88 @@ def test_model_handle_registry_and_plan_without_a_gpu(lib):
     assert h.i2v_unet_get_weight(hd, b"nope", C.byref(p), None, None, None) == 0 and p.value is None
     # the plan: frames within the positional table (unet:725), latent sizes that halve exactly three times (pipe:213-214)
     assert h.i2v_unet_activation_bytes(hd) == 0 and h.i2v_unet_has_step(hd) == 0
+    assert h.i2v_unet_set_plan(hd, b"x" * 200, 200) == -1 and b"i2v_unet_plan" in h.i2v_last_error()      # the problem first
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 77, 0))) == 0
-    assert h.i2v_unet_activation_bytes(hd) == 2 * 16 * 64 * 64 * 320 * 2
+    assert h.i2v_unet_activation_bytes(hd) == 0                    # ... is the installed launch plan's arena: none yet
+    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"no launch plan" in h.i2v_last_error()
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 33, 64, 64, 77, 0))) == -1 and b"positional table" in h.i2v_last_error()
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 60, 64, 77, 0))) == -1 and b"multiples of 8" in h.i2v_last_error()
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 81, 1))) == -1 and b"image tokens" in h.i2v_last_error()
     assert h.i2v_unet_replay_step(hd, None) == -1 and b"no captured step" in h.i2v_last_error()
     assert h.i2v_unet_end_capture(hd) == -1 and h.i2v_unet_capture_step(hd, None) == -1
     assert h.i2v_unet_destroy(hd) == 0 and h.i2v_unet_destroy(None) == 0
+
+
+def _plan_blob(lib, ops, keys=(), arena=0, problem=(2, 16, 64, 64, 77, 0), abi=None, io_mask=0):
+    """a launch plan by hand (the format handle.py `record_forward_plan` writes; csrc/handle.hip PlanHeader / PlanOp / PlanReloc):
+    ops = [(entry id, struct bytes, [slots], [(payload offset, kind, index, addend)])]"""
+    import struct
+    key_tab = bytearray()
+    for k in keys:
+        key_tab += struct.pack("<I", len(k)) + k + b"\0" * (-len(k) % 4)
+    key_tab += b"\0" * (-len(key_tab) % 8)
+    ops_bin, relocs, payload = [], [], bytearray()
+    for entry, sbytes, slots, rel in ops:
+        blk = bytearray(sbytes) + bytearray(-len(sbytes) % 8) + b"".join(struct.pack("<q", v) for v in slots)
+        ops_bin.append(struct.pack("<IIIIII", entry, len(payload), len(blk), len(relocs), len(rel), len(sbytes)))
+        relocs += [struct.pack("<IIIIQ", off, kind, idx, 0, add) for off, kind, idx, add in rel]
+        payload += blk
+    hdr_size = struct.calcsize("<6I6iQ2I6Q")
+    keys_off = hdr_size
+    ops_off = keys_off + len(key_tab)
+    relocs_off = ops_off + 24 * len(ops_bin)
+    payload_off = relocs_off + 24 * len(relocs)
+    total = payload_off + len(payload)
+    hdr = struct.pack("<6I6iQ2I6Q", 0x50563249, 1, lib.ABI_VERSION if abi is None else abi, len(ops_bin), len(keys), len(relocs), *problem,
+                      arena, io_mask, 0, keys_off, ops_off, relocs_off, payload_off, len(payload), total)
+    return bytes(hdr + key_tab + b"".join(ops_bin) + b"".join(relocs) + payload)
+
+
+def test_model_handle_launch_plan_without_a_gpu(lib):
+    """i2v_unet_set_plan / i2v_unet_forward (ABI 9; unet:1289-1451 as a launch plan): what the library checks before anything is
+    launched -- the blob's magic / ABI / problem / struct sizes / relocation targets, unregistered weight keys, missing arguments and
+    arena -- on hand-made plans; a launch whose own argument check fails returns that entry point's error.  No kernel runs here."""
+    import struct
+    from i2v_adapter_unofficial_amd import handle as H
+    assert list(H.ENTRY_IDS.values()) == list(range(len(H.ENTRY_IDS)))
+    h = lib.load()
+    cfg = lib.UnetConfig(4, 4, (C.c_int32 * 4)(320, 640, 1280, 1280), 2, 8, 768, 32, 32, 8, 1, 0)
+    hd = C.c_void_p()
+    assert h.i2v_unet_create(C.byref(cfg), C.byref(hd)) == 0
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 77, 0))) == 0
+    sp = lambda b: h.i2v_unet_set_plan(hd, b, len(b))
+    empty = _plan_blob(lib, [])
+    assert sp(empty) == 0 and h.i2v_unet_plan_launches(hd) == 0 and h.i2v_unet_plan_num_keys(hd) == 0
+    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == 0          # nothing to launch, nothing read
+    assert sp(empty[:50]) == -1 and b"not a launch plan" in h.i2v_last_error()
+    assert sp(b"XXXX" + empty[4:]) == -1 and b"magic" in h.i2v_last_error()
+    assert sp(_plan_blob(lib, [], abi=lib.ABI_VERSION - 1)) == -1 and b"recorded against ABI" in h.i2v_last_error()
+    assert sp(_plan_blob(lib, [], problem=(2, 8, 64, 64, 77, 0))) == -1 and b"recorded for" in h.i2v_last_error()
+    assert sp(empty + b"\0" * 8) == -1 and b"bytes" in h.i2v_last_error()
+    silu = H.ENTRY_IDS["i2v_silu_f16"]
+    assert sp(_plan_blob(lib, [(99, b"", [0, 0, 0], [])])) == -1 and b"entry point 99" in h.i2v_last_error()
+    assert sp(_plan_blob(lib, [(silu, b"", [0, 0], [])])) == -1 and b"another header" in h.i2v_last_error()      # a slot short
+    gemm = H.ENTRY_IDS["i2v_gemm_f16"]
+    assert sp(_plan_blob(lib, [(gemm, b"\0" * (C.sizeof(lib.GemmParams) - 8), [], [])])) == -1 and b"another header" in h.i2v_last_error()
+    assert sp(_plan_blob(lib, [(silu, b"", [0, 0, 8], [(24, 0, 0, 0)])])) == -1 and b"relocation" in h.i2v_last_error()
+    assert sp(_plan_blob(lib, [(silu, b"", [0, 0, 8], [(0, 1, 3, 0)])], keys=(b"a#w",))) == -1 and b"names key 3" in h.i2v_last_error()
+    assert sp(_plan_blob(lib, [(silu, b"", [0, 0, 8], [(0, 0, 0, 4096)])], arena=1024)) == -1 and b"outside the arena" in h.i2v_last_error()
+    # a plan of one launch: silu(weight `blk#w` -> arena + 256), 8 elements
+    one = _plan_blob(lib, [(silu, b"", [0, 0, 8], [(0, 1, 0, 16), (8, 0, 0, 256)])], keys=(b"blk#w",), arena=1024, io_mask=0)
+    assert sp(one) == 0 and h.i2v_unet_plan_launches(hd) == 1 and h.i2v_unet_plan_key(hd, 0) == b"blk#w" and h.i2v_unet_plan_key(hd, 1) is None
+    assert h.i2v_unet_activation_bytes(hd) == 1024
+    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"arena" in h.i2v_last_error()
+    assert h.i2v_unet_set_workspace(hd, 4096 + 8, 2048) == -1 and b"256-byte aligned" in h.i2v_last_error()
+    assert h.i2v_unet_set_workspace(hd, 4096, 512) == 0
+    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"the plan needs 1024" in h.i2v_last_error()
+    assert h.i2v_unet_set_workspace(hd, 4096, 2048) == 0
+    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"`blk#w` of the launch plan is not registered" in h.i2v_last_error()
+    # an argument the plan reads must be passed
+    needs_ctx = _plan_blob(lib, [(silu, b"", [0, 0, 8], [(0, 2, 2, 0), (8, 0, 0, 0)])], arena=1024, io_mask=1 << 2)
+    assert sp(needs_ctx) == 0
+    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"`context` is NULL" in h.i2v_last_error()
+    # a new problem drops the plan; the same problem keeps it
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 77, 0))) == 0 and h.i2v_unet_plan_launches(hd) == 1
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 8, 64, 64, 77, 0))) == 0 and h.i2v_unet_plan_launches(hd) == 0
+    assert h.i2v_unet_abort_capture(hd) == 0 and h.i2v_unet_abort_capture(None) == -1
+    assert h.i2v_unet_destroy(hd) == 0

@@ -1355,53 +1355,3 @@ def test_gemm_alternating_groups_opt_in_child_process(dev):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     errs = [float(m) for m in re.findall(r"rel err ([0-9.e+-]+)", r.stdout)]
     assert len(errs) == 11 and max(errs) < 2e-3 and "finite False" not in r.stdout, r.stdout
-
-
-def test_model_handle_captures_and_replays_a_step(dev):
-    """the model handle (include/i2v_hip.h "Model handle"): a host with its own buffers registers the weights under
-    their state-dict keys, plans the step, captures the launches it issues through the per-kernel entry points on its stream
-    and replays them -- here two chained GEMMs (the second with a residual) standing in for a step; the replayed result equals
-    the eager one bit for bit, a replay sees new inputs in the same buffers, and a new plan drops the step."""
-    import i2v_adapter_unofficial_amd as pkg
-    k = K()
-    g = torch.Generator().manual_seed(3)
-    x = h(torch.randn(512, 320, generator=g)).half().to(dev)
-    w1, w2 = (h(torch.randn(320, 320, generator=g) * 320 ** -0.5).half().to(dev) for _ in range(2))
-    b1 = h(0.1 * torch.randn(320, generator=g)).half().to(dev)
-    y, z = torch.empty_like(x), torch.empty_like(x)
-
-    def step():
-        k.gemm(x, w1, b1, out=y)
-        k.gemm(y, w2, residual=x, out=z)
-
-    step()
-    torch.cuda.synchronize()
-    eager = z.clone()
-    hd = pkg.UNetHandle(dict(block_out_channels=(320, 640, 1280, 1280)))
-    assert hd.set_weights({"a.weight": w1, "a.bias": b1, "b.weight": w2, "step": torch.zeros(1, dtype=torch.int64)}) == 3
-    ptr, dt, shape = hd.weight_ptr("b.weight")
-    assert ptr == w2.data_ptr() and dt == 0 and shape == (320, 320) and hd.weight_ptr("c.weight") is None
-    assert hd.plan(2, 16, 64, 64) == 2 * 16 * 64 * 64 * 320 * 2 and not hd.has_step
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    z.zero_()
-    hd.capture(s, step)
-    assert hd.has_step
-    hd.replay(s)
-    s.synchronize()
-    assert torch.equal(z, eager), "capture does not execute; the replay does"
-    x.mul_(0.5)                      # new input in the same buffer: the replay reads it
-    torch.cuda.synchronize()
-    hd.replay(s)
-    s.synchronize()
-    step()
-    torch.cuda.synchronize()
-    ref = z.clone()
-    hd.replay(s)
-    s.synchronize()
-    assert torch.equal(z, ref)
-    hd.plan(2, 8, 32, 32)            # a new plan drops the captured step
-    assert not hd.has_step
-    with pytest.raises(Exception, match="no captured step"):
-        hd.replay(s)
-    hd.close()
