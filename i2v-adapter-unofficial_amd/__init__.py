@@ -12,6 +12,9 @@ from ._lib import HipLibraryError  # noqa: F401
 def __getattr__(name):
     # module classes are imported lazily so that `import i2v_adapter_unofficial_amd.kernels` stays light
     import importlib
+    if name in ("blocks", "handle", "checkpoint", "sharding", "vae", "training", "profiling", "i2v_adapter", "unet_motion_cross_frame_attn",
+                "pipeline_i2v_adapter", "image_processor"):
+        return importlib.import_module(f"{__name__}.{name}")
     for mod in ("i2v_adapter", "unet_motion_cross_frame_attn", "pipeline_i2v_adapter", "blocks", "sharding", "vae",
                 "image_processor", "checkpoint", "handle"):
         m = importlib.import_module(f"{__name__}.{mod}")
