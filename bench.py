@@ -244,6 +244,47 @@ def _profile_files(kind):
     return [n for _, n in sorted(out, reverse=True)]
 
 
+def dominant_kernel(by_shape):
+    """The dominant KERNEL of the step (a kernel, not a class of them) from the newest committed rocprofv3 --kernel-trace --stats
+    summary that was taken on exactly this library's kernel sources (profiles/r*_kernel_stats.txt, `# library_source_stamp`): name,
+    calls, average duration, and -- for the flash-attention kernels, whose launches the instrumented step can attribute by head
+    width -- algorithmic FLOP per launch (average over the launches of that head width in one step) and the fraction of the dense
+    fp16 MFMA peak.  Returns a dict (with `reason` instead when no summary matches)."""
+    import re
+    stamp, seen = source_stamp(), []
+    names = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r(\d+)_kernel_stats\.txt", n)),
+                   key=lambda n: -int(re.match(r"r(\d+)", n).group(1)))
+    for name in names:
+        lines = open(os.path.join(ROOT, "profiles", name)).read().splitlines()
+        st = next((ln.split()[2] for ln in lines if ln.startswith("# library_source_stamp")), None)
+        seen.append(f"{name}: {st}")
+        if st != stamp:
+            continue
+        rows = []
+        for ln in lines:
+            m = re.match(r"(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+            if m and not ln.startswith("#") and "spin_kernel" not in m.group(1):
+                rows.append((m.group(1).strip(), int(m.group(2)), float(m.group(3)), float(m.group(4)), float(m.group(5))))
+        if not rows:
+            continue
+        kname, calls, total_ms, avg_us, pct = max(rows, key=lambda r: r[2])
+        out = {"name": kname, "calls": calls, "avg_us": avg_us, "pct_of_kernel_time": pct,
+               "source": f"profiles/{name} (rocprofv3 --kernel-trace --stats, same kernel sources)"}
+        m = re.match(r".*attn_kernel<\s*\d+,\s*(\d+),", kname)
+        if m and by_shape:
+            dpad = int(m.group(1))           # head_dim padded to a multiple of 16
+            sel = [d for n, d in by_shape.items() if n.startswith("attention ") and
+                   (int(re.search(r" d(\d+)", n).group(1)) + 15) // 16 * 16 == dpad]
+            n_calls = sum(d["calls"] for d in sel)
+            if n_calls:
+                fl = sum(d["flops"] for d in sel) / n_calls
+                out.update(flops_per_launch=fl, achieved_tflops=fl / (avg_us * 1e-6) / 1e12,
+                           frac=fl / (avg_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                           flops_note="algorithmic 4 Lq Lk C per image, averaged over this head width's launches of one step")
+        return out
+    return {"reason": f"no profiles/r*_kernel_stats.txt was taken on this library's kernel sources ({stamp}); found {seen}"}
+
+
 def run_windows(groups, steps, n_windows, n_tab, load_group, run_step, reset_step_index, sync, world, device):
     """The timed region, `n_windows` times: exactly `steps` steps for every group of this rank between barrier + sync on
     both sides, elapsed = MAX over ranks (an all-reduce of one double OUTSIDE the timed bracket).  Returns the list of
@@ -588,6 +629,8 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom, "achieved": d["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": d["gbps"] / HBM_PEAK_GBPS, "traffic": None, "launches": d["calls"],
                         "avg_launch_us": d["ms"] * 1e3 / d["calls"], "bytes_per_launch": d["bytes"] / d["calls"]}
+            roof["class_note"] = "`kernel` is a CLASS of launches timed live; the single dominant kernel is `dominant_kernel`"
+            roof["dominant_kernel"] = dominant_kernel(prof.by_shape())
             # HBM-side bytes per launch of that class: PMC counters cannot be read from inside the process, so this is
             # the committed result of the separate rocprofv3 --pmc passes over this same command
             # (tools/pmc_traffic.sh -> profiles/r2_traffic.json), valid for the default workload only

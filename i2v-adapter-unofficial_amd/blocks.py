@@ -35,6 +35,12 @@ class HipModule(nn.Module):
     def _pack(self):
         return {}
 
+    def __getstate__(self):
+        # the kernel-layout packs are a cache (rebuilt on first use) and hold thunks: neither is pickled with the module
+        state = self.__dict__.copy()
+        state["_packed"], state["_packed_key"] = None, None
+        return state
+
     def packed(self):
         key = tuple((p.data_ptr(), p._version, p.dtype) for p in self.parameters())
         key += tuple((b.data_ptr(), b._version) for b in self.buffers())
@@ -418,11 +424,10 @@ class Upsample2D(HipModule):
         return dict(w=pack_conv3x3(self.conv.weight), b=w16(self.conv.bias))
 
     def _fwd(self, x, output_size=None):
-        if output_size is not None and tuple(output_size) != (2 * x.shape[1], 2 * x.shape[2]):
-            raise NotImplementedError("Upsample2D: only exact 2x nearest upsampling is implemented "
-                                      "(latent sizes must be divisible by 2**num_upsamplers)")
+        # output_size: the skip tensor's size when the latent size is not a multiple of 8 (unet:1304-1311, 1414-1415): 2x or 2x - 1
         p = self.packed()
-        return K.conv3x3(x, p["w"], p["b"], upsample=True)          # (read by conv_shortcut resnets only: no low half needed)
+        return K.conv3x3(x, p["w"], p["b"], upsample=True,          # (read by conv_shortcut resnets only: no low half needed)
+                         output_size=None if output_size is None else tuple(int(v) for v in output_size))
 
     def forward(self, hidden_states, output_size=None, scale: float = 1.0):
         return from_tokens(self._fwd(to_tokens(hidden_states), output_size), hidden_states.dtype)
@@ -608,7 +613,9 @@ class FeedForward(HipModule):
         out = LazyPack(w1=w1, b1=b1, w2=w16(self.net[2].weight), b2=w16(self.net[2].bias))
         if self.activation_fn == "geglu" and K.ff_fused_supported(128, self.net[2].weight.shape[0], self.net[2].weight.shape[1]):
             # operands of the one-launch form (i2v_ff_fused_f16: the SD-1.5 64^2 width), built on first use
-            out.lazy("fused", lambda: K.pack_ff_fused(proj.weight, proj.bias, self.net[2].weight, self.net[2].bias))
+            # (thunks capture the child modules, never `self`: module -> _packed -> thunk -> module would be a reference cycle that
+            #  keeps the fp16 packs alive until a cyclic gc pass after `del unet`)
+            out.lazy("fused", lambda proj=proj, lin=self.net[2]: K.pack_ff_fused(proj.weight, proj.bias, lin.weight, lin.bias))
         return out
 
     def _fwd(self, n2d, residual2d, **store):
@@ -738,11 +745,11 @@ class TemporalTransformerBlock(HipModule):
         # the fused LayerNorm + q / k / v + attention kernel's weights (per head, rows padded to 16) and the fused feed-forward's
         # fp32 LayerNorm constants: built on first use (LazyPack)
         for i, attn in enumerate((self.attn1, self.attn2), 1):
-            p.lazy(f"wqkv{i}", lambda attn=attn: K.pack_motion_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, self.heads))
-            p.lazy(f"wo_frag{i}", lambda attn=attn: K.pack_attn_out(attn.to_out[0].weight, attn.to_out[0].bias, self.heads))
+            p.lazy(f"wqkv{i}", lambda attn=attn, heads=self.heads: K.pack_motion_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, heads))
+            p.lazy(f"wo_frag{i}", lambda attn=attn, heads=self.heads: K.pack_attn_out(attn.to_out[0].weight, attn.to_out[0].bias, heads))
         self._ma_tables = {}          # (site, frames) -> (gamma fp32, beta + pe[frame] fp32), made on first use
-        p.lazy("g3_f32", lambda: self.norm3.weight.detach().float().contiguous())
-        p.lazy("b3_f32", lambda: self.norm3.bias.detach().float().contiguous())
+        p.lazy("g3_f32", lambda n3=self.norm3: n3.weight.detach().float().contiguous())
+        p.lazy("b3_f32", lambda n3=self.norm3: n3.bias.detach().float().contiguous())
         return p
 
     def _fold_ok(self, t, frames):
@@ -847,7 +854,7 @@ class TransformerTemporalModel(HipModule):
         p = LazyPack(g=w16(self.norm.weight), b=w16(self.norm.bias), wi=w16(self.proj_in.weight),
                      bi=w16(self.proj_in.bias), wo=w16(self.proj_out.weight), bo=w16(self.proj_out.bias))
         # proj_out as the tail of the last block's fused feed-forward (the SD-1.5 64^2 width: a square 320 x 320 Linear)
-        p.lazy("tail", lambda: ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels))
+        p.lazy("tail", lambda po=self.proj_out, ci=self.inner_dim, co=self.in_channels: ff_tail_operands(po.weight, po.bias, ci, co))
         return p
 
     def _fwd(self, x, num_frames):

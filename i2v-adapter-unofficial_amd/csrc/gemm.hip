@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const i2v_gemm_params p, cons
           bool ok;
           if (p.upsample) {
             const int uy = crow[i].oy - 1 + dy, ux = crow[i].ox - 1 + dx;
-            ok = (uy >= 0) && (ux >= 0) && (uy < 2 * p.in_h) && (ux < 2 * p.in_w);
+            ok = (uy >= 0) && (ux >= 0) && (uy < p.out_h) && (ux < p.out_w);      // (out = 2 in, or 2 in - 1: forward_upsample_size)
             iy = uy >> 1;
             ix = ux >> 1;
           } else {
@@ -404,8 +404,11 @@ extern "C" int i2v_gemm_f16(const i2v_gemm_params* pp, i2v_stream_t stream) {
     const int padsum = p.asym_pad ? 1 : 2;
     const int eh = p.upsample ? 2 * p.in_h : (p.in_h + padsum - 3) / p.stride + 1;
     const int ew = p.upsample ? 2 * p.in_w : (p.in_w + padsum - 3) / p.stride + 1;
-    I2V_CHECK_ARG(p.out_h == eh && p.out_w == ew, "i2v_gemm_f16: conv output size mismatch (%d x %d vs %d x %d)",
-                  p.out_h, p.out_w, eh, ew);
+    // upsample: nearest to 2 in, or to 2 in - 1 (unet:1304-1311, 1414-1415 `forward_upsample_size`: the skip tensor of a level whose
+    // size was odd before its stride-2 down-sampler; F.interpolate(size=2 in - 1, mode="nearest") reads source floor(i in / (2 in - 1))
+    // = i >> 1, the same gather, with the zero padding at the smaller image's border)
+    I2V_CHECK_ARG((p.out_h == eh || (p.upsample && p.out_h == eh - 1)) && (p.out_w == ew || (p.upsample && p.out_w == ew - 1)),
+                  "i2v_gemm_f16: conv output size mismatch (%d x %d vs %d x %d)", p.out_h, p.out_w, eh, ew);
     I2V_CHECK_ARG((int64_t)p.n_img * p.out_h * p.out_w == p.M, "i2v_gemm_f16: conv M != n_img*out_h*out_w");
     I2V_CHECK_ARG(p.lda >= p.cin, "i2v_gemm_f16: conv pixel stride lda < cin");
     I2V_CHECK_ARG((int64_t)p.n_img * p.in_h * p.in_w < (1ll << 31), "i2v_gemm_f16: conv image too large");

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
         bool ok;
         if (p.upsample) {
           const int uy = cy[i] - 1 + dy, ux = cx[i] - 1 + dx;
-          ok = (uy >= 0) && (ux >= 0) && (uy < 2 * p.in_h) && (ux < 2 * p.in_w);
+          ok = (uy >= 0) && (ux >= 0) && (uy < p.out_h) && (ux < p.out_w);      // (out = 2 in, or 2 in - 1: forward_upsample_size)
           iy = uy >> 1;
           ix = ux >> 1;
         } else {
@@ -1427,6 +1427,8 @@ int i2v_gemm_big_gn_rows(const i2v_gemm_params& p, int vec4) {
   if (plan != 256 && plan != 128) return 0;
   if (p.a_mode != I2V_A_CONV3X3 || big_bn(p) != BIG_BN || p.epilogue != I2V_EPI_NONE || p.store_mode != I2V_STORE_ROWMAJOR) return 0;
   if (p.residual || p.ln_wsum || p.c_is_f32 || p.rows_per_w > 0 || p.a_perm_frames > 0) return 0;
+  // the partials describe acc + bias + rowvec: with an output scale the stored tensor is another one
+  if (p.out_scale != 1.0f) return 0;
   if (p.gn_groups <= 0 || p.N % p.gn_groups != 0) return 0;
   const int cpg = p.N / p.gn_groups, hw = p.out_h * p.out_w;
   if (cpg <= 0 || BIG_BN % cpg != 0 || p.M % plan != 0 || hw % plan != 0) return 0;

@@ -191,9 +191,7 @@ extern "C" int i2v_unet_plan(i2v_unet* h, const i2v_unet_plan_t* plan) {
                 "i2v_unet_plan: non-positive size");
   I2V_CHECK_ARG(plan->frames <= h->cfg.motion_max_seq_length, "i2v_unet_plan: num_frames %d exceeds the positional table (%d)",
                 plan->frames, h->cfg.motion_max_seq_length);
-  // three stride-2 down-samplers: the halving must be exact at every level (unet:1304-1311 forward_upsample_size is not taken)
-  I2V_CHECK_ARG(plan->height % 8 == 0 && plan->width % 8 == 0, "i2v_unet_plan: latent height %d / width %d must be multiples of 8",
-                plan->height, plan->width);
+  // (sizes that are not multiples of 8 take the forward_upsample_size path, unet:1304-1311: whatever the recorded plan does)
   I2V_CHECK_ARG(!plan->has_ip || h->cfg.ip_num_tokens > 0, "i2v_unet_plan: has_ip without image tokens in the configuration");
   drop_step(h);
   if (!h->planned || memcmp(&h->plan, plan, sizeof(*plan)) != 0) drop_plan(h);

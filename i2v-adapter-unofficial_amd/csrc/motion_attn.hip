@@ -592,6 +592,8 @@ extern "C" int i2v_motion_attn_f16(const i2v_motion_attn_params* pp, i2v_stream_
   ma_args a = {};
   a.x = p.x; a.ldx = p.ldx; a.gamma = p.gamma; a.shift = p.shift; a.ld_shift = p.ld_shift; a.w = p.w_qkv; a.out = p.out;
   a.ldo = p.ldo; a.eps = p.eps;
+  // (OUTP: the residual rows go through a buffer descriptor and per-lane offsets of 32 bits)
+  I2V_CHECK_ARG(p.w_o == nullptr || p.ldx < (1 << 23), "i2v_motion_attn_f16: ldx (%lld) must be below 2^23 with the out-projection", (long long)p.ldx);
   I2V_CHECK_ARG((p.w_o == nullptr) == (p.b_o == nullptr) && al16(p.w_o) && al16(p.b_o),
                 "i2v_motion_attn_f16: w_o and b_o come together, 16-byte aligned");
   a.w_o = p.w_o; a.b_o = p.b_o;
@@ -638,6 +640,8 @@ extern "C" int i2v_cross_attn_fused_f16(const i2v_cross_attn_fused_params* pp, i
   a.ctx_frag = p.ctx_frag; a.lt = p.ctx_len;
   a.ip_frag = p.ip_frag; a.ip_len = p.ip_frag ? p.ip_len : 0; a.ip_scale = p.ip_scale;
   a.tiles_per_ctx = (int32_t)(p.rows_per_ctx / (MA_PIX * MA_F));
+  // (OUTP: the residual rows go through a buffer descriptor and per-lane offsets of 32 bits)
+  I2V_CHECK_ARG(p.w_o == nullptr || p.ldx < (1 << 23), "i2v_cross_attn_fused_f16: ldx (%lld) must be below 2^23 with the out-projection", (long long)p.ldx);
   I2V_CHECK_ARG((p.w_o == nullptr) == (p.b_o == nullptr) && al16(p.w_o) && al16(p.b_o),
                 "i2v_cross_attn_fused_f16: w_o and b_o come together, 16-byte aligned");
   a.w_o = p.w_o; a.b_o = p.b_o;

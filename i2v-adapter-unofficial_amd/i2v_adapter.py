@@ -131,27 +131,28 @@ class I2VAdapterTransformerBlock(HipModule):
             p["w_o2"], p["b_o2"] = w16(self.attn2.to_out[0].weight), w16(self.attn2.to_out[0].bias)
             p["f_q2"] = fold_layernorm(self.attn2.to_q.weight, None, self.norm2.weight, self.norm2.bias)
             # the fused LayerNorm + to_q + text cross-attention kernel's operands (64^2 level of SD-1.5): built on first use
-            p.lazy("wq2_frag", lambda: K.pack_cross_q(self.attn2.to_q.weight, self.heads))
-            p.lazy("wo2_frag", lambda: K.pack_attn_out(self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, self.heads))
-            p.lazy("g2_f32", lambda: self.norm2.weight.detach().float().contiguous())
-            p.lazy("b2_f32", lambda: self.norm2.bias.detach().float().contiguous())
+            # (thunks capture child modules and values, never `self`: no module -> _packed -> thunk -> module cycle)
+            p.lazy("wq2_frag", lambda a2=self.attn2, heads=self.heads: K.pack_cross_q(a2.to_q.weight, heads))
+            p.lazy("wo2_frag", lambda a2=self.attn2, heads=self.heads: K.pack_attn_out(a2.to_out[0].weight, a2.to_out[0].bias, heads))
+            p.lazy("g2_f32", lambda n2=self.norm2: n2.weight.detach().float().contiguous())
+            p.lazy("b2_f32", lambda n2=self.norm2: n2.bias.detach().float().contiguous())
         # LayerNorm folded into the consuming projections (i2v:444-445 -> q | k | q_adapter and V^T; i2v:510 -> attn2.to_q;
         # i2v:539 -> GEGLU): operands (W o gamma, row sums, W beta + b) of the LayerNorm-folded GEMM
         p["f_qkq"] = fold_layernorm(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), None,
                                     self.norm1.weight, self.norm1.bias)
         p["f_v1"] = fold_layernorm(a1.to_v.weight, None, self.norm1.weight, self.norm1.bias)
         p["f_ff"] = self.ff.fold_norm(self.norm3)
-        p.lazy("g3_f32", lambda: self.norm3.weight.detach().float().contiguous())
-        p.lazy("b3_f32", lambda: self.norm3.bias.detach().float().contiguous())
+        p.lazy("g3_f32", lambda n3=self.norm3: n3.weight.detach().float().contiguous())
+        p.lazy("b3_f32", lambda n3=self.norm3: n3.bias.detach().float().contiguous())
         # the one-launch LayerNorm 1 + [q | k | q_adapter] + V^T projection's operands (64^2 level of SD-1.5), with and without
         # the adapter's query: built on first use
         if K.ln_qkv_supported(128, self.dim, 3 * self.dim, 128):
-            p.lazy("g1_f32", lambda: self.norm1.weight.detach().float().contiguous())
-            p.lazy("b1_f32", lambda: self.norm1.bias.detach().float().contiguous())
-            p.lazy("w_lnqkv3", lambda: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), a1.to_v.weight))
-            p.lazy("w_lnqkv2", lambda: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight], dim=0), a1.to_v.weight))
+            p.lazy("g1_f32", lambda n1=self.norm1: n1.weight.detach().float().contiguous())
+            p.lazy("b1_f32", lambda n1=self.norm1: n1.bias.detach().float().contiguous())
+            p.lazy("w_lnqkv3", lambda a1=a1, ad=ad: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight, ad.to_q.weight], dim=0), a1.to_v.weight))
+            p.lazy("w_lnqkv2", lambda a1=a1: K.pack_ln_qkv(torch.cat([a1.to_q.weight, a1.to_k.weight], dim=0), a1.to_v.weight))
             # ... and the adapter's K0 | V0^T over the frame-0 rows (i2v:484-492) the same way
-            p.lazy("w_lnkv_ad", lambda: K.pack_ln_qkv(ad.to_k.weight, ad.to_v.weight))
+            p.lazy("w_lnkv_ad", lambda ad=ad: K.pack_ln_qkv(ad.to_k.weight, ad.to_v.weight))
         return p
 
     def _fold_ok(self, x, L, rows_qkq):
@@ -380,7 +381,7 @@ class I2VAdapterTransformer2DModel(HipModule):
                      wi=w16(self.proj_in.weight.reshape(self.inner_dim, self.in_channels)), bi=w16(self.proj_in.bias),
                      wo=w16(self.proj_out.weight.reshape(self.in_channels, self.inner_dim)), bo=w16(self.proj_out.bias))
         # proj_out as the tail of the last block's fused feed-forward (the SD-1.5 64^2 width): built on first use
-        p.lazy("tail", lambda: ff_tail_operands(self.proj_out.weight, self.proj_out.bias, self.inner_dim, self.in_channels))
+        p.lazy("tail", lambda po=self.proj_out, ci=self.inner_dim, co=self.in_channels: ff_tail_operands(po.weight, po.bias, ci, co))
         return p
 
     def packed(self):

@@ -210,7 +210,7 @@ def conv_k_block(cin: int) -> int:
 
 
 def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, rows_per_vec=0, residual=None,
-            out_scale=1.0, asym_pad=False, out_f32=False, gn_stats_groups=0, precise=False):
+            out_scale=1.0, asym_pad=False, out_f32=False, gn_stats_groups=0, precise=False, output_size=None):
     """3x3 / pad 1 convolution of a token-major image x [N, H, W, Cin] with w_packed [Cout, 9 * Cin]
     (k ordered as `blocks.pack_conv3x3` lays it out: tap-major, or channel-block-major when Cin % 64 == 0, see
     conv_k_block); optional nearest-2x upsampling of the input first.  asym_pad (stride 2): no
@@ -219,7 +219,10 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
     gn_stats_groups > 0: returns (out, stats) -- stats = the GroupNorm statistics of `out` over that many channel groups as
     partials written by the convolution's epilogue (i2v_gemm_params.gn_partial), to hand to `groupnorm(out, ..., stats=stats)`,
     or None where the epilogue form is not implemented for this problem (the norm then runs its own statistics pass).
-    precise: as `gemm` (the result and the residual are tensors of the precise residual stream)."""
+    precise: as `gemm` (the result and the residual are tensors of the precise residual stream).
+    output_size (upsample only): (2 H, 2 W) or one less in either dimension -- `F.interpolate(size=output_size, mode="nearest")`
+    in front of the convolution, the reference's forward_upsample_size path for latent sizes that are not multiples of 8
+    (unet:1304-1311, 1414-1415)."""
     lib = _lib.load()
     _req(x, "x")
     if x.dim() != 4 or not x.is_contiguous():
@@ -235,7 +238,14 @@ def conv3x3(x, w_packed, bias=None, *, stride=1, upsample=False, rowvec=None, ro
         if stride != 1:
             raise ValueError("upsample conv must have stride 1")
         oh, ow = 2 * h, 2 * wd
+        if output_size is not None:
+            oh, ow = int(output_size[0]), int(output_size[1])
+            if oh not in (2 * h, 2 * h - 1) or ow not in (2 * wd, 2 * wd - 1):
+                raise NotImplementedError(f"upsample to {(oh, ow)} from {(h, wd)}: only 2x and 2x - 1 (a level that was odd before its "
+                                          "stride-2 down-sampler) occur on the UNet's path")
     else:
+        if output_size is not None:
+            raise ValueError("output_size belongs to an upsampling convolution")
         padsum = 1 if asym_pad else 2
         oh, ow = (h + padsum - 3) // stride + 1, (wd + padsum - 3) // stride + 1
     M = n * oh * ow

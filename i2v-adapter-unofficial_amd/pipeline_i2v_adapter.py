@@ -172,8 +172,8 @@ class I2VAdapterPipeline:
         # the CFG halves are copies of one tensor at one timestep (pipe:672-673): what does not depend on the prompt is
         # computed once (unet._fwd_tokens, cfg_shared)
         y = unet._fwd_tokens(x, None, True, st.get("ctx_proj") or st["ctx_text"], st["ctx_ip"],
-                             st["num_frames"], cfg_shared=CFG_SHARED and st["copies"] == 2,
-                             temb_proj=temb_proj)                                              # pipe:676-683
+                             st["num_frames"], cfg_shared=CFG_SHARED and st["copies"] == 2, temb_proj=temb_proj,
+                             forward_upsample_size=any(s % (2 ** unet.num_upsamplers) for s in st["latents"].shape[-2:]))   # pipe:676-683, unet:1304-1311
         K.ddim_cfg_step(st["latents"], y, st["coef"], st["step_idx"], st["guidance"], st["copies"])  # pipe:686-691
 
     def _graph_key(self, st):
@@ -282,10 +282,7 @@ class I2VAdapterPipeline:
         width = width or w_lat * self.vae_scale_factor
         if height % 8 != 0 or width % 8 != 0:                                                   # pipe:213-214
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
-        up = 2 ** self.unet.num_upsamplers
-        if h_lat % up != 0 or w_lat % up != 0:
-            raise ValueError(f"latent height / width ({h_lat} x {w_lat}) must be multiples of {up}: the reference's "
-                             "forward_upsample_size branch (unet:1304-1311) is not implemented")
+        # (latent sizes that are not multiples of 8 take the UNet's forward_upsample_size path, unet:1304-1311)
         assert 0 < frame_similarity_sample_ratio <= 1, (
             f'"frame_similarity_sample_ratio" for img2vid must in (0, 1]. But receive {frame_similarity_sample_ratio}.')
         batch_size = prompt_embeds.shape[0]
@@ -339,6 +336,10 @@ class I2VAdapterPipeline:
             # eager steps: a per-step host hook (pipe:693-697), and / or the stochastic DDIM update (eta > 0, pipe:550, 659-660:
             # sigma_t is out of the direction coefficient -- `step_coefficients(timesteps, eta)` -- and comes back as fresh noise,
             # one draw of the latents' shape per step from `generator` as diffusers' scheduler draws it)
+            if eta != 0.0 and use_graph:
+                import warnings
+                warnings.warn("eta > 0: the stochastic DDIM update draws fresh noise on the host every step, so the steps run as "
+                              "eager launches instead of the captured hipGraph (about 2x the step time)", RuntimeWarning, stacklevel=2)
             sigmas = self.scheduler.step_sigmas(timesteps, eta)
             st["ctx_proj"] = self.unet.project_context(st["ctx_text"], st["ctx_ip"])
             st["temb_table"] = self.unet.project_time_table(st["t_table"])

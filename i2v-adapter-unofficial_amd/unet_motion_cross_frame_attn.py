@@ -649,7 +649,8 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
         temb = self._embed_time(timesteps_f32.to(torch.float32).contiguous())
         return K.gemm(K.silu(temb), wt, bt, out=out)
 
-    def _fwd_tokens(self, x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=False, temb_proj=None):
+    def _fwd_tokens(self, x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=False, temb_proj=None,
+                    forward_upsample_size=False):
         """x: model-input tokens [B*F, H, W, cin_pad] fp16; temb [B, 4*C0] fp16 (pre-SiLU) -- or temb_proj [B or 1, sum Cout]:
         the resnets' time-embedding projections already computed (project_time_table); ctx_text [B, Lt, D]
         (+ ctx_ip [B, 4, D]) or a ProjectedContext; returns noise-prediction tokens [B*F, H, W, out_channels]."""
@@ -679,13 +680,16 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
                 x, r = blk._fwd(x, temb_act, num_frames)
             res += r
         x = self.mid_block._fwd(x, temb_act, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames)
-        for blk in self.up_blocks:                                                      # unet:1406-1436
+        upsample_size = None
+        for bi, blk in enumerate(self.up_blocks):                                       # unet:1406-1436
             r = res[-len(blk.resnets):]
             res = res[: -len(blk.resnets)]
+            if bi + 1 < len(self.up_blocks) and forward_upsample_size:                  # unet:1414-1415
+                upsample_size = tuple(res[-1].shape[1:3])
             if getattr(blk, "has_cross_attention", False):
-                x = blk._fwd(x, r, temb_act, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames)
+                x = blk._fwd(x, r, temb_act, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, upsample_size)
             else:
-                x = blk._fwd(x, r, temb_act, num_frames)
+                x = blk._fwd(x, r, temb_act, num_frames, upsample_size)
         x = K.groupnorm(x, p["g_out"], p["be_out"], self.config.norm_num_groups, self.config.norm_eps, silu=True)
         # the 4-channel noise prediction stays fp32: the CFG combine (pipe:686-688) would amplify an fp16 rounding here
         # by up to 2 * guidance - 1, and the reference returns `sample`'s dtype (fp32 latents in its driver)
@@ -724,10 +728,8 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
         if sample.dim() != 5:
             raise ValueError(f"sample must be (batch, frames, channels, height, width), got {tuple(sample.shape)}")
         b, num_frames, c, hh, ww = sample.shape
-        up = 2 ** self.num_upsamplers
-        if hh % up != 0 or ww % up != 0:
-            raise NotImplementedError(f"latent height / width must be multiples of {up} "
-                                      "(the reference's forward_upsample_size branch is not implemented)")
+        # unet:1304-1311: sizes that do not halve exactly at every level forward the skip tensors' sizes to the up-samplers
+        forward_upsample_size = any(s % (2 ** self.num_upsamplers) != 0 for s in (hh, ww))
         timesteps = timestep                                                              # unet:1319-1334
         if not torch.is_tensor(timesteps):
             timesteps = torch.tensor([timesteps], dtype=torch.float32, device=sample.device)
@@ -745,7 +747,8 @@ class UNetMotionCrossFrameAttnModel(PretrainedMixin, HipModule):
         p = self.packed()
         x = K.nchw_to_tokens(sample.reshape(b * num_frames, c, hh, ww), p["cin_pad"])     # unet:1358
         cfg_shared = bool(cross_attention_kwargs and cross_attention_kwargs.get("cfg_shared_prefix", False))
-        y = self._fwd_tokens(x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=cfg_shared)
+        y = self._fwd_tokens(x, temb, enable_cross_frame_attn, ctx_text, ctx_ip, num_frames, cfg_shared=cfg_shared,
+                             forward_upsample_size=forward_upsample_size)
         out_dt = sample.dtype if sample.dtype in (torch.float32, f16) else f16
         out = K.tokens_to_nchw(y, dtype=out_dt).reshape(b, num_frames, -1, hh, ww)        # unet:1446
         if not return_dict:

@@ -697,9 +697,9 @@ int i2v_unet_set_weight(i2v_unet* h, const char* key, const void* ptr, int32_t d
 /* the registered buffer of a key (0 and *ptr = NULL when absent); shape may be NULL */
 int i2v_unet_get_weight(const i2v_unet* h, const char* key, const void** ptr, int32_t* dtype, int32_t* ndim, int64_t* shape);
 int64_t i2v_unet_num_weights(const i2v_unet* h);
-/* validates and records the step's problem: frames <= motion_max_seq_length (unet:725), even latent sizes at every level
- * (height, width multiples of 8: pipe:213-214 in latent units), ctx_len >= 1; a new problem drops the launch plan and the
- * captured step */
+/* validates and records the step's problem: frames <= motion_max_seq_length (unet:725), positive sizes (latent sizes that are
+ * not multiples of 8 take the forward_upsample_size path, unet:1304-1311: a matter of the recorded plan), ctx_len >= 1; a new
+ * problem drops the launch plan and the captured step */
 int i2v_unet_plan(i2v_unet* h, const i2v_unet_plan_t* plan);
 /* (ABI 9) installs a launch plan (the blob handle.py `record_forward_plan` writes; copied).  Checked: magic / version, the ABI
  * version it was recorded against, sizeof of every parameter struct it carries, entry-point ids, relocation targets inside their

@@ -140,7 +140,8 @@ def test_model_handle_registry_and_plan_without_a_gpu(lib):
     assert h.i2v_unet_activation_bytes(hd) == 0                    # ... is the installed launch plan's arena: none yet
     assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"no launch plan" in h.i2v_last_error()
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 33, 64, 64, 77, 0))) == -1 and b"positional table" in h.i2v_last_error()
-    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 60, 64, 77, 0))) == -1 and b"multiples of 8" in h.i2v_last_error()
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 60, 63, 77, 0))) == 0      # forward_upsample_size sizes are the plan's business
+    assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 0, 64, 77, 0))) == -1 and b"non-positive" in h.i2v_last_error()
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 81, 1))) == -1 and b"image tokens" in h.i2v_last_error()
     assert h.i2v_unet_replay_step(hd, None) == -1 and b"no captured step" in h.i2v_last_error()
     assert h.i2v_unet_end_capture(hd) == -1 and h.i2v_unet_capture_step(hd, None) == -1

@@ -592,3 +592,131 @@ print("RCCL_OK", nbytes)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ------------------------------------------------------------------------------------------------ full-size oracle FIXTURES (r6)
+# tests/golden/oracle_full_*.safetensors (oracle/make_full_fixtures.py, made in the build container): the fp32 CPU oracle's outputs
+# at BASELINE's full sizes on weights re-created from a seed by the CPU generator, so that every configuration is compared with the
+# oracle here in seconds (config 5's oracle forward alone is 15 minutes of 8 cores) -- VERDICT r5 items 2 / weak #3.
+# Tolerances (measured r6, both residual-stream modes, profiles/r6_parity_fixtures.jsonl): forward max-abs <= 4e-3 (the bench gate)
+# and rms error <= 1.2e-3 of the output's rms (measured 8.6 - 9.2e-4 default, 7.4 - 7.9e-4 precise); latents <= 3.3e-3 of max|latent|
+# at every stored step (REL_TOL_TRAJECTORY).
+FWD_RMS_REL_TOL = 1.2e-3
+
+
+def _golden(name):
+    import os
+    from safetensors.torch import load_file
+    from tests.parity import GOLDEN_DIR
+    path = os.path.join(GOLDEN_DIR, name)
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: python -m oracle.make_full_fixtures (build container)")
+    return load_file(path)
+
+
+def _seeded_hip_model(dev, ip):
+    """the HIP model on the fixture's weights (re-created on the CPU from the seed, pinned by the fixture's checksum)"""
+    from tests.parity import (FULL_SEED, FULL_SEED_IP, hip_unet_from_oracle, oracle_full_width_cpu_seeded, sd15_ip_state_dict,
+                              weights_checksum)
+    host_threads()
+    ou = oracle_full_width_cpu_seeded(FULL_SEED_IP if ip else FULL_SEED, ip=ip)
+    chk = weights_checksum(ou)
+    hu = hip_unet_from_oracle(ou, dev, ip_state_dict=sd15_ip_state_dict(ou) if ip else None)
+    del ou
+    return hu, chk
+
+
+@pytest.fixture(scope="module")
+def seeded(dev):
+    return _seeded_hip_model(dev, ip=False)
+
+
+@pytest.fixture(scope="module")
+def seeded_ip(dev):
+    return _seeded_hip_model(dev, ip=True)
+
+
+def _both_modes(fn):
+    """fn() under the default and under the precise residual stream (blocks.set_precise_stream): {'default': ..., 'precise': ...}"""
+    from i2v_adapter_unofficial_amd import blocks
+    out = {}
+    for mode in (False, True):
+        prev = blocks.set_precise_stream(mode)
+        try:
+            out["precise" if mode else "default"] = fn()
+        finally:
+            blocks.set_precise_stream(prev)
+    return out
+
+
+@pytest.mark.parametrize("name,frames,h_lat,ip", [("config2", 16, 64, False), ("config3", 16, 64, True), ("config5", 32, 96, False)])
+def test_full_size_forward_vs_oracle_fixture(dev, request, name, frames, h_lat, ip):
+    """BASELINE configs[1] / [2] / [4] at FULL size: the CFG forward (unet:1289-1451; IP-Adapter unet:1230-1287, 1346-1355; 32 frames =
+    the positional table's limit, unet:725) against the committed fp32 oracle output, in both residual-stream modes."""
+    from tests.parity import full_forward_inputs
+    hu, chk = request.getfixturevalue("seeded_ip" if ip else "seeded")
+    fx = _golden(f"oracle_full_{name}.safetensors")
+    assert torch.allclose(fx["weights_checksum"], chk, rtol=1e-12, atol=0), \
+        "the weights re-created from the seed differ from the ones the fixture was made with (another torch build?)"
+    ref = fx["noise_pred"]
+    inp = full_forward_inputs(frames, h_lat, ip)
+    added = {"image_embeds": inp["image_embeds"].to(dev)} if ip else None
+    assert ref.shape == (2, frames, 4, h_lat, h_lat)
+
+    def fwd():
+        with torch.no_grad():
+            return hu(inp["sample"].to(dev), inp["t"].to(dev), True, inp["ctx"].to(dev), added_cond_kwargs=added).sample.float().cpu()
+    got = _both_modes(fwd)
+    rms_ref = ref.pow(2).mean().sqrt().item()
+    res = {}
+    for mode, y in got.items():
+        err, scale = compare(y, ref, abs_tol=4.0e-3, name=f"{name} full-size forward vs oracle fixture ({mode} stream)")
+        rms = (y - ref).pow(2).mean().sqrt().item()
+        log_error(f"{name} full-size forward vs oracle fixture ({mode} stream), rms", rms, rms_ref, FWD_RMS_REL_TOL * rms_ref)
+        res[mode] = (err, rms)
+        assert rms <= FWD_RMS_REL_TOL * rms_ref, f"{name} ({mode}): rms error {rms:.3e} at rms {rms_ref:.3e}"
+    print(f"{name} full size vs oracle fixture (max|ref| {ref.abs().max().item():.3f}, rms {rms_ref:.3f}): "
+          + "; ".join(f"{m} max {e:.3e} rms {r:.3e}" for m, (e, r) in res.items()))
+    assert res["precise"][1] < res["default"][1]
+
+
+def test_config2_latent_trajectory_vs_oracle_fixture(dev, seeded):
+    """north_star words its tolerance on LATENTS: the 25-step CFG DDIM trajectory of config 2 (pipe:629-700; hipGraph-captured step)
+    against the fp32 oracle pipeline's latents after steps 1, 2, 3, 5, 10, 15, 20, 25 -- the error's growth along the trajectory,
+    printed and bounded per step, in both residual-stream modes.  (With random-init weights the CFG-amplified latents grow along the
+    trajectory -- max|latent| is printed -- so the bound is relative to max|latent| of the step.)"""
+    from tests.parity import REL_TOL_TRAJECTORY, trajectory_inputs
+    hu, chk = seeded
+    fx = _golden("oracle_latents_config2_25steps.safetensors")
+    assert torch.allclose(fx["weights_checksum"], chk, rtol=1e-12, atol=0)
+    steps = sorted(int(k[len("latents_step"):]) for k in fx if k.startswith("latents_step"))
+    kw, gens = trajectory_inputs(16, 64)
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+
+    def run():
+        snaps = {}
+
+        def cb(i, t, latents):
+            if i + 1 in steps:
+                snaps[i + 1] = latents.detach().float().cpu().clone()
+        final = pipe(**kw, **gens(), callback=cb).frames.float().cpu()
+        return snaps, final
+    got = _both_modes(run)
+    worst = {}
+    for mode, (snaps, final) in got.items():
+        line = []
+        for s in steps:
+            ref = fx[f"latents_step{s:02d}"]
+            d = (snaps[s] - ref)
+            rel = d.abs().max().item() / ref.abs().max().item()
+            line.append(f"{s}: {d.abs().max().item():.2e}/{ref.abs().max().item():.1f}={rel:.2e}")
+            log_error(f"config 2 latents after step {s} vs oracle fixture ({mode} stream)", d.abs().max().item(), ref.abs().max().item(),
+                      REL_TOL_TRAJECTORY * ref.abs().max().item(), rms_err=d.pow(2).mean().sqrt().item(), rms_ref=ref.pow(2).mean().sqrt().item())
+            worst[mode] = max(worst.get(mode, 0.0), rel)
+            assert rel <= REL_TOL_TRAJECTORY, f"latents after step {s} ({mode}): {rel:.3e} of max|latent|"
+        print(f"config 2 latent trajectory vs oracle ({mode} stream), max-abs err / max|latent| per step: " + "  ".join(line))
+        assert torch.equal(final[:, 0], kw["condition_image_latents"]), "frame 0 must equal the condition latents (pipe:699-700)"
+        compare(final, fx["final"], rel=REL_TOL_TRAJECTORY, name=f"config 2 final latents vs oracle fixture ({mode} stream)")
+    # the hipGraph route (no callback) reproduces the callback route's final latents bit for bit
+    graph_final = pipe(**kw, **gens()).frames.float().cpu()
+    assert torch.equal(graph_final, got["default"][1])

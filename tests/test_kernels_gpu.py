@@ -179,6 +179,25 @@ def test_conv3x3_big_tiles(dev, n, hh, ww, cin, cout, stride, up):
     close(out.permute(0, 3, 1, 2), ref, name="big conv3x3")
 
 
+@pytest.mark.parametrize("n,hh,ww,cin,cout,size", [(8, 32, 32, 64, 320, (63, 64)), (8, 32, 32, 64, 320, (64, 63)), (4, 16, 16, 640, 640, (31, 31)),
+                                                   (3, 7, 5, 16, 40, (13, 10)), (2, 1, 1, 32, 64, (1, 1))])
+def test_conv3x3_upsample_to_output_size(dev, n, hh, ww, cin, cout, size):
+    """Upsample2D with `output_size` (unet:1414-1415 forward_upsample_size; diffusers Upsample2D: F.interpolate(size=..., mode="nearest")
+    then the conv): sizes 2x and 2x - 1, through the 8-wave and the generic kernels."""
+    k = K()
+    g = torch.Generator().manual_seed(cin + cout + size[0])
+    x = h(torch.randn(n, cin, hh, ww, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = h(torch.randn(cout, generator=g))
+    ref = F.conv2d(F.interpolate(x, size=size, mode="nearest"), w, b, padding=1)
+    xt = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    out = k.conv3x3(xt, _pack_conv(w).to(dev), b.half().to(dev), upsample=True, output_size=size)
+    assert tuple(out.shape) == (n, size[0], size[1], cout)
+    close(out.permute(0, 3, 1, 2), ref, name=f"conv3x3 after nearest upsampling to {size}")
+    with pytest.raises(NotImplementedError, match="2x"):
+        k.conv3x3(xt, _pack_conv(w).to(dev), b.half().to(dev), upsample=True, output_size=(2 * hh + 1, 2 * ww))
+
+
 def test_gemm_rowvec_gelu(dev):
     k = K()
     g = torch.Generator().manual_seed(3)
@@ -920,6 +939,9 @@ def test_groupnorm_statistics_from_the_conv_epilogue(dev, n, hh, cin, cout, mean
     # where the form does not exist (a convolution that splits K, a residual epilogue) the caller is told so
     small = k.conv3x3(xt[:1, :8, :8].contiguous(), wp, D(b), gn_stats_groups=32)
     assert small[1] is None and tuple(small[0].shape) == (1, 8, 8, cout)
+    # ... and with an output scale: the partials would describe acc + bias, not the tensor that is stored
+    scaled = k.conv3x3(xt, wp, D(b), rowvec=D(tv), rows_per_vec=rpv, gn_stats_groups=32, out_scale=0.5)
+    assert scaled[1] is None and tuple(scaled[0].shape) == tuple(out.shape)
     with pytest.raises(ValueError, match="stats"):
         k.groupnorm(out, D(ga), D(be), 32, 1e-6, silu=True, stats=(part[:, :1].contiguous(), rows))
 

@@ -148,6 +148,26 @@ def test_small_unet_forward(dev, cross_frame, ip):
             hu(inp["sample"].to(dev), inp["timestep"].to(dev), cross_frame, inp["ctx"].to(dev))
 
 
+@pytest.mark.parametrize("hh,ww", [(12, 20), (15, 10), (9, 13), (4, 4)])
+def test_small_unet_forward_upsample_size(dev, hh, ww):
+    """latent sizes that are not multiples of 8 (unet:1304-1311, 1414-1415 `forward_upsample_size`): the stride-2 down-samplers
+    round up (12 -> 6 -> 3 -> 2), and every up-sampler but the last block's interpolates to the size of the skip tensor it meets --
+    2x or 2x - 1 -- before its convolution (diffusers Upsample2D `F.interpolate(size=output_size, mode="nearest")`).  The oracle
+    takes the same branch; ragged token counts (225 pixels per image) go through the generic kernel forms."""
+    ou = oracle_small_unet()
+    hu = hip_unet_from_oracle(ou, dev)
+    g = torch.Generator().manual_seed(hh * 31 + ww)
+    hlf = lambda t: t.half().float()
+    sample, ctx = hlf(torch.randn(2, 4, 4, hh, ww, generator=g)), hlf(torch.randn(2, 7, 64, generator=g))
+    t = torch.tensor([10, 500])
+    with torch.no_grad():
+        ref = ou(sample, t, True, ctx).sample
+        got = hu(sample.to(dev), t.to(dev), True, ctx.to(dev)).sample
+    assert got.shape == ref.shape == (2, 4, 4, hh, ww)
+    err, scale = compare(got, ref, rel=REL_TOL_UNET, name=f"UNet forward at {hh} x {ww} latents (forward_upsample_size)")
+    print(f"small UNet at {hh} x {ww}: max abs err {err:.3e} (max|ref| {scale:.3e})")
+
+
 @pytest.mark.parametrize("gain", [2.0, 3.0, 4.0])
 def test_small_unet_forward_sharp_attention(dev, gain):
     """the whole UNet with every attention layer's to_q / to_k (spatial, cross-frame adapter, text, IP, temporal) multiplied by

@@ -146,8 +146,9 @@ def test_pipeline_with_vae_end_to_end(dev, tmp_path):
     arr = pipe(output_type="np", **kw, **gens()).frames[0]
     assert arr.shape == (4, 64, 64, 3) and 0.0 <= arr.min() and arr.max() <= 1.0
     assert np.abs(arr - p.VaeImageProcessor.denormalize(vid[0].cpu()).permute(0, 2, 3, 1).numpy()).max() == 0
-    with pytest.raises(ValueError, match="multiples of 8"):     # latents 4 x 4 cannot go through three down / up samplings
-        pipe(output_type="latent", **{**kw, "height": 32, "width": 32}, **gens())
+    # latents 4 x 4 (not a multiple of 8): three down-samplings 4 -> 2 -> 1 -> 1, the up path through forward_upsample_size (unet:1304-1311)
+    small = pipe(output_type="latent", **{**kw, "height": 32, "width": 32}, **gens()).frames
+    assert tuple(small.shape[-2:]) == (4, 4) and torch.isfinite(small).all()
     with pytest.raises(ValueError, match="vae"):
         p.I2VAdapterPipeline(unet=hu)(output_type="pt", **{k: v for k, v in kw.items() if k != "condition_image"},
                                       condition_image_latents=lat[:, 0], **gens())
