@@ -117,10 +117,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
         const float mean_c = kshift[e] + s[e] * inv_n, m2_c = fmaxf(q[e] - s[e] * s[e] * inv_n, 0.f);
         dst[2 * e] = mean_c;                  // mean of this (chunk, channel)
         dst[2 * e + 1] = m2_c;                // M2
-        if (gpartial != nullptr) {
-          chan[2 * (col * 8 + e)] = mean_c;
-          chan[2 * (col * 8 + e) + 1] = m2_c;
-        }
+        // [value e][column]: consecutive lanes write consecutive 8-byte slots.  (r6, VERDICT r5 7a: as chan[2 (8 col + e)] a wave's
+        // stores were 16 floats apart -- every fourth lane on the same bank, 16 deep -- which is what the 0.716 SQ_LDS_BANK_CONFLICT of
+        // the round-5 collection was made of after `red` had been transposed: few LDS cycles, nearly all of them conflicts.  The
+        // kernel's time is its global loads -- 71 % wait -- so the step does not move.)
+        if (gpartial != nullptr) *reinterpret_cast<float2*>(chan + 2 * (e * nvec + col)) = float2{mean_c, m2_c};
       }
     }
     __syncthreads();
@@ -128,13 +129,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
   if (gpartial != nullptr && tid < groups) {
     const int cpg = C / groups;
     const float n = (float)(row_end - row_begin);
+    auto slot = [&](int ch) { return 2 * ((ch & 7) * nvec + (ch >> 3)); };      // channel ch = 8 col + e sits at [e][col]
     float mg = 0.f;
-    for (int c = 0; c < cpg; ++c) mg += chan[2 * (tid * cpg + c)];
+    for (int c = 0; c < cpg; ++c) mg += chan[slot(tid * cpg + c)];
     mg /= (float)cpg;
     float m2 = 0.f;
     for (int c = 0; c < cpg; ++c) {
-      const float dm = chan[2 * (tid * cpg + c)] - mg;
-      m2 += chan[2 * (tid * cpg + c) + 1] + n * dm * dm;
+      const float dm = chan[slot(tid * cpg + c)] - mg;
+      m2 += chan[slot(tid * cpg + c) + 1] + n * dm * dm;
     }
     float* dst = gpartial + (((int64_t)img * nchunk + chunk) * groups + tid) * 2;
     dst[0] = mg;

@@ -32,6 +32,7 @@ cp gpurun_out/traffic.json gpurun_out/${tag}_traffic.json
 # the headline line LAST, with this box's traffic and ceilings where bench.py looks for them (the copies under profiles/ on
 # the box are scratch; the ones to commit are the gpurun_out/ files)
 cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json
+cp gpurun_out/${tag}_kernel_stats.txt profiles/${tag}_kernel_stats.txt      # bench.py's roofline.dominant_kernel reads it (same source stamp)
 if [ -s gpurun_out/${tag}_ceilings.json ]; then cp gpurun_out/${tag}_ceilings.json profiles/${tag}_ceilings.json; fi
 python bench.py --shapes gpurun_out/${tag}_step_shapes.txt > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 python -c "
