@@ -64,9 +64,14 @@ __device__ __forceinline__ uint32_t pack_rn(float a, float b) {
 // (descriptors, staging offsets, the tail mask, 64-bit addresses: 19.6 VALU per MFMA, a VALU-bound kernel,
 // profiles/r4_pmc_summary.txt); the set-up is now paid once per qbw blocks.  A template parameter: the long-sequence kernels
 // keep their single trip (and their register allocation).
+// (r6 A/B, profiles/r6_attn_d80_occupancy.txt: waves per SIMD requested for the head_dim-80 kernel -- 1 lets the compiler keep its 244
+//  registers = 2 waves; 3 caps it at 168)
+#ifndef I2V_ATTN_OCC_D80
+#define I2V_ATTN_OCC_D80 1
+#endif
 template <int DQK, int DPV, int QT, int KVT, bool SPARE, bool WALK = false>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(DQK == 64 && DPV == 48 && QT == 2 && KVT == 64 && !WALK ? 4 : 1)))
+__attribute__((amdgpu_waves_per_eu(DQK == 64 && DPV == 48 && QT == 2 && KVT == 64 && !WALK ? 4 : (DQK == 96 && DPV == 80 && !WALK ? I2V_ATTN_OCC_D80 : 1))))
 void attn_kernel(const i2v_attn_params p, const float scale_log2, const int qbw_arg) {
   const int qbw = WALK ? qbw_arg : 1;
   constexpr int KS = DQK + 8;          // K LDS row stride (halfs)
