@@ -193,15 +193,17 @@ def test_small_unet_precise_mode(dev, small_pair):
     from tests.parity import REL_TOL_UNET, compare, small_unet_inputs
     ou, hu = small_pair
     inp = small_unet_inputs()
-    with torch.no_grad():
-        ref = ou(inp["sample"], inp["timestep"], True, inp["ctx"]).sample
-        base = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
-        prev = blocks.set_precise_stream(True)
-        try:
+    entry = blocks.set_precise_stream(False)          # (whatever I2V_STREAM_PRECISE set for the process: this test switches itself)
+    try:
+        with torch.no_grad():
+            ref = ou(inp["sample"], inp["timestep"], True, inp["ctx"]).sample
+            base = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
+            blocks.set_precise_stream(True)
             got = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
-        finally:
-            blocks.set_precise_stream(prev)
-        again = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
+            blocks.set_precise_stream(False)
+            again = hu(inp["sample"].to(dev), inp["timestep"].to(dev), True, inp["ctx"].to(dev)).sample
+    finally:
+        blocks.set_precise_stream(entry)
     assert torch.equal(again, base), "switching the precise stream off must restore the default path bit for bit"
     e1, scale = compare(got, ref, rel=REL_TOL_UNET, name="small UNet, precise stream")
     e0, _ = compare(base, ref, rel=REL_TOL_UNET, name="small UNet, default stream")
@@ -220,14 +222,15 @@ def test_full_width_unet_precise_mode(dev):
     g = torch.Generator().manual_seed(3)
     sample, ctx = h(torch.randn(2, 8, 4, 32, 32, generator=g)), h(torch.randn(2, 77, 768, generator=g))
     t = torch.tensor([481, 481])
-    with torch.no_grad():
-        ref = ou(sample, t, True, ctx).sample
-        base = hu(sample.to(dev), t.to(dev), True, ctx.to(dev)).sample
-        prev = blocks.set_precise_stream(True)
-        try:
+    entry = blocks.set_precise_stream(False)
+    try:
+        with torch.no_grad():
+            ref = ou(sample, t, True, ctx).sample
+            base = hu(sample.to(dev), t.to(dev), True, ctx.to(dev)).sample
+            blocks.set_precise_stream(True)
             got = hu(sample.to(dev), t.to(dev), True, ctx.to(dev)).sample
-        finally:
-            blocks.set_precise_stream(prev)
+    finally:
+        blocks.set_precise_stream(entry)
     e1, scale = compare(got, ref, abs_tol=4.2e-3, name="full-width UNet forward, precise stream")
     e0, _ = compare(base, ref, abs_tol=4.2e-3, name="full-width UNet forward, default stream (same weights)")
     rms = lambda t_: (t_.float().cpu() - ref).pow(2).mean().sqrt().item()
