@@ -184,8 +184,9 @@ class I2VAdapterPipeline:
         wsig = hash(tuple((p.data_ptr(), p._version) for p in unet.parameters()))
         ips = tuple((a.ip_num_tokens, float(a.ip_scale)) for a in unet._cross_attention_layers())
         shp = lambda t: None if t is None else (tuple(t.shape), t.dtype)
+        from .blocks import precise_stream      # (a captured step keeps the residual-stream mode it was captured in)
         return (tuple(st["latents"].shape), st["copies"], st["num_frames"], st["guidance"], shp(st["t_table"]),
-                shp(st["ctx_text"]), shp(st["ctx_ip"]), str(st["latents"].device), wsig, ips)
+                shp(st["ctx_text"]), shp(st["ctx_ip"]), str(st["latents"].device), wsig, ips, precise_stream())
 
     def _run_steps(self, st, n_steps, use_graph):
         if not use_graph:

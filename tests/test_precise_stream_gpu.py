@@ -237,3 +237,31 @@ def test_full_width_unet_precise_mode(dev):
     print(f"full-width UNet vs oracle: default max {e0:.3e} rms {rms(base):.3e}; precise max {e1:.3e} rms {rms(got):.3e} "
           f"(max|ref| {scale:.3e})")
     assert rms(got) < 0.95 * rms(base)
+
+
+def test_pipeline_graph_is_recaptured_when_the_mode_changes(dev, small_pair):
+    """the pipeline keeps its captured step across calls (pipe:666-697 as one hipGraph): the residual-stream mode is part of what a
+    captured step has baked in, so switching it must re-capture -- the same pipeline object gives the other mode's latents, equal to
+    what a fresh pipeline in that mode computes, and switching back reproduces the first result bit for bit."""
+    import i2v_adapter_unofficial_amd as pkg
+    from i2v_adapter_unofficial_amd import blocks
+    _, hu = small_pair
+    g = torch.Generator().manual_seed(4)
+    kw = dict(prompt_embeds=h(torch.randn(1, 7, 64, generator=g)), negative_prompt_embeds=h(torch.randn(1, 7, 64, generator=g)),
+              condition_image_latents=torch.randn(1, 4, 16, 16, generator=g), num_frames=4, num_inference_steps=4, guidance_scale=7.5,
+              blur_sigma=1.0)
+    gens = lambda: dict(generator=torch.Generator().manual_seed(5), prior_mask_generator=torch.Generator().manual_seed(6),
+                        prior_noise_generator=torch.Generator().manual_seed(7))
+    pipe = pkg.I2VAdapterPipeline(unet=hu)
+    entry = blocks.set_precise_stream(False)
+    try:
+        a = pipe(**kw, **gens()).frames.clone()
+        blocks.set_precise_stream(True)
+        b = pipe(**kw, **gens()).frames.clone()
+        fresh = pkg.I2VAdapterPipeline(unet=hu)(**kw, **gens()).frames
+        blocks.set_precise_stream(False)
+        c = pipe(**kw, **gens()).frames
+    finally:
+        blocks.set_precise_stream(entry)
+    assert not torch.equal(a, b) and torch.equal(b, fresh) and torch.equal(a, c)
+    assert (a - b).abs().max().item() < 2e-2 * a.abs().max().item()
