@@ -283,6 +283,7 @@ SIGNATURES = {
     "i2v_unet_set_workspace": (C.c_int, [_P, _P, C.c_int64]),
     "i2v_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "i2v_unet_abort_capture": (C.c_int, [_P]),
+    "i2v_unet_run": (C.c_int, [_P, C.POINTER(_P), C.c_int32, _P]),
     "i2v_unet_capture_step": (C.c_int, [_P, _P]),
     "i2v_unet_end_capture": (C.c_int, [_P]),
     "i2v_unet_replay_step": (C.c_int, [_P, _P]),

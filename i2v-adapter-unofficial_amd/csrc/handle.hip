@@ -36,12 +36,12 @@ enum { RELOC_ARENA = 0, RELOC_WEIGHT = 1, RELOC_IO = 2 };
 enum Entry {
   E_GEMM = 0, E_ATTN, E_TATTN, E_MOTION_ATTN, E_CROSS_ATTN_FUSED, E_LN_QKV, E_FF_FUSED, E_GROUPNORM, E_LAYERNORM,      // struct + stream
   E_GROUPNORM_FOLD, E_NCHW_TO_TOKENS, E_TOKENS_TO_NCHW, E_TIMESTEP_EMBEDDING, E_SILU, E_REPEAT_ROWS, E_COPY3D, E_SELECT_ROW,
-  E_PACK_CTX_FRAGMENTS, E_COUNT
+  E_PACK_CTX_FRAGMENTS, E_DDIM_PREP, E_DDIM_CFG_STEP, E_COUNT
 };
 struct EntryInfo {
   const char* name;
   uint32_t struct_bytes;      // sizeof of the parameter struct the payload starts with (0: none)
-  uint32_t slots;             // 8-byte argument slots behind it (integers as int64, floats as double, pointers)
+  uint32_t slots;             // 8-byte argument slots behind it (integers as int64, a float as a double, pointers)
 };
 const EntryInfo ENTRIES[E_COUNT] = {
     {"i2v_gemm_f16", sizeof(i2v_gemm_params), 0},
@@ -62,6 +62,8 @@ const EntryInfo ENTRIES[E_COUNT] = {
     {"i2v_copy3d_f16", 0, 9},
     {"i2v_select_row_f16", 0, 6},
     {"i2v_pack_ctx_fragments_f16", 0, 10},
+    {"i2v_ddim_prep", 0, 9},
+    {"i2v_ddim_cfg_step", 0, 13},
 };
 inline uint32_t pad8(uint32_t n) { return (n + 7u) & ~7u; }
 
@@ -296,18 +298,28 @@ extern "C" int i2v_unet_set_workspace(i2v_unet* h, void* arena, int64_t bytes) {
   return I2V_OK;
 }
 
+extern "C" int i2v_unet_run(i2v_unet* h, const void* const* io_args, int32_t n_io, i2v_stream_t stream);
+
 extern "C" int i2v_unet_forward(i2v_unet* h, const void* sample, const void* timesteps, const void* context, const void* image_embeds,
                                 void* out, i2v_stream_t stream) {
-  I2V_CHECK_ARG(h != nullptr, "i2v_unet_forward: null handle");
+  const void* io[I2V_IO_SLOTS] = {sample, timesteps, context, image_embeds, out};
+  return i2v_unet_run(h, io, I2V_IO_SLOTS, stream);
+}
+
+extern "C" int i2v_unet_run(i2v_unet* h, const void* const* io_args, int32_t n_io, i2v_stream_t stream) {
+  I2V_CHECK_ARG(h != nullptr && (n_io == 0 || io_args != nullptr) && n_io >= 0 && n_io <= I2V_IO_SLOTS, "i2v_unet_forward: null handle / argument array");
   const PlanHeader* hd = h->header();
   I2V_CHECK_ARG(hd != nullptr, "i2v_unet_forward: no launch plan (i2v_unet_set_plan)");
   I2V_CHECK_ARG(hd->arena_bytes == 0 || (h->arena != nullptr && (uint64_t)h->arena_bytes >= hd->arena_bytes),
                 "i2v_unet_forward: the arena holds %lld bytes, the plan needs %llu (i2v_unet_set_workspace)", (long long)h->arena_bytes,
                 (unsigned long long)hd->arena_bytes);
-  const void* io[I2V_IO_SLOTS] = {sample, timesteps, context, image_embeds, out};
+  const void* io[I2V_IO_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int s = 0; s < n_io; ++s) io[s] = io_args[s];
+  // (the names of the forward's arguments; a plan of another launch sequence -- handle.py record_plan -- gives the slots its own meaning)
   static const char* io_name[I2V_IO_SLOTS] = {"sample", "timesteps", "context", "image_embeds", "out"};
   for (int s = 0; s < I2V_IO_SLOTS; ++s)
-    I2V_CHECK_ARG(!((hd->io_read_mask >> s) & 1u) || io[s] != nullptr, "i2v_unet_forward: `%s` is NULL and the plan uses it", io_name[s]);
+    I2V_CHECK_ARG(!((hd->io_read_mask >> s) & 1u) || io[s] != nullptr, "i2v_unet_forward: `%s` (argument %d) is NULL and the plan uses it",
+                  io_name[s], s);
   // the plan's weight keys through the registry (again whenever a weight was registered since)
   if (h->bound_generation != h->weights_generation) {
     for (size_t i = 0; i < h->keys.size(); ++i) {
@@ -342,6 +354,7 @@ extern "C" int i2v_unet_forward(i2v_unet* h, const void* sample, const void* tim
     const unsigned char* sl = buf + pad8(op.struct_bytes);
     auto P = [&](int k) { void* v; memcpy(&v, sl + 8 * k, 8); return v; };
     auto I = [&](int k) { int64_t v; memcpy(&v, sl + 8 * k, 8); return v; };
+    auto F = [&](int k) { double v; memcpy(&v, sl + 8 * k, 8); return (float)v; };
     int rc = I2V_OK;
     switch (op.entry) {
       case E_GEMM: rc = i2v_gemm_f16(reinterpret_cast<const i2v_gemm_params*>(buf), stream); break;
@@ -374,6 +387,15 @@ extern "C" int i2v_unet_forward(i2v_unet* h, const void* sample, const void* tim
         break;
       case E_PACK_CTX_FRAGMENTS:
         rc = i2v_pack_ctx_fragments_f16(P(0), I(1), P(2), I(3), I(4), P(5), (int32_t)I(6), (int32_t)I(7), (int32_t)I(8), (int32_t)I(9), stream);
+        break;
+      case E_DDIM_PREP:
+        rc = i2v_ddim_prep(reinterpret_cast<float*>(P(0)), reinterpret_cast<const float*>(P(1)), P(2), (int32_t)I(3), (int32_t)I(4), (int32_t)I(5),
+                           (int32_t)I(6), (int32_t)I(7), (int32_t)I(8), stream);
+        break;
+      case E_DDIM_CFG_STEP:
+        rc = i2v_ddim_cfg_step(reinterpret_cast<float*>(P(0)), P(1), (int32_t)I(2), I(3), reinterpret_cast<const float*>(P(4)), (int32_t)I(5),
+                               reinterpret_cast<int32_t*>(P(6)), F(7), (int32_t)I(8), (int32_t)I(9), (int32_t)I(10), (int32_t)I(11), (int32_t)I(12),
+                               stream);
         break;
       default: I2V_FAIL(I2V_ERR_UNSUPPORTED, "i2v_unet_forward: launch %u names entry point %u", i, op.entry);
     }

@@ -30,7 +30,7 @@ ENTRY_IDS = {name: i for i, name in enumerate((
     "i2v_gemm_f16", "i2v_attention_f16", "i2v_temporal_attention_f16", "i2v_motion_attn_f16", "i2v_cross_attn_fused_f16", "i2v_ln_qkv_f16",
     "i2v_ff_fused_f16", "i2v_groupnorm_f16", "i2v_layernorm_f16", "i2v_groupnorm_fold_f16", "i2v_nchw_to_tokens", "i2v_tokens_to_nchw",
     "i2v_timestep_embedding", "i2v_silu_f16", "i2v_repeat_rows_f16", "i2v_copy3d_f16", "i2v_select_row_f16",
-    "i2v_pack_ctx_fragments_f16"))}
+    "i2v_pack_ctx_fragments_f16", "i2v_ddim_prep", "i2v_ddim_cfg_step"))}
 IO_SAMPLE, IO_TIMESTEPS, IO_CONTEXT, IO_IMAGE_EMBEDS, IO_OUT = range(5)
 RELOC_ARENA, RELOC_WEIGHT, RELOC_IO = range(3)
 _INT_TYPES = (C.c_int32, C.c_int64, C.c_int)
@@ -86,11 +86,13 @@ class _RecordingLib:
                 v = int(v) if v else 0
                 if v:
                     ptrs.append((_pad8(len(sbytes)) + 8 * len(slots), v, f"{name} argument {len(slots)}"))
-                slots.append(v)
+                slots.append(struct.pack("<Q", v))
             elif at in _INT_TYPES:
-                slots.append(int(arg))
+                slots.append(struct.pack("<q", int(arg)))
+            elif at is C.c_float:
+                slots.append(struct.pack("<d", float(arg)))          # (the C side reads a float slot as a double)
             else:
-                raise TypeError(f"{name}: a launch plan carries pointers and integers, not {at}")
+                raise TypeError(f"{name}: a launch plan carries pointers, integers and floats, not {at}")
         self.ops.append((ENTRY_IDS[name], sbytes, slots, ptrs))
 
 
@@ -128,29 +130,28 @@ def _storage_range(t):
     return st.data_ptr(), st.data_ptr() + st.nbytes()
 
 
-def record_forward_plan(unet, sample, timesteps, encoder_hidden_states, image_embeds=None, enable_cross_frame_attn=True,
-                        cfg_shared_prefix=False):
-    """One `unet.forward` (unet:1289-1451) as a launch plan.  Arguments as `i2v_unet_forward` takes them: sample fp16 / fp32
-    [B, F, C, H, W], timesteps fp32 [B], encoder_hidden_states fp16 [B, L, D], image_embeds fp16 [B, clip] or None -- all contiguous
-    on the model's device.  Returns (blob, weights): the plan and {key: tensor} of exactly the persistent tensors it names (register
-    each with `UNetHandle.set_weights`, or `save_weights` them for another host).  The plan holds for this problem size, these
-    switches (I2V_* environment, `blocks.set_precise_stream`) and this library build only."""
-    dev = sample.device
-    io = {IO_SAMPLE: sample, IO_TIMESTEPS: timesteps, IO_CONTEXT: encoder_hidden_states}
-    if image_embeds is not None:
-        io[IO_IMAGE_EMBEDS] = image_embeds
-    if sample.dim() != 5 or sample.dtype not in (torch.float16, torch.float32) or timesteps.dtype != torch.float32 or \
-            tuple(timesteps.shape) != (sample.shape[0],) or encoder_hidden_states.dtype != torch.float16 or \
-            (image_embeds is not None and image_embeds.dtype != torch.float16):
-        raise ValueError("record_forward_plan: sample [B, F, C, H, W] fp16 / fp32, timesteps fp32 [B], context / image_embeds fp16")
-    for s, t in io.items():
+def record_plan(run, *, unet, io, problem, late_io=None, extra_persistent=None, restore=None):
+    """The launches `run()` issues, as a launch plan for `i2v_unet_run` (`UNetHandle.run`).
+      io                {slot: tensor}: buffers that exist before the call -- the plan's arguments (read and / or written in place)
+      late_io           result -> {slot: tensor}: tensors `run()` allocates and returns that the caller wants as arguments (a forward's
+                        output): claimed in the LAST launch only (an earlier, freed activation may have had the address)
+      extra_persistent  {name: tensor}: more buffers that outlive the call and are registered by name like weights (per-sample
+                        buffers: `sample#...`)
+      restore           called before every invocation of `run()` (it is invoked twice: once to build every lazily packed operand,
+                        once recorded): puts in / out arguments back to their initial contents
+      problem           (batch, frames, height, width, ctx_len, has_ip) for the blob's header (`i2v_unet_plan` must match)
+    Returns (blob, weights) as `record_forward_plan`."""
+    dev = next(iter(io.values())).device
+    for t in io.values():
         if not t.is_cuda or not t.is_contiguous():
-            raise ValueError("record_forward_plan: the forward's arguments must be contiguous device tensors")
-    kw = dict(added_cond_kwargs={"image_embeds": image_embeds} if image_embeds is not None else None,
-              cross_attention_kwargs={"cfg_shared_prefix": True} if cfg_shared_prefix else None)
+            raise ValueError("record_plan: the arguments must be contiguous device tensors")
     with torch.no_grad():
-        unet(sample, timesteps, enable_cross_frame_attn, encoder_hidden_states, **kw)      # builds every lazily packed operand
+        if restore is not None:
+            restore()
+        run()                                                  # builds every lazily packed operand
         torch.cuda.synchronize(dev)
+        if restore is not None:
+            restore()
         real = _lib.load()
         rec = _RecordingLib(real)
         pool = torch.cuda.MemPool()
@@ -158,24 +159,30 @@ def record_forward_plan(unet, sample, timesteps, encoder_hidden_states, image_em
         _lib._lib = rec
         try:
             with torch.cuda.use_mem_pool(pool, device=dev):
-                out = unet(sample, timesteps, enable_cross_frame_attn, encoder_hidden_states, **kw).sample
+                result = run()
         finally:
             _lib._lib = saved
         torch.cuda.synchronize(dev)
-    if not out.is_contiguous() or out.dtype != sample.dtype:
-        raise RuntimeError("record_forward_plan: unexpected output layout")
-    io[IO_OUT] = out
+    late = dict(late_io(result)) if late_io is not None else {}
+    for t in late.values():
+        if not t.is_contiguous():
+            raise RuntimeError("record_plan: unexpected output layout")
     segments = sorted((s["address"], s["total_size"]) for s in pool.snapshot())
     seg_off, arena_bytes = {}, 0
     for addr, size in segments:
         seg_off[addr] = arena_bytes
         arena_bytes += (size + 255) & ~255
     seg_starts = [a for a, _ in segments]
-    # io ranges are the tensors themselves (the C caller passes the tensor's first byte); `out` lives in the pool and is claimed first
-    io_ranges = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), s) for s, t in io.items()]
+    # io ranges are the tensors themselves (the C caller passes the tensor's first byte)
+    io_ranges = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), s, False) for s, t in io.items()]
+    io_ranges += [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), s, True) for s, t in late.items()]
     pers = persistent_tensors(unet)
+    pers.update({k: v for k, v in (extra_persistent or {}).items() if v is not None and v.is_cuda and v.numel()})
     spans = {}
-    for name in sorted(pers):                                   # one name per storage: the first in sorted order
+    # one name per storage.  A tensor the kernels read exactly as the checkpoint holds it (fp16 biases, norm affines, Linear / 1x1
+    # weights: `w16` of an fp16 parameter is the parameter) goes by its STATE-DICT key -- a host can register the reference's
+    # checkpoint tensor for it directly -- and only the re-laid-out operands by `<module path>#<pack>`
+    for name in sorted(pers, key=lambda n: ("#" in n, n)):
         lo, hi = _storage_range(pers[name])
         spans.setdefault((lo, hi), name)
     span_list = sorted((lo, hi, name) for (lo, hi), name in spans.items())
@@ -186,13 +193,11 @@ def record_forward_plan(unet, sample, timesteps, encoder_hidden_states, image_em
     for op_i, (entry, sbytes, slots, ptrs) in enumerate(rec.ops):
         blockb = bytearray(sbytes) + bytearray(_pad8(len(sbytes)) - len(sbytes))
         for v in slots:
-            blockb += struct.pack("<q", v)
+            blockb += v
         begin = len(relocs)
         last = op_i == len(rec.ops) - 1
         for off, v, what in ptrs:
-            # (`out` was allocated from the pool at the end of the forward: an earlier, already freed activation may have had its
-            #  address, so only the LAST launch -- unet:1446, tokens -> NCHW -- can mean it)
-            hit = next(((RELOC_IO, s, v - lo) for lo, hi, s in io_ranges if lo <= v < hi and (s != IO_OUT or last)), None)
+            hit = next(((RELOC_IO, s, v - lo) for lo, hi, s, is_late in io_ranges if lo <= v < hi and (not is_late or last)), None)
             if hit is None:
                 i = bisect.bisect_right(span_starts, v) - 1
                 if i >= 0 and v < span_list[i][1]:
@@ -206,15 +211,17 @@ def record_forward_plan(unet, sample, timesteps, encoder_hidden_states, image_em
                 if i >= 0 and v < segments[i][0] + segments[i][1]:
                     hit = (RELOC_ARENA, 0, seg_off[segments[i][0]] + v - segments[i][0])
             if hit is None:
-                raise RuntimeError(f"record_forward_plan: {what} = {v:#x} is neither an argument, a persistent tensor of the model nor "
-                                   "memory the forward allocated -- a buffer the plan cannot name")
+                raise RuntimeError(f"record_plan: {what} = {v:#x} is neither an argument, a persistent tensor of the model nor "
+                                   "memory the call allocated -- a buffer the plan cannot name")
             if hit[0] == RELOC_IO:
                 io_mask |= 1 << hit[1]
             blockb[off: off + 8] = b"\0" * 8
             relocs.append(struct.pack("<IIIIQ", off, hit[0], hit[1], 0, hit[2]))
         ops_bin.append(struct.pack("<IIIIII", entry, len(payload), len(blockb), begin, len(relocs) - begin, len(sbytes)))
         payload += blockb
-    b, f, _c, hh, ww = sample.shape
+    for s_ in late:
+        if not (io_mask >> s_) & 1:
+            raise RuntimeError("record_plan: the last launch does not write the call's result")
     key_tab = bytearray()
     for k in keys:
         kb = k.encode()
@@ -227,14 +234,102 @@ def record_forward_plan(unet, sample, timesteps, encoder_hidden_states, image_em
     payload_off = relocs_off + 24 * len(relocs)
     total = payload_off + len(payload)
     hdr = struct.pack("<6I6iQ2I6Q", PLAN_MAGIC, PLAN_VERSION, _lib.ABI_VERSION, len(ops_bin), len(keys), len(relocs),
-                      b, f, hh, ww, encoder_hidden_states.shape[1], int(image_embeds is not None), arena_bytes, io_mask, 0,
+                      *[int(v) for v in problem], arena_bytes, io_mask, 0,
                       keys_off, ops_off, relocs_off, payload_off, len(payload), total)
-    if not (io_mask >> IO_OUT) & 1:
-        raise RuntimeError("record_forward_plan: the last launch does not write the forward's result")
     blob = bytes(hdr + key_tab + b"".join(ops_bin) + b"".join(relocs) + payload)
     assert len(blob) == total
-    weights = {k: pers[k] for k in keys}
+    return blob, {k: pers[k] for k in keys}
+
+
+def record_forward_plan(unet, sample, timesteps, encoder_hidden_states, image_embeds=None, enable_cross_frame_attn=True,
+                        cfg_shared_prefix=False):
+    """One `unet.forward` (unet:1289-1451) as a launch plan.  Arguments as `i2v_unet_forward` takes them: sample fp16 / fp32
+    [B, F, C, H, W], timesteps fp32 [B], encoder_hidden_states fp16 [B, L, D], image_embeds fp16 [B, clip] or None -- all contiguous
+    on the model's device.  Returns (blob, weights): the plan and {key: tensor} of exactly the persistent tensors it names (register
+    each with `UNetHandle.set_weights`, or `save_weights` them for another host).  The plan holds for this problem size, these
+    switches (I2V_* environment, `blocks.set_precise_stream`) and this library build only."""
+    io = {IO_SAMPLE: sample, IO_TIMESTEPS: timesteps, IO_CONTEXT: encoder_hidden_states}
+    if image_embeds is not None:
+        io[IO_IMAGE_EMBEDS] = image_embeds
+    if sample.dim() != 5 or sample.dtype not in (torch.float16, torch.float32) or timesteps.dtype != torch.float32 or \
+            tuple(timesteps.shape) != (sample.shape[0],) or encoder_hidden_states.dtype != torch.float16 or \
+            (image_embeds is not None and image_embeds.dtype != torch.float16):
+        raise ValueError("record_forward_plan: sample [B, F, C, H, W] fp16 / fp32, timesteps fp32 [B], context / image_embeds fp16")
+    kw = dict(added_cond_kwargs={"image_embeds": image_embeds} if image_embeds is not None else None,
+              cross_attention_kwargs={"cfg_shared_prefix": True} if cfg_shared_prefix else None)
+    b, f, _c, hh, ww = sample.shape
+
+    def late(out):
+        if out.dtype != sample.dtype:
+            raise RuntimeError("record_forward_plan: unexpected output dtype")
+        return {IO_OUT: out}
+    return record_plan(lambda: unet(sample, timesteps, enable_cross_frame_attn, encoder_hidden_states, **kw).sample, unet=unet, io=io,
+                       late_io=late, problem=(b, f, hh, ww, encoder_hidden_states.shape[1], int(image_embeds is not None)))
+
+
+# ---- the whole denoising loop (pipe:663-700) for a host without Python: a per-sample preparation plan and a per-step plan whose
+#      per-sample buffers are named like weights
+STEP_LATENTS, STEP_COND, STEP_INDEX, STEP_COEF = range(4)          # io slots of a step plan
+PREP_CONTEXT, PREP_TIMESTEPS, PREP_IMAGE_EMBEDS = range(3)         # io slots of a preparation plan
+
+
+def sample_buffers(unet, st):
+    """name -> tensor of the per-sample buffers a prepared pipeline state holds and its captured step reads (`_run_steps`): the
+    time-embedding table of the schedule and every cross-attention layer's K / V^T of the context (+ their fragment form)"""
+    out = {"sample#temb_table": st["temb_table"]}
+    pc = st["ctx_proj"]
+    for i, attn in enumerate(unet._cross_attention_layers()):
+        for nm, t in zip(("k", "vt", "k_ip", "vt_ip"), pc.kv[attn]):
+            if t is not None:
+                out[f"sample#ctx.{i}.{nm}"] = t
+        for j, t in enumerate(pc.frag.get(attn) or ()):
+            if t is not None:
+                out[f"sample#ctx.{i}.frag{j}"] = t
+    return out
+
+
+def _step_problem(st):
+    b, f, _c, hh, ww = st["latents"].shape
+    return (st["copies"] * b, f, hh, ww, st["ctx_text"].shape[1], int(st["ctx_ip"] is not None))
+
+
+def record_step_plan(pipe, st):
+    """ONE iteration of pipe:666-697 -- `I2VAdapterPipeline._step`: frame-0 overwrite + CFG duplicate (i2v_ddim_prep), the UNet as the
+    pipeline routes it (projected context, the step's row of the time-embedding table, the CFG prefix computed once), CFG combine +
+    DDIM update (i2v_ddim_cfg_step) -- as a launch plan.  `st` is a PREPARED pipeline state (static buffers, `ctx_proj`, `temb_table`).
+    io: STEP_LATENTS fp32 [B, F, C, H, W] (in / out), STEP_COND fp32 [B, C, H, W], STEP_INDEX int32 [1] (in / out: advanced by the
+    step), STEP_COEF fp32 [T, 4]; the per-sample buffers are weights named `sample#...` (`sample_buffers`)."""
+    keep = (st["latents"].clone(), st["step_idx"].clone())
+
+    def restore():
+        st["latents"].copy_(keep[0])
+        st["step_idx"].copy_(keep[1])
+    blob, weights = record_plan(lambda: pipe._step(st), unet=pipe.unet, restore=restore, problem=_step_problem(st),
+                                io={STEP_LATENTS: st["latents"], STEP_COND: st["cond"], STEP_INDEX: st["step_idx"], STEP_COEF: st["coef"]},
+                                extra_persistent=sample_buffers(pipe.unet, st))
+    restore()
     return blob, weights
+
+
+def record_prepare_plan(pipe, st, image_embeds=None):
+    """What the pipeline computes once per sample before its steps (`_run_steps`; the reference recomputes it inside every UNet call):
+    ImageProjection of the image embeds (unet:1284-1287, 1351-1352), to_k / to_v of the context for the 16 cross-attention layers
+    (i2v:527-532, unet:1263-1279) written into the state's `ctx_proj` buffers, and time_proj -> time_embedding -> silu -> the 22
+    time_emb_proj of every timestep of the schedule (unet:1336-1343) written into `temb_table` -- as a launch plan.
+    io: PREP_CONTEXT fp16 [2 B, L, D] (= st["ctx_text"]), PREP_TIMESTEPS fp32 [T] (= st["t_table"]), PREP_IMAGE_EMBEDS fp16 [2 B, clip]."""
+    unet = pipe.unet
+    io = {PREP_CONTEXT: st["ctx_text"], PREP_TIMESTEPS: st["t_table"]}
+    if image_embeds is not None:
+        io[PREP_IMAGE_EMBEDS] = image_embeds
+
+    def run():
+        ip = unet._project_image_embeds({"image_embeds": image_embeds}) if image_embeds is not None else None
+        unet.project_context(st["ctx_text"], ip, out=st["ctx_proj"])
+        unet.project_time_table(st["t_table"], out=st["temb_table"])
+    try:
+        return record_plan(run, unet=unet, io=io, problem=_step_problem(st), extra_persistent=sample_buffers(unet, st))
+    finally:
+        st["ctx_proj"].ip = st["ctx_ip"]          # (not the projection the recorded call allocated from its private pool)
 
 
 def base_tensor(t):
@@ -332,6 +427,13 @@ class UNetHandle:
         _lib.check(self._lib.i2v_unet_forward(self._h, p(sample), p(timesteps), p(context), p(image_embeds), p(out),
                                               C.c_void_p(s.cuda_stream)), "i2v_unet_forward")
         return out
+
+    def run(self, io, stream=None):
+        """the installed plan with {slot: tensor} as its arguments (`i2v_unet_run`): plans of `record_step_plan` / `record_prepare_plan`"""
+        dev_t = next(iter(io.values()))
+        s = stream if stream is not None else torch.cuda.current_stream(dev_t.device)
+        arr = (C.c_void_p * 5)(*[(io[i].data_ptr() if io.get(i) is not None else None) for i in range(5)])
+        _lib.check(self._lib.i2v_unet_run(self._h, arr, 5, C.c_void_p(s.cuda_stream)), "i2v_unet_run")
 
     def capture(self, stream, launch):
         """capture what `launch()` issues on `stream` (a torch.cuda.Stream made current for the call) as the handle's step.

@@ -720,6 +720,14 @@ int i2v_unet_set_workspace(i2v_unet* h, void* arena, int64_t bytes);
  * argument the plan reads; errors of the launches themselves are returned as they come. */
 int i2v_unet_forward(i2v_unet* h, const void* sample, const void* timesteps, const void* context, const void* image_embeds,
                      void* out, i2v_stream_t stream);
+/* (ABI 9) the general form: runs the installed plan with `io[slot]` as its arguments (n_io <= I2V_IO_SLOTS; the rest NULL).
+ * i2v_unet_forward is i2v_unet_run with {sample, timesteps, context, image_embeds, out}.  Plans of OTHER launch sequences of the host
+ * mirror use it with their own slot meaning (handle.py `record_plan`): the per-sample preparation (context K / V^T of the 16
+ * cross-attention layers + the time-embedding table of the schedule; `record_prepare_plan`) and one whole DDIM step -- i2v_ddim_prep,
+ * the UNet on the CFG batch as the pipeline routes it, i2v_ddim_cfg_step, pipe:666-697 -- (`record_step_plan`), whose per-sample
+ * buffers are registered by name like weights (`sample#...`).  tests/c_host/denoise_host.c runs the reference's whole denoising
+ * loop (pipe:663-700) that way. */
+int i2v_unet_run(i2v_unet* h, const void* const* io, int32_t n_io, i2v_stream_t stream);
 /* begin / end the capture of one step on `stream` (hipStreamBeginCapture, relaxed mode): everything launched on the stream in
  * between -- i2v_unet_forward and the host's DDIM kernels -- becomes the handle's step; i2v_unet_abort_capture ends a capture
  * whose launches failed and discards it */

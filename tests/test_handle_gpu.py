@@ -143,7 +143,11 @@ def test_full_width_forward_through_the_c_abi(dev, monkeypatch, ip):
         hd.forward(inp["sample"], inp["t"], inp["ctx"], inp["ie"], out)
         torch.cuda.synchronize()
     assert torch.equal(out, ref)
-    print(f"SD-1.5 width, ip={ip}: {hd.set_plan(blob)[0]} launches, {len(weights)} weight keys "
+    sd_keys = set(hu.state_dict())
+    n_sd = sum(k in sd_keys for k in weights)
+    assert n_sd > 300 and all(("#" in k) != (k in sd_keys) for k in weights)      # checkpoint tensors go by their state-dict key
+    print(f"SD-1.5 width, ip={ip}: {hd.set_plan(blob)[0]} launches, {len(weights)} weight keys ({n_sd} of them state-dict keys: tensors "
+          f"read as the checkpoint holds them; {len(weights) - n_sd} re-laid-out packs) "
           f"({sum(pkg().handle.base_tensor(w).numel() * w.element_size() for w in weights.values()) / 1e9:.2f} GB), arena "
           f"{hd.activation_bytes / 1e9:.2f} GB, plan {len(blob) / 1e6:.2f} MB")
     hd.close()
@@ -177,4 +181,146 @@ def test_c_host_runs_the_forward_without_python(dev, tmp_path):
     print(r.stdout.strip())
     import numpy as np
     got = torch.from_numpy(np.fromfile(tmp_path / "out.bin", dtype=np.float16).copy()).view(ref.shape)
+    assert torch.equal(got, ref.cpu())
+
+
+# ------------------------------------------------------------------------------------------------ the whole denoising loop from C
+def _prepared_state(pipe, hu, dev, B, F, h_lat, ctx_len, ctx_dim, clip_dim, seed, T=25):
+    """a pipeline state as `I2VAdapterPipeline.__call__` / bench.py build it: static buffers + the per-sample buffers (pipe:629-660)"""
+    g = torch.Generator().manual_seed(seed)
+    sch = pipe.scheduler
+    sch.set_timesteps(T)
+    ts = sch.timesteps
+    ie = torch.randn(2 * B, clip_dim, generator=g).half().to(dev) if clip_dim else None
+    st = dict(latents=torch.randn(B, F, 4, h_lat, h_lat, generator=g).to(dev), cond=torch.randn(B, 4, h_lat, h_lat, generator=g).to(dev),
+              copies=2, num_frames=F, guidance=7.5, t_table=ts.float().to(dev), coef=sch.step_coefficients(ts).to(dev),
+              step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
+              ctx_text=torch.randn(2 * B, ctx_len, ctx_dim, generator=g).half().to(dev),
+              ctx_ip=hu._project_image_embeds({"image_embeds": ie}) if ie is not None else None)
+    with torch.no_grad():
+        st["ctx_proj"] = hu.project_context(st["ctx_text"], st["ctx_ip"])
+        st["temb_table"] = hu.project_time_table(st["t_table"])
+    return st, ie
+
+
+def _python_loop(pipe, hu, st, ie, latents0, n_steps):
+    """the reference loop through the host mirror: per-sample preparation, then n_steps x `_step` (pipe:663-700)"""
+    with torch.no_grad():
+        st["latents"].copy_(latents0)
+        st["step_idx"].zero_()
+        ip = hu._project_image_embeds({"image_embeds": ie}) if ie is not None else None
+        hu.project_context(st["ctx_text"], ip, out=st["ctx_proj"])
+        hu.project_time_table(st["t_table"], out=st["temb_table"])
+        for _ in range(n_steps):
+            pipe._step(st)
+        torch.cuda.synchronize()
+    return st["latents"].clone()
+
+
+def _scramble(st, hu):
+    H = pkg().handle
+    for t in H.sample_buffers(hu, st).values():
+        t.fill_(float("nan"))
+
+
+@pytest.mark.parametrize("width", ["small", "sd15"])
+def test_denoising_loop_through_the_c_abi(dev, monkeypatch, width):
+    """pipe:663-700 without the host mirror on the call path: `record_prepare_plan` + `record_step_plan`, then per sample ONE
+    `i2v_unet_run` (context K / V^T, ImageProjection, time-embedding table) and per step ONE graph replay of ONE `i2v_unet_run`
+    (i2v_ddim_prep -> the UNet as the pipeline routes it -> i2v_ddim_cfg_step).  For a NEW prompt / image (other contents in the same
+    buffers than at recording time) the latents after 4 steps equal the Python loop's bit for bit."""
+    H = pkg().handle
+    if width == "small":
+        ou = oracle_small_unet(ip=True)
+        hu = hip_unet_from_oracle(ou, dev, ip_state_dict=small_ip_state_dict(ou))
+        dims = dict(B=1, F=4, h_lat=16, ctx_len=7, ctx_dim=64, clip_dim=48)
+    else:
+        hu = hip_model_random(SD15, dev, seed=78)
+        hu._load_ip_adapter_weights(sd15_ip_state_dict(hu))
+        dims = dict(B=1, F=8, h_lat=32, ctx_len=77, ctx_dim=768, clip_dim=1024)
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+    st, ie = _prepared_state(pipe, hu, dev, seed=31, **dims)
+    with torch.no_grad():
+        step_blob, w_step = H.record_step_plan(pipe, st)            # (its warm-up run also makes the fused kernels' context fragments)
+        prep_blob, w_prep = H.record_prepare_plan(pipe, st, image_embeds=ie)
+    weights = {**w_step, **w_prep}
+    assert any(k.startswith("sample#") for k in w_step) and any(k.startswith("sample#") for k in w_prep)
+    problem = H._step_problem(st)
+    handles = []
+    for blob in (prep_blob, step_blob):
+        hd = pkg().UNetHandle(hu, ip_num_tokens=4)
+        hd.plan(*problem[:4], ctx_len=problem[4], has_ip=bool(problem[5]))
+        hd.set_plan(blob)
+        hd.set_weights(weights)
+        handles.append(hd)
+    hp, hs = handles
+    arena = torch.empty(max(hp.activation_bytes, hs.activation_bytes), dtype=torch.uint8, device=dev)
+    hp.set_workspace(arena)
+    hs.set_workspace(arena)
+    # a new sample in the same buffers
+    g = torch.Generator().manual_seed(32)
+    st["ctx_text"].copy_(torch.randn(st["ctx_text"].shape, generator=g).half())
+    ie.copy_(torch.randn(ie.shape, generator=g).half())
+    st["cond"].copy_(torch.randn(st["cond"].shape, generator=g))
+    latents0 = torch.randn(st["latents"].shape, generator=g).to(dev)
+    n_steps = 4
+    ref = _python_loop(pipe, hu, st, ie, latents0, n_steps)
+    _scramble(st, hu)
+    st["latents"].copy_(latents0)
+    st["step_idx"].zero_()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with monkeypatch.context() as m:
+        _no_python_launches(m)
+        with torch.cuda.stream(s):
+            hp.run({H.PREP_CONTEXT: st["ctx_text"], H.PREP_TIMESTEPS: st["t_table"], H.PREP_IMAGE_EMBEDS: ie}, stream=s)
+        io = {H.STEP_LATENTS: st["latents"], H.STEP_COND: st["cond"], H.STEP_INDEX: st["step_idx"], H.STEP_COEF: st["coef"]}
+        hs.capture(s, lambda: hs.run(io, stream=s))
+        for _ in range(n_steps):
+            hs.replay(s)
+        s.synchronize()
+    assert torch.equal(st["latents"], ref), f"max |d| {(st['latents'] - ref).abs().max().item():.3e}"
+    assert int(st["step_idx"].item()) == n_steps and torch.equal(st["latents"][:, 0] * 0, ref[:, 0] * 0)
+    print(f"{width}: preparation {hp.set_plan(prep_blob)[0]} launches, step {hs.set_plan(step_blob)[0]} launches, "
+          f"{sum(k.startswith('sample#') for k in weights)} per-sample buffers")
+    for hd in handles:
+        hd.close()
+
+
+def test_c_host_runs_the_denoising_loop_without_python(dev, tmp_path):
+    """tests/c_host/denoise_host.c: prepare.plan + step.plan + weights.bin + inputs -> final latents, in a process that links
+    libi2v_hip.so and the HIP runtime only; equal to the Python loop's latents bit for bit."""
+    exe = os.path.join(ROOT, "tests", "c_host", "denoise_host")
+    if not os.path.exists(exe):
+        pytest.fail("tests/c_host/denoise_host is not built (python __graft_entry__.py)")
+    H = pkg().handle
+    ou = oracle_small_unet(ip=True)
+    hu = hip_unet_from_oracle(ou, dev, ip_state_dict=small_ip_state_dict(ou))
+    pipe = pkg().I2VAdapterPipeline(unet=hu)
+    dims = dict(B=1, F=4, h_lat=16, ctx_len=7, ctx_dim=64, clip_dim=48)
+    st, ie = _prepared_state(pipe, hu, dev, seed=41, **dims)
+    with torch.no_grad():
+        step_blob, w_step = H.record_step_plan(pipe, st)
+        prep_blob, w_prep = H.record_prepare_plan(pipe, st, image_embeds=ie)
+    latents0 = st["latents"].clone()
+    n_steps = 6
+    ref = _python_loop(pipe, hu, st, ie, latents0, n_steps)
+    _scramble(st, hu)                                   # the file carries garbage for the per-sample buffers: the C host must compute them
+    H.save_plan(prep_blob, tmp_path / "prepare.plan")
+    H.save_plan(step_blob, tmp_path / "step.plan")
+    H.save_weights({**w_step, **w_prep}, tmp_path / "weights.bin")
+    cfg = hu.config
+    ints = [cfg.in_channels, cfg.out_channels, *cfg.block_out_channels, cfg.layers_per_block, cfg.num_attention_heads, cfg.cross_attention_dim,
+            cfg.norm_num_groups, cfg.motion_max_seq_length, cfg.motion_num_attention_heads, 1, 4,
+            2, 4, 16, 16, 7, 48, st["t_table"].numel(), 1, 0, 0]
+    with open(tmp_path / "inputs.bin", "wb") as f:
+        f.write(b"I2VD" + struct.pack("<24i", *ints))
+        for t in (latents0, st["cond"], st["ctx_text"], st["t_table"], st["coef"], ie):
+            f.write(t.cpu().contiguous().numpy().tobytes())
+    r = subprocess.run([exe, str(tmp_path / "prepare.plan"), str(tmp_path / "step.plan"), str(tmp_path / "weights.bin"),
+                        str(tmp_path / "inputs.bin"), str(tmp_path / "out.bin"), str(n_steps)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    print(r.stdout.strip())
+    import numpy as np
+    got = torch.from_numpy(np.fromfile(tmp_path / "out.bin", dtype=np.float32).copy()).view(ref.shape)
     assert torch.equal(got, ref.cpu())
