@@ -135,8 +135,8 @@ def record_plan(run, *, unet, io, problem, late_io=None, extra_persistent=None, 
       io                {slot: tensor}: buffers that exist before the call -- the plan's arguments (read and / or written in place)
       late_io           result -> {slot: tensor}: tensors `run()` allocates and returns that the caller wants as arguments (a forward's
                         output): claimed in the LAST launch only (an earlier, freed activation may have had the address)
-      extra_persistent  {name: tensor}: more buffers that outlive the call and are registered by name like weights (per-sample
-                        buffers: `sample#...`)
+      extra_persistent  {name: tensor} (or a callable returning it, evaluated after the call): more buffers that outlive the call and
+                        are registered by name like weights (per-sample buffers: `sample#...`)
       restore           called before every invocation of `run()` (it is invoked twice: once to build every lazily packed operand,
                         once recorded): puts in / out arguments back to their initial contents
       problem           (batch, frames, height, width, ctx_len, has_ip) for the blob's header (`i2v_unet_plan` must match)
@@ -177,7 +177,8 @@ def record_plan(run, *, unet, io, problem, late_io=None, extra_persistent=None, 
     io_ranges = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), s, False) for s, t in io.items()]
     io_ranges += [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), s, True) for s, t in late.items()]
     pers = persistent_tensors(unet)
-    pers.update({k: v for k, v in (extra_persistent or {}).items() if v is not None and v.is_cuda and v.numel()})
+    extra = extra_persistent() if callable(extra_persistent) else (extra_persistent or {})       # (after the call: it may create some)
+    pers.update({k: v for k, v in extra.items() if v is not None and v.is_cuda and v.numel()})
     spans = {}
     # one name per storage.  A tensor the kernels read exactly as the checkpoint holds it (fp16 biases, norm affines, Linear / 1x1
     # weights: `w16` of an fp16 parameter is the parameter) goes by its STATE-DICT key -- a host can register the reference's
@@ -306,7 +307,7 @@ def record_step_plan(pipe, st):
         st["step_idx"].copy_(keep[1])
     blob, weights = record_plan(lambda: pipe._step(st), unet=pipe.unet, restore=restore, problem=_step_problem(st),
                                 io={STEP_LATENTS: st["latents"], STEP_COND: st["cond"], STEP_INDEX: st["step_idx"], STEP_COEF: st["coef"]},
-                                extra_persistent=sample_buffers(pipe.unet, st))
+                                extra_persistent=lambda: sample_buffers(pipe.unet, st))
     restore()
     return blob, weights
 
@@ -327,7 +328,7 @@ def record_prepare_plan(pipe, st, image_embeds=None):
         unet.project_context(st["ctx_text"], ip, out=st["ctx_proj"])
         unet.project_time_table(st["t_table"], out=st["temb_table"])
     try:
-        return record_plan(run, unet=unet, io=io, problem=_step_problem(st), extra_persistent=sample_buffers(unet, st))
+        return record_plan(run, unet=unet, io=io, problem=_step_problem(st), extra_persistent=lambda: sample_buffers(unet, st))
     finally:
         st["ctx_proj"].ip = st["ctx_ip"]          # (not the projection the recorded call allocated from its private pool)
 
