@@ -215,7 +215,11 @@ def test_model_handle_launch_plan_without_a_gpu(lib):
     # an argument the plan reads must be passed
     needs_ctx = _plan_blob(lib, [(silu, b"", [0, 0, 8], [(0, 2, 2, 0), (8, 0, 0, 0)])], arena=1024, io_mask=1 << 2)
     assert sp(needs_ctx) == 0
-    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"`context` is NULL" in h.i2v_last_error()
+    assert h.i2v_unet_forward(hd, None, None, None, None, None, None) == -1 and b"`context` (argument 2) is NULL" in h.i2v_last_error()
+    # the general entry: i2v_unet_run with the arguments as an array (i2v_unet_forward is it with the forward's five)
+    arr = (C.c_void_p * 5)(None, None, None, None, None)
+    assert h.i2v_unet_run(hd, arr, 5, None) == -1 and b"argument 2" in h.i2v_last_error()
+    assert h.i2v_unet_run(hd, arr, 9, None) == -1 and h.i2v_unet_run(hd, None, 3, None) == -1
     # a new problem drops the plan; the same problem keeps it
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 16, 64, 64, 77, 0))) == 0 and h.i2v_unet_plan_launches(hd) == 1
     assert h.i2v_unet_plan(hd, C.byref(lib.UnetPlan(2, 8, 64, 64, 77, 0))) == 0 and h.i2v_unet_plan_launches(hd) == 0
