@@ -130,6 +130,45 @@ def _storage_range(t):
     return st.data_ptr(), st.data_ptr() + st.nbytes()
 
 
+def pack_plan(keys, ops_bin, relocs, payload, problem, arena_bytes, io_mask):
+    """the blob `i2v_unet_set_plan` takes (csrc/handle.hip PlanHeader / PlanOp / PlanReloc; little-endian, sections 8-byte aligned):
+    header, key table (u32 length + bytes, padded to 4), ops (6 x u32: entry, payload offset, payload bytes, first relocation,
+    relocation count, struct bytes), relocations (offset, kind, index, pad: 4 x u32; addend: u64), payload"""
+    key_tab = bytearray()
+    for k in keys:
+        kb = k.encode() if isinstance(k, str) else bytes(k)
+        key_tab += struct.pack("<I", len(kb)) + kb + b"\0" * (-len(kb) % 4)
+    key_tab += b"\0" * (-len(key_tab) % 8)
+    hdr_size = struct.calcsize("<6I6iQ2I6Q")
+    keys_off = hdr_size
+    ops_off = keys_off + len(key_tab)
+    relocs_off = ops_off + 24 * len(ops_bin)
+    payload_off = relocs_off + 24 * len(relocs)
+    total = payload_off + len(payload)
+    hdr = struct.pack("<6I6iQ2I6Q", PLAN_MAGIC, PLAN_VERSION, _lib.ABI_VERSION, len(ops_bin), len(keys), len(relocs),
+                      *[int(v) for v in problem], arena_bytes, io_mask, 0,
+                      keys_off, ops_off, relocs_off, payload_off, len(payload), total)
+    blob = bytes(hdr + key_tab + b"".join(ops_bin) + b"".join(relocs) + bytes(payload))
+    assert len(blob) == total
+    return blob
+
+
+def pack_op(entry, struct_bytes, slots, relocations, payload, relocs):
+    """one launch appended to `payload` / `relocs`; returns its PlanOp record.  slots: 8-byte values (bytes); relocations:
+    (offset in the launch's block, kind, index, addend)"""
+    blockb = bytearray(struct_bytes) + bytearray(_pad8(len(struct_bytes)) - len(struct_bytes))
+    for v in slots:
+        blockb += v
+    begin = len(relocs)
+    for off, kind, index, addend in relocations:
+        if off + 8 <= len(blockb):                  # (a relocation outside its block is the parser's business to refuse)
+            blockb[off: off + 8] = b"\0" * 8
+        relocs.append(struct.pack("<IIIIQ", off, kind, index, 0, addend))
+    rec = struct.pack("<IIIIII", entry, len(payload), len(blockb), begin, len(relocs) - begin, len(struct_bytes))
+    payload += blockb
+    return rec
+
+
 def record_plan(run, *, unet, io, problem, late_io=None, extra_persistent=None, restore=None):
     """The launches `run()` issues, as a launch plan for `i2v_unet_run` (`UNetHandle.run`).
       io                {slot: tensor}: buffers that exist before the call -- the plan's arguments (read and / or written in place)
@@ -192,11 +231,8 @@ def record_plan(run, *, unet, io, problem, late_io=None, extra_persistent=None, 
     keys, key_index, relocs, ops_bin, payload = [], {}, [], [], bytearray()
     io_mask = 0
     for op_i, (entry, sbytes, slots, ptrs) in enumerate(rec.ops):
-        blockb = bytearray(sbytes) + bytearray(_pad8(len(sbytes)) - len(sbytes))
-        for v in slots:
-            blockb += v
-        begin = len(relocs)
         last = op_i == len(rec.ops) - 1
+        hits = []
         for off, v, what in ptrs:
             hit = next(((RELOC_IO, s, v - lo) for lo, hi, s, is_late in io_ranges if lo <= v < hi and (not is_late or last)), None)
             if hit is None:
@@ -216,29 +252,12 @@ def record_plan(run, *, unet, io, problem, late_io=None, extra_persistent=None, 
                                    "memory the call allocated -- a buffer the plan cannot name")
             if hit[0] == RELOC_IO:
                 io_mask |= 1 << hit[1]
-            blockb[off: off + 8] = b"\0" * 8
-            relocs.append(struct.pack("<IIIIQ", off, hit[0], hit[1], 0, hit[2]))
-        ops_bin.append(struct.pack("<IIIIII", entry, len(payload), len(blockb), begin, len(relocs) - begin, len(sbytes)))
-        payload += blockb
+            hits.append((off,) + hit)
+        ops_bin.append(pack_op(entry, sbytes, slots, hits, payload, relocs))
     for s_ in late:
         if not (io_mask >> s_) & 1:
             raise RuntimeError("record_plan: the last launch does not write the call's result")
-    key_tab = bytearray()
-    for k in keys:
-        kb = k.encode()
-        key_tab += struct.pack("<I", len(kb)) + kb + b"\0" * (-len(kb) % 4)
-    key_tab += b"\0" * (-len(key_tab) % 8)
-    hdr_size = struct.calcsize("<6I6iQ2I6Q")
-    keys_off = hdr_size
-    ops_off = keys_off + len(key_tab)
-    relocs_off = ops_off + 24 * len(ops_bin)
-    payload_off = relocs_off + 24 * len(relocs)
-    total = payload_off + len(payload)
-    hdr = struct.pack("<6I6iQ2I6Q", PLAN_MAGIC, PLAN_VERSION, _lib.ABI_VERSION, len(ops_bin), len(keys), len(relocs),
-                      *[int(v) for v in problem], arena_bytes, io_mask, 0,
-                      keys_off, ops_off, relocs_off, payload_off, len(payload), total)
-    blob = bytes(hdr + key_tab + b"".join(ops_bin) + b"".join(relocs) + payload)
-    assert len(blob) == total
+    blob = pack_plan(keys, ops_bin, relocs, payload, problem, arena_bytes, io_mask)
     return blob, {k: pers[k] for k in keys}
 
 

@@ -149,28 +149,17 @@ def test_model_handle_registry_and_plan_without_a_gpu(lib):
 
 
 def _plan_blob(lib, ops, keys=(), arena=0, problem=(2, 16, 64, 64, 77, 0), abi=None, io_mask=0):
-    """a launch plan by hand (the format handle.py `record_forward_plan` writes; csrc/handle.hip PlanHeader / PlanOp / PlanReloc):
-    ops = [(entry id, struct bytes, [slots], [(payload offset, kind, index, addend)])]"""
+    """a launch plan by hand THROUGH THE RECORDER'S OWN WRITER (handle.pack_op / pack_plan: the format `record_plan` emits, parsed by
+    csrc/handle.hip): ops = [(entry id, struct bytes, [slot integers], [(payload offset, kind, index, addend)])]"""
     import struct
-    key_tab = bytearray()
-    for k in keys:
-        key_tab += struct.pack("<I", len(k)) + k + b"\0" * (-len(k) % 4)
-    key_tab += b"\0" * (-len(key_tab) % 8)
+    from i2v_adapter_unofficial_amd import handle as H
     ops_bin, relocs, payload = [], [], bytearray()
     for entry, sbytes, slots, rel in ops:
-        blk = bytearray(sbytes) + bytearray(-len(sbytes) % 8) + b"".join(struct.pack("<q", v) for v in slots)
-        ops_bin.append(struct.pack("<IIIIII", entry, len(payload), len(blk), len(relocs), len(rel), len(sbytes)))
-        relocs += [struct.pack("<IIIIQ", off, kind, idx, 0, add) for off, kind, idx, add in rel]
-        payload += blk
-    hdr_size = struct.calcsize("<6I6iQ2I6Q")
-    keys_off = hdr_size
-    ops_off = keys_off + len(key_tab)
-    relocs_off = ops_off + 24 * len(ops_bin)
-    payload_off = relocs_off + 24 * len(relocs)
-    total = payload_off + len(payload)
-    hdr = struct.pack("<6I6iQ2I6Q", 0x50563249, 1, lib.ABI_VERSION if abi is None else abi, len(ops_bin), len(keys), len(relocs), *problem,
-                      arena, io_mask, 0, keys_off, ops_off, relocs_off, payload_off, len(payload), total)
-    return bytes(hdr + key_tab + b"".join(ops_bin) + b"".join(relocs) + payload)
+        ops_bin.append(H.pack_op(entry, sbytes, [struct.pack("<q", v) for v in slots], rel, payload, relocs))
+    blob = bytearray(H.pack_plan(list(keys), ops_bin, relocs, payload, problem, arena, io_mask))
+    if abi is not None:
+        blob[8:12] = struct.pack("<I", abi)
+    return bytes(blob)
 
 
 def test_model_handle_launch_plan_without_a_gpu(lib):
