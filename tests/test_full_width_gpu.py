@@ -88,6 +88,23 @@ def test_full_width_unet_forward(dev, pair, cross_frame):
         assert (got - off).abs().max().item() > 10 * FWD_ABS_TOL
 
 
+def test_full_width_unet_forward_upsample_size(dev, pair):
+    """SD-1.5 width at 36 x 28 latents (288 x 224 pixels: divisible by 8 as pipe:213-214 demands, not by 64): the levels are 36 x 28,
+    18 x 14, 9 x 7, 5 x 4, so two of the three up-samplers interpolate to 2 n - 1 (unet:1304-1311, 1414-1415 forward_upsample_size),
+    the fused 320-channel kernels see 1008 rows per image (not a multiple of their 128-row tiles: the un-fused forms run) and every
+    GEMM / conv / attention runs on ragged row counts -- against the oracle, same tolerance as the aligned sizes."""
+    ou, hu = pair
+    g = torch.Generator().manual_seed(21)
+    sample, ctx = h(torch.randn(2, 4, 4, 36, 28, generator=g)), h(torch.randn(2, 77, 768, generator=g))
+    t = torch.tensor([481, 481])
+    with torch.no_grad():
+        ref = ou(sample, t, True, ctx).sample
+        got = hu(sample.to(dev), t.to(dev), True, ctx.to(dev)).sample
+    assert got.shape == ref.shape == (2, 4, 4, 36, 28)
+    err, scale = compare(got, ref, abs_tol=FWD_ABS_TOL, name="full-width UNet forward at 36 x 28 latents (forward_upsample_size)")
+    print(f"full-width UNet at 36 x 28 latents: HIP err {err:.3e} (rms {(got.float().cpu() - ref).pow(2).mean().sqrt().item():.3e}), max|ref| {scale:.3e}")
+
+
 def test_full_width_unet_forward_ip(dev, pair_ip):
     ou, hu = pair_ip
     inp = _inputs(seed=5)
