@@ -474,3 +474,88 @@ class UNetHandle:
     @property
     def has_step(self):
         return bool(self._lib.i2v_unet_has_step(self._h))
+
+
+# ---- export for a host without Python: everything tests/c_host/denoise_host.c (or a service of the reader's own) loads
+def export_denoiser(pipe, out_dir, *, num_frames, latent_height, latent_width, batch=1, ctx_len=77, clip_dim=None,
+                    num_inference_steps=25, guidance_scale=7.5):
+    """Writes the reference's denoising loop (pipe:663-700) for ONE problem size as files a C host runs through `i2v_unet_run`:
+        prepare.plan   once per sample (`record_prepare_plan`)       step.plan   once per DDIM step (`record_step_plan`)
+        weights.bin    every buffer the two plans name (`save_weights`: model weights by state-dict key / `<module>#<pack>`, per-sample
+                       buffers `sample#...` -- the preparation overwrites those)
+        manifest.json  the problem, the io slots of both plans with their dtypes and shapes, the schedule's tables (timesteps,
+                       DDIM coefficients) and the values baked into the step (guidance scale, CFG copies, table length)
+    `pipe`: an `I2VAdapterPipeline` on the GPU (its UNet with or without the IP-Adapter: clip_dim = the image embeds' width, None
+    without).  Returns the manifest.  A plan holds for this size, these switches and this library build."""
+    import json
+    import os
+    unet = pipe.unet
+    dev = unet.device
+    sch = pipe.scheduler
+    sch.set_timesteps(num_inference_steps)
+    ts = sch.timesteps
+    B, F, hh, ww = batch, num_frames, latent_height, latent_width
+    c_in, d_ctx = unet.config.in_channels, unet.config.cross_attention_dim
+    with torch.no_grad():
+        ie = torch.zeros(2 * B, clip_dim, dtype=torch.float16, device=dev) if clip_dim else None
+        st = dict(latents=torch.zeros(B, F, c_in, hh, ww, device=dev), cond=torch.zeros(B, c_in, hh, ww, device=dev), copies=2,
+                  num_frames=F, guidance=float(guidance_scale), t_table=ts.float().to(dev), coef=sch.step_coefficients(ts).to(dev),
+                  step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
+                  ctx_text=torch.zeros(2 * B, ctx_len, d_ctx, dtype=torch.float16, device=dev),
+                  ctx_ip=unet._project_image_embeds({"image_embeds": ie}) if ie is not None else None)
+        st["ctx_proj"] = unet.project_context(st["ctx_text"], st["ctx_ip"])
+        st["temb_table"] = unet.project_time_table(st["t_table"])
+        step_blob, w_step = record_step_plan(pipe, st)
+        prep_blob, w_prep = record_prepare_plan(pipe, st, image_embeds=ie)
+    os.makedirs(out_dir, exist_ok=True)
+    save_plan(prep_blob, os.path.join(out_dir, "prepare.plan"))
+    save_plan(step_blob, os.path.join(out_dir, "step.plan"))
+    weights = {**w_step, **w_prep}
+    save_weights(weights, os.path.join(out_dir, "weights.bin"))
+    desc = lambda t: None if t is None else {"dtype": str(t.dtype).replace("torch.", ""), "shape": list(t.shape)}
+    cfg = unet.config
+    manifest = {
+        "abi_version": _lib.ABI_VERSION,
+        "unet_config": {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in dict(cfg).items()
+                        if isinstance(v, (int, float, str, bool, tuple, list)) or v is None},
+        "ip_num_tokens": 4 if ie is not None else 0,
+        "problem": dict(zip(("batch", "frames", "height", "width", "ctx_len", "has_ip"), _step_problem(st))),
+        "samples": B, "cfg_copies": 2, "guidance_scale": float(guidance_scale), "num_inference_steps": int(num_inference_steps),
+        "prepare": {"plan": "prepare.plan", "launches": int.from_bytes(prep_blob[12:16], "little"),
+                    "io": {str(PREP_CONTEXT): {"name": "context [negative ; positive] prompt embeds", **desc(st["ctx_text"])},
+                           str(PREP_TIMESTEPS): {"name": "timesteps of the schedule", **desc(st["t_table"])},
+                           **({str(PREP_IMAGE_EMBEDS): {"name": "image embeds [zeros ; image]", **desc(ie)}} if ie is not None else {})}},
+        "step": {"plan": "step.plan", "launches": int.from_bytes(step_blob[12:16], "little"),
+                 "io": {str(STEP_LATENTS): {"name": "latents (in / out)", **desc(st["latents"])},
+                        str(STEP_COND): {"name": "condition image latents", **desc(st["cond"])},
+                        str(STEP_INDEX): {"name": "device-side step counter (in / out; start at 0)", **desc(st["step_idx"])},
+                        str(STEP_COEF): {"name": "DDIM coefficients per step", **desc(st["coef"])}}},
+        "timesteps": [float(v) for v in st["t_table"].cpu()], "ddim_coefficients": st["coef"].cpu().tolist(),
+        "arena_bytes": max(int.from_bytes(prep_blob[48:56], "little"), int.from_bytes(step_blob[48:56], "little")),
+        "weights": {"file": "weights.bin", "tensors": len(weights), "state_dict_keys": sum("#" not in k for k in weights),
+                    "packs": sum("#" in k and not k.startswith("sample#") for k in weights),
+                    "per_sample_buffers": sum(k.startswith("sample#") for k in weights)},
+    }
+    with open(os.path.join(out_dir, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    return manifest
+
+
+def write_denoise_inputs(path, unet_config, manifest, latents, cond, context, image_embeds=None):
+    """the inputs file of tests/c_host/denoise_host.c for an `export_denoiser` manifest: initial latents fp32 [B, F, C, H, W] (after
+    the first-frame prior and add_noise, pipe:647-656), condition latents fp32 [B, C, H, W], context fp16 [2 B, L, D] (negative rows
+    first), image embeds fp16 [2 B, clip] (zeros first) -- host or device tensors."""
+    cfg, pr = unet_config, manifest["problem"]
+    get = (lambda k: cfg.get(k) if isinstance(cfg, dict) else getattr(cfg, k))
+    clip = 0 if image_embeds is None else image_embeds.shape[1]
+    ints = [get("in_channels"), get("out_channels"), *get("block_out_channels"), get("layers_per_block"), get("num_attention_heads"),
+            get("cross_attention_dim"), get("norm_num_groups"), get("motion_max_seq_length"), get("motion_num_attention_heads"), 1,
+            manifest["ip_num_tokens"], pr["batch"], pr["frames"], pr["height"], pr["width"], pr["ctx_len"], clip,
+            len(manifest["timesteps"]), manifest["samples"], 0, 0]
+    tt = torch.tensor(manifest["timesteps"], dtype=torch.float32)
+    coef = torch.tensor(manifest["ddim_coefficients"], dtype=torch.float32)
+    with open(path, "wb") as f:
+        f.write(b"I2VD" + struct.pack("<24i", *[int(v) for v in ints]))
+        for t, dt in ((latents, torch.float32), (cond, torch.float32), (context, torch.float16), (tt, torch.float32), (coef, torch.float32)) + \
+                (((image_embeds, torch.float16),) if image_embeds is not None else ()):
+            f.write(t.detach().to("cpu", dt).contiguous().numpy().tobytes())

@@ -288,8 +288,10 @@ def test_denoising_loop_through_the_c_abi(dev, monkeypatch, width):
 
 
 def test_c_host_runs_the_denoising_loop_without_python(dev, tmp_path):
-    """tests/c_host/denoise_host.c: prepare.plan + step.plan + weights.bin + inputs -> final latents, in a process that links
-    libi2v_hip.so and the HIP runtime only; equal to the Python loop's latents bit for bit."""
+    """`handle.export_denoiser` (prepare.plan + step.plan + weights.bin + manifest.json, recorded on zeros) and
+    `write_denoise_inputs` -> tests/c_host/denoise_host.c: the final latents of a process that links libi2v_hip.so and the HIP
+    runtime only equal the Python loop's bit for bit."""
+    import json
     exe = os.path.join(ROOT, "tests", "c_host", "denoise_host")
     if not os.path.exists(exe):
         pytest.fail("tests/c_host/denoise_host is not built (python __graft_entry__.py)")
@@ -298,25 +300,16 @@ def test_c_host_runs_the_denoising_loop_without_python(dev, tmp_path):
     hu = hip_unet_from_oracle(ou, dev, ip_state_dict=small_ip_state_dict(ou))
     pipe = pkg().I2VAdapterPipeline(unet=hu)
     dims = dict(B=1, F=4, h_lat=16, ctx_len=7, ctx_dim=64, clip_dim=48)
+    manifest = H.export_denoiser(pipe, str(tmp_path), num_frames=4, latent_height=16, latent_width=16, batch=1, ctx_len=7, clip_dim=48,
+                                 num_inference_steps=25, guidance_scale=7.5)
+    assert json.load(open(tmp_path / "manifest.json")) == manifest and manifest["weights"]["per_sample_buffers"] > 0
+    assert manifest["problem"] == dict(batch=2, frames=4, height=16, width=16, ctx_len=7, has_ip=1)
+    # the sample: the Python loop on a state of its own
     st, ie = _prepared_state(pipe, hu, dev, seed=41, **dims)
-    with torch.no_grad():
-        step_blob, w_step = H.record_step_plan(pipe, st)
-        prep_blob, w_prep = H.record_prepare_plan(pipe, st, image_embeds=ie)
     latents0 = st["latents"].clone()
     n_steps = 6
     ref = _python_loop(pipe, hu, st, ie, latents0, n_steps)
-    _scramble(st, hu)                                   # the file carries garbage for the per-sample buffers: the C host must compute them
-    H.save_plan(prep_blob, tmp_path / "prepare.plan")
-    H.save_plan(step_blob, tmp_path / "step.plan")
-    H.save_weights({**w_step, **w_prep}, tmp_path / "weights.bin")
-    cfg = hu.config
-    ints = [cfg.in_channels, cfg.out_channels, *cfg.block_out_channels, cfg.layers_per_block, cfg.num_attention_heads, cfg.cross_attention_dim,
-            cfg.norm_num_groups, cfg.motion_max_seq_length, cfg.motion_num_attention_heads, 1, 4,
-            2, 4, 16, 16, 7, 48, st["t_table"].numel(), 1, 0, 0]
-    with open(tmp_path / "inputs.bin", "wb") as f:
-        f.write(b"I2VD" + struct.pack("<24i", *ints))
-        for t in (latents0, st["cond"], st["ctx_text"], st["t_table"], st["coef"], ie):
-            f.write(t.cpu().contiguous().numpy().tobytes())
+    H.write_denoise_inputs(tmp_path / "inputs.bin", hu.config, manifest, latents0, st["cond"], st["ctx_text"], ie)
     r = subprocess.run([exe, str(tmp_path / "prepare.plan"), str(tmp_path / "step.plan"), str(tmp_path / "weights.bin"),
                         str(tmp_path / "inputs.bin"), str(tmp_path / "out.bin"), str(n_steps)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -40,45 +40,41 @@ def main():
     F, h = args.frames, args.size // 8
     s = bench.sample_inputs(0, F, h, args.ip)
     ie = torch.cat([torch.zeros_like(s["ie"]), s["ie"]]).half().to(dev) if args.ip else None
-    st = dict(latents=s["lat"].to(dev), cond=s["cond"].to(dev), copies=2, num_frames=F, guidance=7.5, t_table=ts.float().to(dev),
-              coef=sch.step_coefficients(ts).to(dev), step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
-              ctx_text=torch.cat([s["ne"], s["pe"]]).half().to(dev),
-              ctx_ip=hu._project_image_embeds({"image_embeds": ie}) if ie is not None else None)
-    with torch.no_grad():
-        st["ctx_proj"] = hu.project_context(st["ctx_text"], st["ctx_ip"])
-        st["temb_table"] = hu.project_time_table(st["t_table"])
-        step_blob, w_step = H.record_step_plan(pipe, st)
-        prep_blob, w_prep = H.record_prepare_plan(pipe, st, image_embeds=ie)
-        lat0 = st["latents"].clone()
-        # the Python pipeline's own route: the step captured by torch, replayed
-        st["step_idx"].zero_()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            pipe._step(st)
-        st["latents"].copy_(lat0)
-        st["step_idx"].zero_()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            g.replay()
-        torch.cuda.synchronize()
-        py_ms = (time.perf_counter() - t0) / args.steps * 1e3
-        ref = st["latents"].clone().cpu()
+    ctx = torch.cat([s["ne"], s["pe"]]).half().to(dev)
+    lat0, cond = s["lat"].to(dev), s["cond"].to(dev)
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
-        H.save_plan(prep_blob, os.path.join(d, "prepare.plan"))
-        H.save_plan(step_blob, os.path.join(d, "step.plan"))
         t0 = time.time()
-        H.save_weights({**w_step, **w_prep}, os.path.join(d, "weights.bin"))
-        cfg = hu.config
-        ints = [cfg.in_channels, cfg.out_channels, *cfg.block_out_channels, cfg.layers_per_block, cfg.num_attention_heads, cfg.cross_attention_dim,
-                cfg.norm_num_groups, cfg.motion_max_seq_length, cfg.motion_num_attention_heads, 1, 4 if args.ip else 0,
-                2, F, h, h, 77, 1024 if args.ip else 0, st["t_table"].numel(), 1, 0, 0]
-        with open(os.path.join(d, "inputs.bin"), "wb") as f:
-            f.write(b"I2VD" + struct.pack("<24i", *ints))
-            for t in (lat0, st["cond"], st["ctx_text"], st["t_table"], st["coef"]) + ((ie,) if ie is not None else ()):
-                f.write(t.cpu().contiguous().numpy().tobytes())
+        manifest = H.export_denoiser(pipe, d, num_frames=F, latent_height=h, latent_width=h, batch=1, ctx_len=77,
+                                     clip_dim=1024 if args.ip else None, num_inference_steps=25, guidance_scale=7.5)
+        H.write_denoise_inputs(os.path.join(d, "inputs.bin"), hu.config, manifest, lat0, cond, ctx, ie)
+        # the Python pipeline's own route on the same sample: per-sample preparation, the step captured by torch, replayed
+        with torch.no_grad():
+            st = dict(latents=lat0.clone(), cond=cond, copies=2, num_frames=F, guidance=7.5, t_table=ts.float().to(dev),
+                      coef=sch.step_coefficients(ts).to(dev), step_idx=torch.zeros(1, dtype=torch.int32, device=dev), ctx_text=ctx,
+                      ctx_ip=hu._project_image_embeds({"image_embeds": ie}) if ie is not None else None)
+            st["ctx_proj"] = hu.project_context(st["ctx_text"], st["ctx_ip"])
+            st["temb_table"] = hu.project_time_table(st["t_table"])
+            pipe._step(st)
+            st["latents"].copy_(lat0)
+            st["step_idx"].zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                pipe._step(st)
+            st["latents"].copy_(lat0)
+            st["step_idx"].zero_()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize()
+            py_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            ref = st["latents"].clone().cpu()
+        prep_blob = open(os.path.join(d, "prepare.plan"), "rb").read()
+        step_blob = open(os.path.join(d, "step.plan"), "rb").read()
         wbytes = os.path.getsize(os.path.join(d, "weights.bin"))
-        print(f"# plans {len(prep_blob) / 1e6:.2f} + {len(step_blob) / 1e6:.2f} MB, weights.bin {wbytes / 1e9:.2f} GB written in {time.time() - t0:.0f} s", flush=True)
+        print(f"# export_denoiser: plans {len(prep_blob) / 1e6:.2f} + {len(step_blob) / 1e6:.2f} MB, weights.bin {wbytes / 1e9:.2f} GB "
+              f"({manifest['weights']['state_dict_keys']} state-dict keys, {manifest['weights']['packs']} packs, "
+              f"{manifest['weights']['per_sample_buffers']} per-sample buffers), manifest.json; {time.time() - t0:.0f} s", flush=True)
         del hu, pipe, g, st
         torch.cuda.empty_cache()
         exe = os.path.join(ROOT, "tests", "c_host", "denoise_host")
