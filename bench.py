@@ -278,9 +278,14 @@ def dominant_kernel(by_shape):
             n_calls = sum(d["calls"] for d in sel)
             if n_calls:
                 fl = sum(d["flops"] for d in sel) / n_calls
+                live_us = sum(d["ms"] for d in sel) * 1e3 / n_calls       # HIP events of THIS run's instrumented eager step
                 out.update(flops_per_launch=fl, achieved_tflops=fl / (avg_us * 1e-6) / 1e12,
                            frac=fl / (avg_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
-                           flops_note="algorithmic 4 Lq Lk C per image, averaged over this head width's launches of one step")
+                           live_avg_us=live_us, live_launches=n_calls, live_achieved_tflops=fl / (live_us * 1e-6) / 1e12,
+                           live_frac=fl / (live_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                           flops_note="algorithmic 4 Lq Lk C per image, averaged over this head width's launches of one step; `avg_us` is "
+                                      "rocprofv3's average over the committed profile's graph replays, `live_avg_us` HIP events around the "
+                                      "same launches of this run's eager step (a few per cent slower: cold caches between eager launches)")
         return out
     return {"reason": f"no profiles/r*_kernel_stats.txt was taken on this library's kernel sources ({stamp}); found {seen}"}
 
