@@ -256,7 +256,21 @@ class I2VAdapterPipeline:
                  frame_similarity_sample_ratio: float = 1, frame_similarity_blurred_strength: float = 0.6,
                  condition_image_latents=None, image_embeds=None, negative_image_embeds=None,
                  prior_mask_generator=None, prior_noise_generator=None, blur_sigma: Optional[float] = None,
-                 use_graph: bool = True):
+                 use_graph: bool = True, precise_stream: Optional[bool] = None):
+        """pipe:537-711 (the arguments the reference's `__call__` takes; `use_graph`, the explicit prior generators and
+        `precise_stream` are additions).  precise_stream: True / False runs THIS call with / without the precise residual stream
+        (fp16 hi + lo pairs between the UNet's modules, DESIGN 2.2: closer to the fp32 reference, +2.6 % step time); None keeps the
+        process setting (`blocks.set_precise_stream`, I2V_STREAM_PRECISE)."""
+        if precise_stream is not None:
+            kw = dict(locals())
+            for k in ("self", "precise_stream"):
+                kw.pop(k)
+            from . import blocks
+            prev = blocks.set_precise_stream(precise_stream)
+            try:
+                return self.__call__(**kw)
+            finally:
+                blocks.set_precise_stream(prev)
         if prompt is not None or ip_adapter_image is not None:
             raise NotImplementedError(
                 "the CLIP text / image encoders are out of scope of this build (SURVEY section 2 row 3b): pass "

@@ -264,4 +264,7 @@ def test_pipeline_graph_is_recaptured_when_the_mode_changes(dev, small_pair):
     finally:
         blocks.set_precise_stream(entry)
     assert not torch.equal(a, b) and torch.equal(b, fresh) and torch.equal(a, c)
+    # ... and per call: `precise_stream=` of `__call__` (restores the process setting)
+    d = pipe(**kw, **gens(), precise_stream=True).frames
+    assert torch.equal(d, b) and blocks.precise_stream() == entry
     assert (a - b).abs().max().item() < 2e-2 * a.abs().max().item()
