@@ -18,6 +18,10 @@ applied ONLY at chosen places (everything else exact fp32):
            transformers and motion modules, the samplers' convs, conv_norm_out); the residual adds see the exact stream
   hilo_sc  the same, but conv_shortcut reads the exact stream too (the 1x1 shortcut GEMM over hi AND lo)
   hilo_blocks  hilo + the token stream inside the transformers rounded (what the fused 64^2 kernels keep in fp16)
+  hilo_gn  hilo without the rounding where a GroupNorm kernel could read hi + lo (ResnetBlock2D.norm1, conv_norm_out, the entry norms of
+           the transformers / motion modules below the 64^2 level -- at 64^2 they are folded into proj_in, whose MFMA operand is the raw
+           hi); conv_shortcut and the samplers' convs still read the rounded stream
+  hilo_gn_sc  hilo_gn + conv_shortcut reading the exact stream
 
   python tools/error_classes.py [--frames 16 --size 512] [--modes outer,blocks,everyop] [--out profiles/r4_error_classes.jsonl]
 Test infrastructure only (imports oracle/)."""
@@ -89,17 +93,22 @@ def main():
     def run(mode):
         handles = []
         if mode.startswith("hilo"):
+            gn_exact = mode.startswith("hilo_gn")
+            c0 = bench.SD15["block_out_channels"][0]
             for n, m in ou.named_modules():
                 if isinstance(m, ob.ResnetBlock2D):
-                    handles.append(m.norm1.register_forward_pre_hook(pre16))
-                    if m.conv_shortcut is not None and mode != "hilo_sc":
+                    if not gn_exact:
+                        handles.append(m.norm1.register_forward_pre_hook(pre16))
+                    if m.conv_shortcut is not None and mode not in ("hilo_sc", "hilo_gn_sc"):
                         handles.append(m.conv_shortcut.register_forward_pre_hook(pre16))
                 elif isinstance(m, (oi.I2VAdapterTransformer2DModel, ob.TransformerTemporalModel)):
-                    handles.append(m.norm.register_forward_pre_hook(pre16))
+                    if not gn_exact or m.norm.num_channels == c0:          # (64^2 level: folded into proj_in, the operand is the raw hi)
+                        handles.append(m.norm.register_forward_pre_hook(pre16))
                 elif isinstance(m, (ob.Downsample2D, ob.Upsample2D)):
                     handles.append(m.conv.register_forward_pre_hook(pre16))
                 elif n == "conv_norm_out":
-                    handles.append(m.register_forward_pre_hook(pre16))
+                    if not gn_exact:
+                        handles.append(m.register_forward_pre_hook(pre16))
                 elif mode == "hilo_blocks" and (isinstance(m, block_cls) or n.endswith(".proj_in")):
                     handles.append(m.register_forward_hook(lambda mod, a, o: r16(o)))
         if mode in ("outer", "blocks"):
